@@ -1,0 +1,637 @@
+/*
+ * nuts_oracle.c -- CPU restatement of the per-site sampler -- TEST INFRASTRUCTURE.
+ *
+ * PARITY UNPINNED (see oracle/ep_oracle.py header and DESIGN.md): the
+ * reference samples each site's tilted distribution with PyStan 2.17.0.0 /
+ * Stan 2.17 C++ NUTS (/root/reference/README.md:10, epstan/util.py:34,716,
+ * epstan/method.py:43-118), a third-party dependency that is not in
+ * /root/reference and cannot be installed here.  This file restates
+ *   (1) the site log-densities of the reference's own Stan programs
+ *       /root/reference/experiment/models/m{1,2,3,4,5}b_sg.stan (model block,
+ *       transformed parameters) and their analytic gradients,
+ *   (2) Stan 2.17's published sampler: multinomial NUTS with the generalised
+ *       U-turn criterion (stan/mcmc/hmc/nuts/base_nuts.hpp @ v2.17), diagonal
+ *       Euclidean metric, step-size heuristic (base_hmc::init_stepsize),
+ *       dual averaging (stepsize_adaptation.hpp: delta .8, gamma .05, t0 10,
+ *       kappa .75), windowed variance adaptation (windowed_adaptation.hpp,
+ *       var_adaptation.hpp: 75/25/50 buffers, 15%/75%/10% when warm-up < 150).
+ * It is anchored on the reference's call sites (chains/iter/warmup/thin/init,
+ * method.py:154-160; draws concatenated chain-major, util.py:475-484) and
+ * checked by finite differences and Gaussian known answers in tests/.
+ *
+ * The random stream is counter based (Philox4x32-10) and the tree is built
+ * iteratively so that the HIP kernel (ep-stan_amd/csrc/nuts.hip) can follow the
+ * same sequence of decisions; the two are compared draw by draw in tests.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define EPO_MAX_DEPTH_CAP 16
+
+enum { M1B = 0, M2B = 1, M3B = 2, M4B = 3, M5B = 4 };
+enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
+
+/* per-chain statistics written to `stats` (doubles) */
+enum {
+    ST_STEPSIZE_MEAN = 0, /* mean of stepsize__ over ALL iterations (method.py:99-102) */
+    ST_STEPSIZE_FINAL = 1,
+    ST_NLEAP = 2,         /* total leapfrogs == gradient evaluations in trees */
+    ST_NGRAD = 3,         /* all gradient evaluations incl. step-size searches */
+    ST_NDIV = 4,          /* post-warm-up divergent transitions */
+    ST_ACCEPT_MEAN = 5,   /* post-warm-up mean accept_stat */
+    ST_DEPTH_MEAN = 6,    /* post-warm-up mean tree depth */
+    ST_FAIL = 7,          /* 1 if the initial point had a non-finite density */
+    ST_COUNT = 8
+};
+
+/* ------------------------------------------------------------------ dims */
+int epo_dphi(int model, int D) {
+    switch (model) {
+    case M1B: return D + 1;
+    case M2B: return 2;
+    case M3B: return D + 1;
+    case M4B: case M5B: return 2 * D + 2;
+    }
+    return -1;
+}
+int epo_npar(int model, int D) {
+    switch (model) {
+    case M1B: return D + 2;
+    case M2B: return D + 3;
+    case M3B: return 2 * D + 2;
+    case M4B: case M5B: return 3 * D + 3;
+    }
+    return -1;
+}
+
+/* --------------------------------------------------------------- Philox */
+static inline void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                              uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static inline double u01(uint32_t hi, uint32_t lo) {
+    uint64_t v = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+typedef struct { uint32_t k0, k1; } rng_key;
+static inline rng_key make_key(uint64_t seed, int chain) {
+    rng_key k;
+    k.k0 = (uint32_t)seed;
+    k.k1 = (uint32_t)(seed >> 32) ^ (0x85EBCA6Bu * (uint32_t)(chain + 1));
+    return k;
+}
+static inline void rng_u2(rng_key k, uint32_t t, uint32_t kind, uint32_t a, uint32_t b,
+                          double *u1, double *u2) {
+    uint32_t o[4];
+    philox4x32(k.k0, k.k1, t, kind, a, b, o);
+    *u1 = u01(o[0], o[1]);
+    *u2 = u01(o[2], o[3]);
+}
+static inline double rng_uniform(rng_key k, uint32_t t, uint32_t kind, uint32_t a, uint32_t b) {
+    double u1, u2;
+    rng_u2(k, t, kind, a, b, &u1, &u2);
+    return u1;
+}
+/* standard normal for vector element e (Box-Muller pair shared by e, e^1) */
+static inline double rng_normal(rng_key k, uint32_t t, uint32_t kind, int e, uint32_t b) {
+    double u1, u2;
+    rng_u2(k, t, kind, (uint32_t)(e >> 1), b, &u1, &u2);
+    double r = sqrt(-2.0 * log(u1));
+    double a = 6.283185307179586476925286766559 * u2;
+    return (e & 1) ? r * sin(a) : r * cos(a);
+}
+
+/* ----------------------------------------------------------- log density */
+typedef struct {
+    int model, n, D, d, P;
+    const double *X;   /* n x D row-major (C-order view, method.py:829) */
+    const int32_t *y;  /* n, 0/1 */
+    const double *mu;  /* d cavity mean   (Worker.vec, method.py:221) */
+    const double *Om;  /* d x d cavity precision, symmetric (Worker.Mat, :222) */
+    double *beta;      /* D scratch */
+    double *db;        /* D scratch */
+    double *Ov;        /* d scratch */
+} site_t;
+
+/* log(1+exp(-|f|)) and sigmoid(f) sharing one exp */
+static inline void logistic_terms(double f, double y, double *ll, double *g) {
+    double e = exp(-fabs(f));
+    double l1p = log1p(e);
+    double s = (f >= 0) ? 1.0 / (1.0 + e) : e / (1.0 + e);   /* sigmoid(f) */
+    *ll = y * f - (fmax(f, 0.0) + l1p);   /* y f - log(1+e^f), bernoulli_logit */
+    *g = y - s;
+}
+
+/* m*b_sg.stan model blocks; SURVEY.md Appendix A */
+static double site_lp_grad(const site_t *s, const double *th, double *grad) {
+    const int D = s->D, d = s->d, n = s->n, model = s->model;
+    const double *phi = th;
+    const double eta = th[d];
+    const double *etb = th + d + 1;
+    double alpha, sa;
+    double *beta = s->beta;
+    switch (model) {
+    case M1B:
+        sa = exp(phi[0]); alpha = eta * sa;
+        for (int j = 0; j < D; ++j) beta[j] = phi[1 + j];
+        break;
+    case M2B: {
+        sa = exp(phi[0]); alpha = eta * sa;
+        double sb = exp(phi[1]);
+        for (int j = 0; j < D; ++j) beta[j] = etb[j] * sb;
+        break; }
+    case M3B:
+        sa = exp(phi[0]); alpha = eta * sa;
+        for (int j = 0; j < D; ++j) beta[j] = etb[j] * exp(phi[1 + j]);
+        break;
+    default: /* M4B, M5B */
+        sa = exp(phi[1]); alpha = phi[0] + eta * sa;
+        for (int j = 0; j < D; ++j) beta[j] = phi[2 + j] + etb[j] * exp(phi[2 + D + j]);
+        break;
+    }
+    /* y ~ bernoulli_logit(alpha + X*beta): one fused pass over the rows */
+    double ll = 0.0, da = 0.0;
+    double *db = s->db;
+    for (int j = 0; j < D; ++j) db[j] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double *x = s->X + (size_t)i * D;
+        double f = alpha;
+        for (int j = 0; j < D; ++j) f += x[j] * beta[j];
+        double l, g;
+        logistic_terms(f, (double)s->y[i], &l, &g);
+        ll += l; da += g;
+        for (int j = 0; j < D; ++j) db[j] += g * x[j];
+    }
+    /* phi ~ multi_normal_prec(mu_phi, Omega_phi) */
+    double quad = 0.0;
+    for (int i = 0; i < d; ++i) {
+        double acc = 0.0;
+        const double *row = s->Om + (size_t)i * d;
+        for (int j = 0; j < d; ++j) acc += row[j] * (phi[j] - s->mu[j]);
+        s->Ov[i] = acc;
+        quad += (phi[i] - s->mu[i]) * acc;
+    }
+    double lp = -0.5 * quad + ll;
+    for (int i = 0; i < d; ++i) grad[i] = -s->Ov[i];
+    const int laplace = (model == M5B);
+    /* eta, etb ~ normal(0,1) (double_exponential(0,1) for m5b_sg.stan:40-41) */
+    if (laplace) lp -= fabs(eta); else lp -= 0.5 * eta * eta;
+    if (model != M1B) {
+        for (int j = 0; j < D; ++j)
+            lp -= laplace ? fabs(etb[j]) : 0.5 * etb[j] * etb[j];
+    }
+#define SGN(v) (((v) > 0) - ((v) < 0))
+    switch (model) {
+    case M1B:
+        grad[0] += da * eta * sa;
+        for (int j = 0; j < D; ++j) grad[1 + j] += db[j];
+        grad[d] = da * sa - eta;
+        break;
+    case M2B: {
+        double sb = exp(phi[1]), dot = 0.0;
+        for (int j = 0; j < D; ++j) dot += db[j] * etb[j];
+        grad[0] += da * eta * sa;
+        grad[1] += dot * sb;
+        grad[d] = da * sa - eta;
+        for (int j = 0; j < D; ++j) grad[d + 1 + j] = db[j] * sb - etb[j];
+        break; }
+    case M3B:
+        grad[0] += da * eta * sa;
+        for (int j = 0; j < D; ++j) {
+            double sb = exp(phi[1 + j]);
+            grad[1 + j] += db[j] * etb[j] * sb;
+            grad[d + 1 + j] = db[j] * sb - etb[j];
+        }
+        grad[d] = da * sa - eta;
+        break;
+    default:
+        grad[0] += da;
+        grad[1] += da * eta * sa;
+        for (int j = 0; j < D; ++j) {
+            double sb = exp(phi[2 + D + j]);
+            grad[2 + j] += db[j];
+            grad[2 + D + j] += db[j] * etb[j] * sb;
+            grad[d + 1 + j] = db[j] * sb - (laplace ? (double)SGN(etb[j]) : etb[j]);
+        }
+        grad[d] = da * sa - (laplace ? (double)SGN(eta) : eta);
+        break;
+    }
+    return lp;
+}
+
+int epo_logdensity_grad(int model, int n, int D, const double *X, const int32_t *y,
+                        const double *mu, const double *Omega, const double *theta,
+                        double *lp, double *grad) {
+    site_t s;
+    s.model = model; s.n = n; s.D = D; s.d = epo_dphi(model, D); s.P = epo_npar(model, D);
+    if (s.d < 0) return -1;
+    s.X = X; s.y = y; s.mu = mu; s.Om = Omega;
+    s.beta = (double *)malloc(sizeof(double) * (2 * D + s.d));
+    s.db = s.beta + D; s.Ov = s.db + D;
+    *lp = site_lp_grad(&s, theta, grad);
+    free(s.beta);
+    return 0;
+}
+
+/* ------------------------------------------------------------ NUTS chain */
+static inline double log_sum_exp2(double a, double b) {
+    if (a == -INFINITY) return b;
+    if (a == INFINITY && b == INFINITY) return INFINITY;
+    if (a > b) return a + log1p(exp(b - a));
+    return b + log1p(exp(a - b));
+}
+
+typedef struct {
+    int P;
+    double *q, *p, *g;   /* position, momentum, gradient of lp */
+    double lp;
+} zstate;
+
+typedef struct {
+    const site_t *site;
+    rng_key key;
+    int P, max_depth;
+    double *inv_e;        /* diagonal inverse metric */
+    double eps;
+    /* current sample */
+    double *qs, *gs; double lps;
+    /* work vectors */
+    double *zq, *zp, *zg; double zlp;           /* integrator state */
+    double *pq, *pp, *pg; double plp;           /* tree +end */
+    double *mq, *mp, *mg; double mlp;           /* tree -end */
+    double *rho, *psp, *psm;                    /* whole tree */
+    double *n_rho, *n_psl, *n_pq, *n_pg; double n_lw, n_plp;   /* current node */
+    double *psr;                                /* p_sharp of the newest leaf */
+    double *st_rho, *st_psl, *st_pq, *st_pg;    /* stack: [level][P] */
+    double st_lw[EPO_MAX_DEPTH_CAP], st_plp[EPO_MAX_DEPTH_CAP];
+    double *tq, *tg; double tlp;                /* proposal of the new subtree */
+    long ngrad;
+} chain_t;
+
+static inline double kinetic(const chain_t *c, const double *p) {
+    double t = 0.0;
+    for (int i = 0; i < c->P; ++i) t += c->inv_e[i] * p[i] * p[i];
+    return 0.5 * t;
+}
+
+/* expl_leapfrog: half momentum, full position, gradient, half momentum */
+static void leapfrog(chain_t *c, double eps) {
+    const int P = c->P;
+    for (int i = 0; i < P; ++i) c->zp[i] += 0.5 * eps * c->zg[i];
+    for (int i = 0; i < P; ++i) c->zq[i] += eps * c->inv_e[i] * c->zp[i];
+    c->zlp = site_lp_grad(c->site, c->zq, c->zg);
+    c->ngrad++;
+    for (int i = 0; i < P; ++i) c->zp[i] += 0.5 * eps * c->zg[i];
+}
+
+static inline int criterion(const chain_t *c, const double *psm, const double *psp,
+                            const double *rho) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < c->P; ++i) { a += psp[i] * rho[i]; b += psm[i] * rho[i]; }
+    return a > 0 && b > 0;
+}
+
+typedef struct { double accept; int nleap; int depth; int divergent; } trans_info;
+
+/* base_nuts::transition @ Stan 2.17, with build_tree unrolled into a loop over
+ * the 2^depth leaves of the new subtree and a per-level stack of pending left
+ * siblings. */
+static trans_info transition(chain_t *c, uint32_t t) {
+    const int P = c->P;
+    const size_t vb = sizeof(double) * P;
+    trans_info ti = {0.0, 0, 0, 0};
+    /* sample momentum p ~ N(0, M), M = diag(1/inv_e) */
+    for (int i = 0; i < P; ++i)
+        c->pp[i] = rng_normal(c->key, t, K_MOM, i, 0) / sqrt(c->inv_e[i]);
+    memcpy(c->pq, c->qs, vb); memcpy(c->pg, c->gs, vb); c->plp = c->lps;
+    memcpy(c->mq, c->qs, vb); memcpy(c->mg, c->gs, vb); c->mlp = c->lps;
+    memcpy(c->mp, c->pp, vb);
+    for (int i = 0; i < P; ++i) { c->psp[i] = c->inv_e[i] * c->pp[i]; c->psm[i] = c->psp[i]; }
+    memcpy(c->rho, c->pp, vb);
+    double H0 = -c->lps + kinetic(c, c->pp);
+    double lsw = 0.0, sum_metro = 0.0;
+    int depth = 0, nleap = 0, divergent = 0;
+
+    while (depth < c->max_depth) {
+        int fwd = rng_uniform(c->key, t, K_DIR, (uint32_t)depth, 0) > 0.5;
+        double eps = fwd ? c->eps : -c->eps;
+        if (fwd) { memcpy(c->zq, c->pq, vb); memcpy(c->zp, c->pp, vb); memcpy(c->zg, c->pg, vb); c->zlp = c->plp; }
+        else     { memcpy(c->zq, c->mq, vb); memcpy(c->zp, c->mp, vb); memcpy(c->zg, c->mg, vb); c->zlp = c->mlp; }
+        int valid = 1;
+        const int nleaf = 1 << depth;
+        for (int i = 0; i < nleaf; ++i) {
+            leapfrog(c, eps);
+            ++nleap;
+            double h = -c->zlp + kinetic(c, c->zp);
+            if (isnan(h)) h = INFINITY;
+            if (h - H0 > 1000.0) divergent = 1;
+            double dH = H0 - h;
+            sum_metro += (dH > 0) ? 1.0 : exp(dH);
+            if (divergent) { valid = 0; break; }
+            /* depth-0 node */
+            memcpy(c->n_rho, c->zp, vb);
+            for (int j = 0; j < P; ++j) c->psr[j] = c->inv_e[j] * c->zp[j];
+            memcpy(c->n_psl, c->psr, vb);
+            memcpy(c->n_pq, c->zq, vb); memcpy(c->n_pg, c->zg, vb); c->n_plp = c->zlp;
+            c->n_lw = dH;
+            /* merge with pending left siblings while this leaf closes them */
+            int l = 0, ii = i;
+            while (ii & 1) {
+                const double *L_rho = c->st_rho + (size_t)l * P;
+                const double *L_psl = c->st_psl + (size_t)l * P;
+                double lw_new = log_sum_exp2(c->st_lw[l], c->n_lw);
+                double u = rng_uniform(c->key, t, K_MERGE, ((uint32_t)depth << 16) | (uint32_t)i, (uint32_t)l);
+                int take_right = (c->n_lw > lw_new) || (u < exp(c->n_lw - lw_new));
+                if (!take_right) {
+                    memcpy(c->n_pq, c->st_pq + (size_t)l * P, vb);
+                    memcpy(c->n_pg, c->st_pg + (size_t)l * P, vb);
+                    c->n_plp = c->st_plp[l];
+                }
+                for (int j = 0; j < P; ++j) c->n_rho[j] += L_rho[j];
+                memcpy(c->n_psl, L_psl, vb);
+                c->n_lw = lw_new;
+                if (!criterion(c, c->n_psl, c->psr, c->n_rho)) { valid = 0; break; }
+                ii >>= 1; ++l;
+            }
+            if (!valid) break;
+            if (i != nleaf - 1) {
+                memcpy(c->st_rho + (size_t)l * P, c->n_rho, vb);
+                memcpy(c->st_psl + (size_t)l * P, c->n_psl, vb);
+                memcpy(c->st_pq + (size_t)l * P, c->n_pq, vb);
+                memcpy(c->st_pg + (size_t)l * P, c->n_pg, vb);
+                c->st_lw[l] = c->n_lw; c->st_plp[l] = c->n_plp;
+            }
+        }
+        if (fwd) { memcpy(c->pq, c->zq, vb); memcpy(c->pp, c->zp, vb); memcpy(c->pg, c->zg, vb); c->plp = c->zlp; }
+        else     { memcpy(c->mq, c->zq, vb); memcpy(c->mp, c->zp, vb); memcpy(c->mg, c->zg, vb); c->mlp = c->zlp; }
+        if (!valid) break;
+        ++depth;
+        /* biased progressive sampling of the new subtree's proposal */
+        int take;
+        if (c->n_lw > lsw) take = 1;
+        else take = rng_uniform(c->key, t, K_TOP, (uint32_t)(depth - 1), 0) < exp(c->n_lw - lsw);
+        if (take) { memcpy(c->qs, c->n_pq, vb); memcpy(c->gs, c->n_pg, vb); c->lps = c->n_plp; }
+        lsw = log_sum_exp2(lsw, c->n_lw);
+        for (int j = 0; j < P; ++j) c->rho[j] += c->n_rho[j];
+        if (fwd) memcpy(c->psp, c->psr, vb); else memcpy(c->psm, c->psr, vb);
+        if (!criterion(c, c->psm, c->psp, c->rho)) break;
+    }
+    ti.accept = sum_metro / (double)nleap;
+    ti.nleap = nleap; ti.depth = depth; ti.divergent = divergent;
+    return ti;
+}
+
+/* base_hmc::init_stepsize @ Stan 2.17 */
+static void init_stepsize(chain_t *c, uint32_t t) {
+    const int P = c->P;
+    const size_t vb = sizeof(double) * P;
+    if (c->eps == 0 || c->eps > 1e7 || isnan(c->eps)) return;
+    const double log08 = log(0.8);
+    int direction = 0;
+    for (uint32_t trial = 0;; ++trial) {
+        for (int i = 0; i < P; ++i)
+            c->zp[i] = rng_normal(c->key, t, K_SSMOM, i, trial) / sqrt(c->inv_e[i]);
+        memcpy(c->zq, c->qs, vb); memcpy(c->zg, c->gs, vb); c->zlp = c->lps;
+        double H0 = -c->lps + kinetic(c, c->zp);
+        leapfrog(c, c->eps);
+        double h = -c->zlp + kinetic(c, c->zp);
+        if (isnan(h)) h = INFINITY;
+        double dH = H0 - h;
+        if (trial == 0) { direction = dH > log08 ? 1 : -1; continue; }
+        if (direction == 1 && !(dH > log08)) break;
+        else if (direction == -1 && !(dH < log08)) break;
+        else c->eps = direction == 1 ? 2 * c->eps : 0.5 * c->eps;
+        if (c->eps > 1e7 || c->eps == 0) break;
+        if (trial > 200) break;
+    }
+}
+
+typedef struct {
+    int num_warmup, init_buffer, term_buffer, base_window;
+    int counter, window_size, next_window;
+    double nw; double *mean, *m2;
+} var_adapt;
+
+static void va_restart(var_adapt *v) {
+    v->counter = 0; v->window_size = v->base_window;
+    v->next_window = v->init_buffer + v->window_size - 1;
+}
+static void va_init(var_adapt *v, int num_warmup, int P, double *buf) {
+    v->num_warmup = num_warmup; v->init_buffer = 75; v->term_buffer = 50; v->base_window = 25;
+    if (v->init_buffer + v->base_window + v->term_buffer > num_warmup && num_warmup >= 20) {
+        v->init_buffer = (int)(0.15 * num_warmup);
+        v->term_buffer = (int)(0.1 * num_warmup);
+        v->base_window = num_warmup - (v->init_buffer + v->term_buffer);
+    }
+    v->mean = buf; v->m2 = buf + P; v->nw = 0;
+    for (int i = 0; i < 2 * P; ++i) buf[i] = 0.0;
+    va_restart(v);
+}
+/* var_adaptation::learn_variance; returns 1 when the metric was updated */
+static int va_learn(var_adapt *v, double *var, const double *q, int P) {
+    int in_win = (v->counter >= v->init_buffer) &&
+                 (v->counter < v->num_warmup - v->term_buffer) && (v->counter != v->num_warmup);
+    if (in_win) {
+        v->nw += 1.0;
+        for (int i = 0; i < P; ++i) {
+            double delta = q[i] - v->mean[i];
+            v->mean[i] += delta / v->nw;
+            v->m2[i] += (q[i] - v->mean[i]) * delta;
+        }
+    }
+    int end_win = (v->counter == v->next_window) && (v->counter != v->num_warmup);
+    if (end_win) {
+        /* compute_next_window */
+        if (v->next_window != v->num_warmup - v->term_buffer - 1) {
+            v->window_size *= 2;
+            v->next_window = v->counter + v->window_size;
+            if (v->next_window != v->num_warmup - v->term_buffer - 1) {
+                int boundary = v->next_window + 2 * v->window_size;
+                if (boundary >= v->num_warmup - v->term_buffer)
+                    v->next_window = v->num_warmup - v->term_buffer - 1;
+            }
+        }
+        double n = v->nw;
+        for (int i = 0; i < P; ++i) {
+            double s2 = (n > 1.0) ? v->m2[i] / (n - 1.0) : 0.0;
+            var[i] = (n / (n + 5.0)) * s2 + 1e-3 * (5.0 / (n + 5.0));
+        }
+        v->nw = 0;
+        for (int i = 0; i < P; ++i) { v->mean[i] = 0.0; v->m2[i] = 0.0; }
+        ++v->counter;
+        return 1;
+    }
+    ++v->counter;
+    return 0;
+}
+
+/* One chain of one site update: warm-up + sampling. draws: nkeep x P row-major. */
+static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter, int warmup,
+                      int thin, int max_depth, const double *init, double *draws,
+                      double *last, double *stats) {
+    const int P = site_in->P, D = site_in->D, d = site_in->d;
+    site_t site = *site_in;
+    const size_t nvec = 24 + 4 * (size_t)EPO_MAX_DEPTH_CAP;
+    double *buf = (double *)calloc(nvec * P + 2 * D + d, sizeof(double));
+    double *w = buf;
+#define TAKE(ptr) ptr = w; w += P
+    chain_t c;
+    memset(&c, 0, sizeof(c));
+    c.site = &site; c.P = P; c.max_depth = max_depth; c.key = make_key(seed, chain);
+    TAKE(c.inv_e); TAKE(c.qs); TAKE(c.gs); TAKE(c.zq); TAKE(c.zp); TAKE(c.zg);
+    TAKE(c.pq); TAKE(c.pp); TAKE(c.pg); TAKE(c.mq); TAKE(c.mp); TAKE(c.mg);
+    TAKE(c.rho); TAKE(c.psp); TAKE(c.psm); TAKE(c.n_rho); TAKE(c.n_psl); TAKE(c.n_pq);
+    TAKE(c.n_pg); TAKE(c.psr); TAKE(c.tq); TAKE(c.tg);
+    double *vabuf = w; w += 2 * P;
+    c.st_rho = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
+    c.st_psl = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
+    c.st_pq = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
+    c.st_pg = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
+    site.beta = w; site.db = w + D; site.Ov = w + 2 * D;
+    for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0.0;
+
+    for (int i = 0; i < P; ++i) c.inv_e[i] = 1.0;
+    if (init) memcpy(c.qs, init, sizeof(double) * P);
+    else {
+        /* init='random': U(-2,2) on the unconstrained scale */
+        for (int i = 0; i < P; ++i) {
+            double u1, u2;
+            rng_u2(c.key, 0, K_INIT, (uint32_t)(i >> 1), 0, &u1, &u2);
+            c.qs[i] = -2.0 + 4.0 * ((i & 1) ? u2 : u1);
+        }
+    }
+    c.lps = site_lp_grad(&site, c.qs, c.gs);
+    c.ngrad++;
+    int finite = isfinite(c.lps);
+    for (int i = 0; i < P; ++i) finite = finite && isfinite(c.gs[i]);
+    if (!finite) {
+        stats[ST_FAIL] = 1.0;
+        int nkeep = (iter - warmup + thin - 1) / thin;
+        for (int k = 0; k < nkeep; ++k) memcpy(draws + (size_t)k * P, c.qs, sizeof(double) * P);
+        memcpy(last, c.qs, sizeof(double) * P);
+        free(buf);
+        return;
+    }
+    /* stepsize_adaptation */
+    const double delta = 0.8, gamma = 0.05, t0 = 10.0, kappa = 0.75;
+    c.eps = 1.0;
+    double da_mu = log(10.0 * c.eps), s_bar = 0.0, x_bar = 0.0, da_count = 0.0;
+    init_stepsize(&c, 0);
+    var_adapt va;
+    va_init(&va, warmup, P, vabuf);
+    double eps_sum = 0.0, acc_sum = 0.0, depth_sum = 0.0;
+    long nleap = 0; int kept = 0, ndiv = 0, npost = 0;
+    for (int t = 0; t < iter; ++t) {
+        trans_info ti = transition(&c, (uint32_t)(t + 1));
+        eps_sum += c.eps;
+        nleap += ti.nleap;
+        if (t < warmup) {
+            /* learn_stepsize */
+            da_count += 1.0;
+            double a = ti.accept > 1 ? 1 : ti.accept;
+            double eta = 1.0 / (da_count + t0);
+            s_bar = (1.0 - eta) * s_bar + eta * (delta - a);
+            double x = da_mu - s_bar * sqrt(da_count) / gamma;
+            double x_eta = pow(da_count, -kappa);
+            x_bar = (1.0 - x_eta) * x_bar + x_eta * x;
+            c.eps = exp(x);
+            if (va_learn(&va, c.inv_e, c.qs, P)) {
+                init_stepsize(&c, (uint32_t)(t + 1));
+                da_mu = log(10.0 * c.eps);
+                da_count = 0; s_bar = 0; x_bar = 0;
+            }
+            if (t == warmup - 1) c.eps = exp(x_bar);    /* complete_adaptation */
+        } else {
+            acc_sum += ti.accept; depth_sum += ti.depth; ndiv += ti.divergent; ++npost;
+            if ((t - warmup) % thin == 0) {
+                memcpy(draws + (size_t)kept * P, c.qs, sizeof(double) * P);
+                ++kept;
+            }
+        }
+    }
+    memcpy(last, c.qs, sizeof(double) * P);
+    stats[ST_STEPSIZE_MEAN] = eps_sum / (iter > 0 ? iter : 1);
+    stats[ST_STEPSIZE_FINAL] = c.eps;
+    stats[ST_NLEAP] = (double)nleap;
+    stats[ST_NGRAD] = (double)c.ngrad;
+    stats[ST_NDIV] = ndiv;
+    stats[ST_ACCEPT_MEAN] = npost ? acc_sum / npost : 0.0;
+    stats[ST_DEPTH_MEAN] = npost ? depth_sum / npost : 0.0;
+    free(buf);
+}
+
+/*
+ * Sample `nsites` independent sites (contiguous row blocks k_lim[k]..k_lim[k+1]
+ * of X/y, like method.py:829-830).
+ *   mu:    nsites x d        cavity means
+ *   Omega: nsites x d x d    cavity precisions (symmetric)
+ *   seeds: nsites            the per-site "stan seed" of method.py:346
+ *   init:  nsites x chains x P or NULL (init='random')
+ *   draws: nsites x chains x nkeep x P
+ *   last:  nsites x chains x P
+ *   stats: nsites x chains x ST_COUNT
+ * (site, chain) pairs are spread over `nthreads` OpenMP threads.
+ */
+int epo_nuts_sites(int model, int nsites, int D, const int64_t *k_lim, const double *X,
+                   const int32_t *y, const double *mu, const double *Omega,
+                   const int64_t *seeds, int chains, int iter, int warmup, int thin,
+                   int max_depth, const double *init, double *draws, double *last,
+                   double *stats, int nthreads) {
+    const int d = epo_dphi(model, D), P = epo_npar(model, D);
+    if (d < 0 || max_depth > EPO_MAX_DEPTH_CAP || thin < 1 || warmup > iter) return -1;
+    const int nkeep = (iter - warmup + thin - 1) / thin;
+    const long njobs = (long)nsites * chains;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (long job = 0; job < njobs; ++job) {
+        int k = (int)(job / chains), c = (int)(job % chains);
+        site_t s;
+        s.model = model; s.D = D; s.d = d; s.P = P;
+        s.n = (int)(k_lim[k + 1] - k_lim[k]);
+        s.X = X + (size_t)k_lim[k] * D; s.y = y + k_lim[k];
+        s.mu = mu + (size_t)k * d; s.Om = Omega + (size_t)k * d * d;
+        s.beta = s.db = s.Ov = NULL;
+        size_t jc = (size_t)k * chains + c;
+        run_chain(&s, (uint64_t)seeds[k], c, iter, warmup, thin, max_depth,
+                  init ? init + jc * P : NULL, draws + jc * nkeep * P, last + jc * P,
+                  stats + jc * ST_COUNT);
+    }
+    return 0;
+}
+
+int epo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* raw uniforms / normals of the shared stream, for RNG parity tests */
+void epo_rng_probe(uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a, uint32_t b,
+                   double *u1, double *u2, double *n0, double *n1) {
+    rng_key k = make_key(seed, chain);
+    rng_u2(k, t, kind, a, b, u1, u2);
+    *n0 = rng_normal(k, t, kind, (int)(2 * a), b);
+    *n1 = rng_normal(k, t, kind, (int)(2 * a + 1), b);
+}

@@ -1,0 +1,116 @@
+"""ctypes loader for oracle/libepx_oracle.so (nuts_oracle.c) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'libepx_oracle.so')
+
+MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4}
+STAT_NAMES = ('stepsize_mean', 'stepsize_final', 'nleap', 'ngrad', 'ndiv',
+              'accept_mean', 'depth_mean', 'fail')
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, 'nuts_oracle.c')
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-s', '-C', HERE, 'libepx_oracle.so'])
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+        _lib.epo_dphi.restype = ctypes.c_int
+        _lib.epo_npar.restype = ctypes.c_int
+        _lib.epo_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a, t=ctypes.c_double):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def dims(model, D):
+    L = lib()
+    m = MODEL_IDS[model]
+    return L.epo_dphi(m, D), L.epo_npar(m, D)
+
+
+def logdensity_grad(model, X, y, mu, Omega, theta):
+    L = lib()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    Om = np.ascontiguousarray(Omega, dtype=np.float64)
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    n, D = X.shape
+    lp = ctypes.c_double()
+    g = np.zeros(th.shape[0])
+    rc = L.epo_logdensity_grad(MODEL_IDS[model], n, D, _p(X), _p(y, ctypes.c_int32),
+                               _p(mu), _p(Om), _p(th), ctypes.byref(lp), _p(g))
+    assert rc == 0
+    return lp.value, g
+
+
+def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=None,
+               thin=1, max_depth=10, init=None, nthreads=0):
+    """Sample every site; returns (draws (K,chains,nkeep,P), last (K,chains,P),
+    stats (K,chains,8)). mu (K,d), Omega (K,d,d) symmetric."""
+    L = lib()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
+    K = k_lim.shape[0] - 1
+    D = X.shape[1]
+    d, P = dims(model, D)
+    mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(K, d)
+    Om = np.ascontiguousarray(Omega, dtype=np.float64).reshape(K, d, d)
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    if warmup is None:
+        warmup = iter // 2
+    nkeep = (iter - warmup + thin - 1) // thin
+    draws = np.zeros((K, chains, nkeep, P))
+    last = np.zeros((K, chains, P))
+    stats = np.zeros((K, chains, 8))
+    ip = None
+    if init is not None:
+        init = np.ascontiguousarray(init, dtype=np.float64).reshape(K, chains, P)
+        ip = _p(init)
+    rc = L.epo_nuts_sites(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64), _p(X),
+                          _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
+                          chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
+                          _p(stats), nthreads)
+    if rc != 0:
+        raise ValueError('epo_nuts_sites rc=%d' % rc)
+    return draws, last, stats
+
+
+def rng_probe(seed, chain, t, kind, a, b):
+    L = lib()
+    out = [ctypes.c_double() for _ in range(4)]
+    L.epo_rng_probe(ctypes.c_uint64(seed), chain, ctypes.c_uint32(t), ctypes.c_uint32(kind),
+                    ctypes.c_uint32(a), ctypes.c_uint32(b), *[ctypes.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def split_rhat(x):
+    """PyStan 2.17 split R-hat of one scalar quantity, x: (chains, n)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[1] - (x.shape[1] % 2)
+    h = n // 2
+    halves = np.concatenate([x[:, :h], x[:, x.shape[1] - h:]], axis=0)
+    means = halves.mean(axis=1)
+    vars_ = halves.var(axis=1, ddof=1)
+    var_between = h * means.var(ddof=1)
+    var_within = vars_.mean()
+    return np.sqrt((var_between / var_within + h - 1) / h)
