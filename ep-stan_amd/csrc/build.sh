@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libepx.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-parameter"
+mkdir -p build
+pids=()
+for f in dense nuts epx_api; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ epx_kernels.h -nt build/$f.o ] || [ epx_device.h -nt build/$f.o ] || [ ../../include/epx.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libepx.so build/dense.o build/nuts.o build/epx_api.o
+echo "built $(cd .. && pwd)/libepx.so"

@@ -1,0 +1,769 @@
+// C-ABI of libepx.so (include/epx.h): context management, host<->device
+// copies and kernel launches.  No CPU fallback exists: without a HIP device
+// every entry point fails with an error message.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/epx.h"
+#include "epx_kernels.h"
+
+using namespace epx;
+
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIPCHK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static const size_t LDS_CAP = 160 * 1024;
+
+struct epx_ctx {
+    int device, model, K, D, d, P;
+    int64_t N;
+    hipStream_t stream;
+    std::vector<int64_t> k_lim;
+    int n_max;
+    // device buffers
+    int64_t *k_lim_d;
+    double *X;
+    uint8_t *y;
+    double *Q0, *r0, *Q, *r, *S, *m;
+    double *Qi, *ri, *Qi2, *ri2, *dQi, *dri;
+    double *cav_Om, *cav_mu;
+    double *tilt_mean, *tilt_scatter;
+    uint8_t *flags;
+    int *iflags;              // [4]
+    double *packed, *partial; // sums
+    int nslice;
+    double *dense_ws;         // global workspace for dense kernels (lazily sized)
+    size_t dense_ws_slots;
+    // sampler buffers (lazily sized)
+    int s_chains, s_nkeep;
+    double *draws, *last, *chain_stats, *site_stats, *stack;
+    size_t stack_elems;
+    int64_t *seeds_d;
+    double *dbg;              // [1+P] lp, grad ; [P] theta (test hook)
+    int64_t *dbg_seed;
+    double *inj;              // injected samples (test hook)
+    size_t inj_elems;
+    int has_last;
+    int nsamp;                // draws per site of the last tilted/moments call
+    double last_df;
+    hipEvent_t ev0, ev1;
+};
+
+const char *epx_last_error(void) { return g_err.c_str(); }
+
+int epx_device_count(int *count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail("hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return 0;
+}
+
+int epx_model_dims(int model, int D, int *dphi, int *npar) {
+    int d, P;
+    switch (model) {
+    case EPX_M1B_SG: d = D + 1; P = D + 2; break;
+    case EPX_M2B_SG: d = 2; P = D + 3; break;
+    case EPX_M3B_SG: d = D + 1; P = 2 * D + 2; break;
+    case EPX_M4B_SG: case EPX_M5B_SG: d = 2 * D + 2; P = 3 * D + 3; break;
+    default: return fail("unknown model id %d", model);
+    }
+    if (dphi) *dphi = d;
+    if (npar) *npar = P;
+    return 0;
+}
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+}
+
+static inline int ld_of(int d) { return d | 1; }
+static inline size_t dense_slot_doubles(int d) { return 2 * (size_t)d * ld_of(d) + 4 * (size_t)ld_of(d); }
+
+// LDS or global workspace for `nblocks` concurrent dense blocks
+static int dense_ws(epx_ctx *c, int d, int nblocks, DenseWs *ws, size_t *lds_bytes) {
+    const size_t bytes = dense_slot_doubles(d) * 8;
+    if (bytes + 1024 <= LDS_CAP) { ws->use_lds = 1; ws->global = nullptr; *lds_bytes = bytes; return 0; }
+    ws->use_lds = 0; *lds_bytes = 0;
+    if (c->dense_ws_slots < (size_t)nblocks) {
+        if (c->dense_ws) (void)hipFree(c->dense_ws);
+        HIPCHK(dalloc(&c->dense_ws, dense_slot_doubles(d) * nblocks));
+        c->dense_ws_slots = nblocks;
+    }
+    ws->global = c->dense_ws;
+    return 0;
+}
+
+template <typename K>
+static int set_lds(K kern, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail("hipFuncSetAttribute(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
+                   const int32_t *y, epx_ctx **out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("no HIP device available: libepx has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
+    int d, P;
+    if (epx_model_dims(model, D, &d, &P)) return -1;
+    if (K_local < 1) return fail("K_local must be >= 1");
+    if (D < 1) return fail("D must be >= 1");
+    HIPCHK(hipSetDevice(device));
+    epx_ctx *c = new epx_ctx();
+    memset((void *)c, 0, sizeof(int) * 6);
+    c->device = device; c->model = model; c->K = K_local; c->D = D; c->d = d; c->P = P;
+    c->k_lim.assign(k_lim, k_lim + K_local + 1);
+    c->N = k_lim[K_local] - k_lim[0];
+    c->n_max = 0;
+    for (int k = 0; k < K_local; ++k) {
+        const int64_t n = k_lim[k + 1] - k_lim[k];
+        if (n < 1) { delete c; return fail("site %d is empty", k); }
+        if (n > c->n_max) c->n_max = (int)n;
+    }
+    if (k_lim[0] != 0) { delete c; return fail("k_lim[0] must be 0 (rows are rank-local)"); }
+    c->dense_ws = nullptr; c->dense_ws_slots = 0;
+    c->draws = c->last = c->chain_stats = c->site_stats = c->stack = nullptr;
+    c->seeds_d = nullptr; c->inj = nullptr; c->inj_elems = 0; c->stack_elems = 0;
+    c->s_chains = 0; c->s_nkeep = 0; c->has_last = 0; c->nsamp = 0; c->last_df = 0.0;
+    HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    const size_t K = K_local, d2 = (size_t)d * d;
+    HIPCHK(dalloc(&c->k_lim_d, K + 1));
+    HIPCHK(dalloc(&c->X, (size_t)c->N * D));
+    HIPCHK(dalloc(&c->y, (size_t)c->N));
+    HIPCHK(dalloc(&c->Q0, d2)); HIPCHK(dalloc(&c->r0, d));
+    HIPCHK(dalloc(&c->Q, d2)); HIPCHK(dalloc(&c->r, d));
+    HIPCHK(dalloc(&c->S, d2)); HIPCHK(dalloc(&c->m, d));
+    HIPCHK(dalloc(&c->Qi, K * d2)); HIPCHK(dalloc(&c->ri, K * d));
+    HIPCHK(dalloc(&c->Qi2, K * d2)); HIPCHK(dalloc(&c->ri2, K * d));
+    HIPCHK(dalloc(&c->dQi, K * d2)); HIPCHK(dalloc(&c->dri, K * d));
+    HIPCHK(dalloc(&c->cav_Om, K * d2)); HIPCHK(dalloc(&c->cav_mu, K * d));
+    HIPCHK(dalloc(&c->tilt_mean, K * d)); HIPCHK(dalloc(&c->tilt_scatter, K * d2));
+    HIPCHK(dalloc(&c->flags, K));
+    HIPCHK(dalloc(&c->iflags, 4));
+    HIPCHK(dalloc(&c->dbg, 2 * (size_t)P + 1));
+    HIPCHK(dalloc(&c->dbg_seed, 1));
+    const int len = 2 * (int)(d2 + d);
+    c->nslice = K_local >= 64 ? 32 : 1;
+    HIPCHK(dalloc(&c->packed, len));
+    HIPCHK(dalloc(&c->partial, (size_t)len * c->nslice));
+    HIPCHK(hipMemcpy(c->k_lim_d, k_lim, (K + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->X, X, (size_t)c->N * D * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<uint8_t> yb((size_t)c->N);
+        for (int64_t i = 0; i < c->N; ++i) {
+            if (y[i] != 0 && y[i] != 1) { epx_ctx_destroy(c); return fail("y[%lld] = %d is not 0/1", (long long)i, y[i]); }
+            yb[i] = (uint8_t)y[i];
+        }
+        HIPCHK(hipMemcpy(c->y, yb.data(), yb.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemset(c->Qi, 0, K * d2 * 8)); HIPCHK(hipMemset(c->ri, 0, K * d * 8));
+    HIPCHK(hipMemset(c->Qi2, 0, K * d2 * 8)); HIPCHK(hipMemset(c->ri2, 0, K * d * 8));
+    HIPCHK(hipMemset(c->dQi, 0, K * d2 * 8)); HIPCHK(hipMemset(c->dri, 0, K * d * 8));
+    HIPCHK(hipMemset(c->Q0, 0, d2 * 8)); HIPCHK(hipMemset(c->r0, 0, d * 8));
+    HIPCHK(hipMemset(c->Q, 0, d2 * 8)); HIPCHK(hipMemset(c->r, 0, d * 8));
+    HIPCHK(hipMemset(c->flags, 0, K));
+    *out = c;
+    return 0;
+}
+
+int epx_ctx_destroy(epx_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    void *ptrs[] = {c->k_lim_d, c->X, c->y, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+                    c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
+                    c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
+                    c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+#define CTX(c)                                      \
+    if (!(c)) return fail("null context");          \
+    HIPCHK(hipSetDevice((c)->device));
+
+int epx_set_prior(epx_ctx *c, const double *Q0, const double *r0) {
+    CTX(c);
+    HIPCHK(hipMemcpy(c->Q0, Q0, (size_t)c->d * c->d * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->r0, r0, (size_t)c->d * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int check_range(epx_ctx *c, int k0, int count) {
+    if (k0 < 0 || count < 1 || k0 + count > c->K) return fail("site range [%d,%d) outside [0,%d)", k0, k0 + count, c->K);
+    return 0;
+}
+
+static int site_ptrs(epx_ctx *c, int which, double **Q, double **r) {
+    switch (which) {
+    case EPX_QI: *Q = c->Qi; *r = c->ri; return 0;
+    case EPX_QI2: *Q = c->Qi2; *r = c->ri2; return 0;
+    case EPX_DQI: *Q = c->dQi; *r = c->dri; return 0;
+    }
+    return fail("unknown site array %d", which);
+}
+
+int epx_set_sites(epx_ctx *c, int which, const double *QF, const double *rF) {
+    CTX(c);
+    double *Q, *r;
+    if (site_ptrs(c, which, &Q, &r)) return -1;
+    const size_t K = c->K, d = c->d;
+    if (QF) HIPCHK(hipMemcpy(Q, QF, K * d * d * 8, hipMemcpyHostToDevice));
+    if (rF) HIPCHK(hipMemcpy(r, rF, K * d * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int epx_get_sites(epx_ctx *c, int which, double *QF, double *rF) {
+    CTX(c);
+    double *Q, *r;
+    if (site_ptrs(c, which, &Q, &r)) return -1;
+    const size_t K = c->K, d = c->d;
+    if (which == EPX_QI2) {
+        // materialise the proposal Qi + df*dQi of the last trial (method.py:1071-1072)
+        hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, c->stream, c->Qi2, c->Qi, c->dQi, c->last_df, K * d * d);
+        hipLaunchKernelGGL(k_axpy, dim3(64), dim3(256), 0, c->stream, c->ri2, c->ri, c->dri, c->last_df, K * d);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (QF) HIPCHK(hipMemcpy(QF, Q, K * d * d * 8, hipMemcpyDeviceToHost));
+    if (rF) HIPCHK(hipMemcpy(rF, r, K * d * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_set_site(epx_ctx *c, int which, int k, const double *Qh, const double *rh) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    double *Q, *r;
+    if (site_ptrs(c, which, &Q, &r)) return -1;
+    const size_t d = c->d;
+    if (Qh) HIPCHK(hipMemcpy(Q + (size_t)k * d * d, Qh, d * d * 8, hipMemcpyHostToDevice));
+    if (rh) HIPCHK(hipMemcpy(r + (size_t)k * d, rh, d * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int epx_get_site(epx_ctx *c, int which, int k, double *Qh, double *rh) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    double *Q, *r;
+    if (site_ptrs(c, which, &Q, &r)) return -1;
+    if (which == EPX_QI2) return fail("epx_get_site: use epx_get_sites for the proposal array");
+    const size_t d = c->d;
+    if (Qh) HIPCHK(hipMemcpy(Qh, Q + (size_t)k * d * d, d * d * 8, hipMemcpyDeviceToHost));
+    if (rh) HIPCHK(hipMemcpy(rh, r + (size_t)k * d, d * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_set_global(epx_ctx *c, const double *Q, const double *r) {
+    CTX(c);
+    if (Q) HIPCHK(hipMemcpy(c->Q, Q, (size_t)c->d * c->d * 8, hipMemcpyHostToDevice));
+    if (r) HIPCHK(hipMemcpy(c->r, r, (size_t)c->d * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+int epx_get_global(epx_ctx *c, double *Q, double *r) {
+    CTX(c);
+    if (Q) HIPCHK(hipMemcpy(Q, c->Q, (size_t)c->d * c->d * 8, hipMemcpyDeviceToHost));
+    if (r) HIPCHK(hipMemcpy(r, c->r, (size_t)c->d * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int launch_cavity(epx_ctx *c, const double *Qs, const double *rs, const double *dQs,
+                         const double *drs, double df, int k0, int count) {
+    CavityArgs a;
+    a.k0 = k0; a.d = c->d; a.ld = ld_of(c->d);
+    size_t lds;
+    if (dense_ws(c, c->d, count, &a.ws, &lds)) return -1;
+    a.Q = c->Q; a.r = c->r; a.Qsite = Qs; a.rsite = rs; a.dQsite = dQs; a.drsite = drs;
+    a.site_stride = (size_t)c->d * c->d; a.rsite_stride = c->d; a.df = df;
+    a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu; a.flags = c->flags;
+    if (set_lds(k_cavity, lds)) return -1;
+    hipLaunchKernelGGL(k_cavity, dim3(count), dim3(256), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int epx_cavity_batch(epx_ctx *c, int which, int k0, int count, uint8_t *posdef) {
+    CTX(c);
+    if (check_range(c, k0, count)) return -1;
+    int rc;
+    if (which == EPX_QI) rc = launch_cavity(c, c->Qi, c->ri, nullptr, nullptr, 0.0, k0, count);
+    else if (which == EPX_QI2) rc = launch_cavity(c, c->Qi, c->ri, c->dQi, c->dri, c->last_df, k0, count);
+    else return fail("cavity needs EPX_QI or EPX_QI2");
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (posdef) HIPCHK(hipMemcpy(posdef, c->flags + k0, count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_cavity_site(epx_ctx *c, int k, const double *Q, const double *r, const double *Qi,
+                    const double *ri, uint8_t *posdef) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    const size_t d = c->d;
+    // the caller's arrays become the context's state for this site (Worker.cavity
+    // aliases Q, r: method.py:286-287)
+    HIPCHK(hipMemcpy(c->Q, Q, d * d * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->r, r, d * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->Qi2 + (size_t)k * d * d, Qi, d * d * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->ri2 + (size_t)k * d, ri, d * 8, hipMemcpyHostToDevice));
+    if (launch_cavity(c, c->Qi2, c->ri2, nullptr, nullptr, 0.0, k, 1)) return -1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (posdef) HIPCHK(hipMemcpy(posdef, c->flags + k, 1, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_get_cavity(epx_ctx *c, int k, double *Mat, double *vec) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    const size_t d = c->d;
+    if (Mat) HIPCHK(hipMemcpy(Mat, c->cav_Om + (size_t)k * d * d, d * d * 8, hipMemcpyDeviceToHost));
+    if (vec) HIPCHK(hipMemcpy(vec, c->cav_mu + (size_t)k * d, d * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------ sampler
+static int norm_opts(const epx_sampler_opts *o, epx_sampler_opts *n) {
+    if (!o) return fail("null sampler options");
+    *n = *o;
+    if (n->chains < 1 || n->chains > 16) return fail("chains must be in 1..16 (got %d)", n->chains);
+    if (n->iter < 1) return fail("iter must be >= 1");
+    if (n->warmup < 0) n->warmup = n->iter / 2;                 // method.py:157,567-569
+    if (n->warmup >= n->iter) return fail("warmup (%d) must be smaller than iter (%d)", n->warmup, n->iter);
+    if (n->thin < 1) return fail("thin must be >= 1");
+    if (n->max_depth <= 0) n->max_depth = 10;
+    if (n->max_depth > MAX_DEPTH_CAP) return fail("max_depth > %d", MAX_DEPTH_CAP);
+    if (n->init < 0 || n->init > 2) return fail("bad init mode");
+    return 0;
+}
+
+static int ensure_sampler_buffers(epx_ctx *c, int chains, int nkeep) {
+    const size_t K = c->K, P = c->P;
+    if (c->s_chains != chains || c->s_nkeep != nkeep) {
+        if (c->draws) (void)hipFree(c->draws);
+        if (c->last) (void)hipFree(c->last);
+        if (c->chain_stats) (void)hipFree(c->chain_stats);
+        if (c->site_stats) (void)hipFree(c->site_stats);
+        if (c->seeds_d) (void)hipFree(c->seeds_d);
+        c->draws = c->last = c->chain_stats = c->site_stats = nullptr; c->seeds_d = nullptr;
+        HIPCHK(dalloc(&c->draws, K * chains * nkeep * P));
+        HIPCHK(dalloc(&c->last, K * chains * P));
+        HIPCHK(dalloc(&c->chain_stats, K * chains * ST_COUNT));
+        HIPCHK(dalloc(&c->site_stats, K * 8));
+        HIPCHK(dalloc(&c->seeds_d, K));
+        HIPCHK(hipMemset(c->last, 0, K * chains * P * 8));
+        HIPCHK(hipMemset(c->chain_stats, 0, K * chains * ST_COUNT * 8));
+        c->s_chains = chains; c->s_nkeep = nkeep; c->has_last = 0;
+    }
+    return 0;
+}
+
+static int pad_dp(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : -1; }
+
+static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts &o, NutsArgs &a,
+                           int *wpc_out, int *dp_out, int *nv_out) {
+    const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
+    const int dp = pad_dp(c->D);
+    if (dp < 0) return fail("D = %d > 32: the streaming-X sampler variant is not built yet", c->D);
+    const int nv = (c->P + 63) / 64;
+    if (nv > 2) return fail("P = %d > 128 sampled coordinates not supported yet", c->P);
+    memset(&a, 0, sizeof a);
+    a.model = c->model; a.D = c->D; a.d = c->d; a.P = c->P; a.k0 = k0;
+    a.chains = o.chains; a.iter = o.iter; a.warmup = o.warmup; a.thin = o.thin; a.nkeep = nkeep;
+    a.max_depth = o.max_depth; a.init_mode = o.init;
+    a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
+    // layout: one block per site when there are enough sites to fill the 256 CUs,
+    // else one block per (site, chain) with 4 cooperating waves
+    int layout = o.layout;
+    if (layout == 0) layout = count >= 192 ? 1 : 2;
+    int wpc;
+    if (layout == 1) { wpc = 1; a.cpb = o.chains < 4 ? o.chains : 4; }
+    else { wpc = 4; a.cpb = 1; }
+    const size_t lds = nuts_lds_layout(a, wpc, dp, c->n_max);
+    if (lds > LDS_CAP)
+        return fail("site rows do not fit LDS (%zu B > %zu B): n_max=%d, D=%d; streaming variant not built yet",
+                    lds, LDS_CAP, c->n_max, c->D);
+    if (!a.stack_in_lds) {
+        const size_t need = (size_t)count * o.chains * o.max_depth * (4 * nv * 64 + 2);
+        if (c->stack_elems < need) {
+            if (c->stack) (void)hipFree(c->stack);
+            HIPCHK(dalloc(&c->stack, need));
+            c->stack_elems = need;
+        }
+        a.stack = c->stack;
+    }
+    *wpc_out = wpc; *dp_out = dp; *nv_out = nv;
+    return 0;
+}
+
+static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, const epx_sampler_opts &o,
+                       double *elapsed_ms) {
+    const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
+    if (ensure_sampler_buffers(c, o.chains, nkeep)) return -1;
+    if (o.init == EPX_INIT_PREV && !c->has_last) return fail("init=PREV before any sampling call");
+    NutsArgs a;
+    int wpc, dp, nv;
+    if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv)) return -1;
+    a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
+    HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    int rc = launch_nuts(a, count, wpc, dp, nv, c->stream);
+    if (rc != 0) return fail("NUTS kernel launch failed (%d: %s)", rc, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    RhatArgs ra;
+    ra.k0 = k0; ra.chains = o.chains; ra.nkeep = nkeep; ra.P = c->P;
+    ra.draws = c->draws; ra.chain_stats = c->chain_stats; ra.site_stats = c->site_stats;
+    hipLaunchKernelGGL(k_site_stats, dim3(count), dim3(128), 0, c->stream, ra);
+    HIPCHK(hipGetLastError());
+    c->has_last = 1;
+    c->nsamp = o.chains * nkeep;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (elapsed_ms) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        *elapsed_ms = ms;
+    }
+    return 0;
+}
+
+static int launch_moments(epx_ctx *c, int k0, int count, const double *draws, long site0,
+                          long stride_site, long stride_s, long stride_i, int S, int prec_estim) {
+    if (prec_estim != EPX_PREC_SAMPLE && prec_estim != EPX_PREC_OLSE) return fail("bad prec_estim %d", prec_estim);
+    if (S < c->d) return fail("fewer draws (%d) than dimensions (%d)", S, c->d);   // method.py:427 raises ValueError
+    MomentArgs a;
+    a.k0 = k0; a.d = c->d; a.ld = ld_of(c->d); a.S = S; a.prec_estim = prec_estim;
+    size_t lds;
+    if (dense_ws(c, c->d, count, &a.ws, &lds)) return -1;
+    a.draws = draws; a.draws_site0 = site0; a.stride_site = stride_site; a.stride_s = stride_s; a.stride_i = stride_i;
+    a.Q = c->Q; a.r = c->r; a.dQi = c->dQi; a.dri = c->dri;
+    a.tilt_mean = c->tilt_mean; a.tilt_scatter = c->tilt_scatter; a.flags = c->flags;
+    if (set_lds(k_moments, lds)) return -1;
+    hipLaunchKernelGGL(k_moments, dim3(count), dim3(256), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int epx_sample_batch(epx_ctx *c, int k0, int count, const int64_t *seeds, const epx_sampler_opts *opts,
+                     double *stats, double *elapsed_ms) {
+    CTX(c);
+    if (check_range(c, k0, count)) return -1;
+    epx_sampler_opts o;
+    if (norm_opts(opts, &o)) return -1;
+    if (run_sampler(c, k0, count, seeds, o, elapsed_ms)) return -1;
+    if (stats) HIPCHK(hipMemcpy(stats, c->site_stats, (size_t)count * 8 * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_tilted_batch(epx_ctx *c, int k0, int count, const int64_t *seeds, const epx_sampler_opts *opts,
+                     int prec_estim, uint8_t *posdef, double *stats, double *elapsed_ms) {
+    CTX(c);
+    if (check_range(c, k0, count)) return -1;
+    epx_sampler_opts o;
+    if (norm_opts(opts, &o)) return -1;
+    if (run_sampler(c, k0, count, seeds, o, elapsed_ms)) return -1;
+    const int nkeep = c->s_nkeep;
+    // native draw layout: (site, chain, keep, P) -> draw s = chain*nkeep + keep is contiguous
+    if (launch_moments(c, k0, count, c->draws, k0, (long)o.chains * nkeep * c->P, c->P, 1,
+                       o.chains * nkeep, prec_estim)) return -1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (posdef) HIPCHK(hipMemcpy(posdef, c->flags + k0, count, hipMemcpyDeviceToHost));
+    if (stats) HIPCHK(hipMemcpy(stats, c->site_stats, (size_t)count * 8 * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_moments_batch(epx_ctx *c, int k0, int count, const double *samples, int S, int prec_estim,
+                      uint8_t *posdef) {
+    CTX(c);
+    if (check_range(c, k0, count)) return -1;
+    const size_t need = (size_t)count * S * c->d;
+    if (c->inj_elems < need) {
+        if (c->inj) (void)hipFree(c->inj);
+        HIPCHK(dalloc(&c->inj, need));
+        c->inj_elems = need;
+    }
+    HIPCHK(hipMemcpy(c->inj, samples, need * 8, hipMemcpyHostToDevice));
+    // (S, d) F-order per site: element (s, i) at i*S + s
+    if (launch_moments(c, k0, count, c->inj, 0, (long)S * c->d, 1, S, S, prec_estim)) return -1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->nsamp = S;
+    if (posdef) HIPCHK(hipMemcpy(posdef, c->flags + k0, count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_get_tilted(epx_ctx *c, int k, double *Mat, double *vec, int *nsamp) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    const size_t d = c->d;
+    if (Mat) HIPCHK(hipMemcpy(Mat, c->tilt_scatter + (size_t)k * d * d, d * d * 8, hipMemcpyDeviceToHost));
+    if (vec) HIPCHK(hipMemcpy(vec, c->tilt_mean + (size_t)k * d, d * 8, hipMemcpyDeviceToHost));
+    if (nsamp) *nsamp = c->nsamp;
+    return 0;
+}
+
+int epx_num_draws(epx_ctx *c, int *S) {
+    if (!c) return fail("null context");
+    *S = c->s_chains * c->s_nkeep;
+    return 0;
+}
+
+int epx_get_draws(epx_ctx *c, int k, int all_params, double *out) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    if (!c->draws) return fail("no draws yet");
+    const size_t S = (size_t)c->s_chains * c->s_nkeep, P = c->P;
+    std::vector<double> tmp(S * P);
+    HIPCHK(hipMemcpy(tmp.data(), c->draws + (size_t)k * S * P, S * P * 8, hipMemcpyDeviceToHost));
+    const size_t ncol = all_params ? P : (size_t)c->d;
+    for (size_t j = 0; j < ncol; ++j)
+        for (size_t s = 0; s < S; ++s) out[j * S + s] = tmp[s * P + j];      // (S, ncol) F-order
+    return 0;
+}
+
+int epx_get_chain_stats(epx_ctx *c, int k0, int count, double *out) {
+    CTX(c);
+    if (check_range(c, k0, count)) return -1;
+    if (!c->chain_stats) return fail("no sampling call yet");
+    HIPCHK(hipMemcpy(out, c->chain_stats + (size_t)k0 * c->s_chains * ST_COUNT,
+                     (size_t)count * c->s_chains * ST_COUNT * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_logdensity_grad(epx_ctx *c, int k, const double *theta, double *lp, double *grad) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    // the sampler kernel itself evaluates the initial point and stops (NutsArgs::dbg)
+    epx_sampler_opts o;
+    memset(&o, 0, sizeof o);
+    o.chains = 1; o.iter = 2; o.warmup = 1; o.thin = 1; o.init = EPX_INIT_PREV; o.max_depth = 10; o.layout = 2;
+    NutsArgs a;
+    int wpc, dp, nv;
+    if (build_nuts_args(c, k, 1, o, a, &wpc, &dp, &nv)) return -1;
+    const size_t P = c->P;
+    HIPCHK(hipMemcpy(c->dbg + P + 1, theta, P * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->dbg_seed, 0, sizeof(int64_t)));
+    a.seeds = c->dbg_seed;
+    a.last = c->dbg + P + 1 - (size_t)k * P;      // kernel reads last[(k*chains + chain)*P], chains = 1
+    a.dbg = c->dbg;
+    int rc = launch_nuts(a, 1, wpc, dp, nv, c->stream);
+    if (rc != 0) return fail("NUTS kernel launch failed (%d)", rc);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<double> outv(P + 1);
+    HIPCHK(hipMemcpy(outv.data(), c->dbg, (P + 1) * 8, hipMemcpyDeviceToHost));
+    *lp = outv[0];
+    memcpy(grad, outv.data() + 1, P * 8);
+    return 0;
+}
+
+// ------------------------------------------------------------- global update
+int epx_packed_len(epx_ctx *c, int *len) {
+    if (!c) return fail("null context");
+    *len = 2 * (c->d * c->d + c->d);
+    return 0;
+}
+
+int epx_site_sums(epx_ctx *c, double *packed_host, double *packed_dev) {
+    CTX(c);
+    SumArgs a;
+    a.K = c->K; a.d = c->d; a.len = 2 * (c->d * c->d + c->d); a.nslice = c->nslice;
+    a.Qi = c->Qi; a.ri = c->ri; a.dQi = c->dQi; a.dri = c->dri;
+    a.partial = c->partial; a.out = packed_dev ? packed_dev : c->packed;
+    const int nb = (a.len + 255) / 256;
+    hipLaunchKernelGGL(k_site_sums_partial, dim3(nb, a.nslice), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_site_sums_final, dim3(nb), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (packed_host) HIPCHK(hipMemcpy(packed_host, a.out, (size_t)a.len * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int launch_global(epx_ctx *c, const double *packed_dev, double df, int want_moments) {
+    GlobalArgs a;
+    a.d = c->d; a.ld = ld_of(c->d); a.want_moments = want_moments;
+    size_t lds;
+    if (dense_ws(c, c->d, c->K, &a.ws, &lds)) return -1;
+    a.packed = packed_dev; a.Q0 = c->Q0; a.r0 = c->r0; a.df = df;
+    a.Q = c->Q; a.r = c->r; a.S = c->S; a.m = c->m; a.flag = c->iflags;
+    if (set_lds(k_global, lds)) return -1;
+    hipLaunchKernelGGL(k_global, dim3(1), dim3(256), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int epx_damped_trial(epx_ctx *c, double df, const double *packed_host, const double *packed_dev,
+                     int *global_pd, int *cav_pd, int *first_bad) {
+    CTX(c);
+    const double *pk = packed_dev;
+    if (packed_host) {
+        HIPCHK(hipMemcpyAsync(c->packed, packed_host, (size_t)2 * (c->d * c->d + c->d) * 8,
+                              hipMemcpyHostToDevice, c->stream));
+        pk = c->packed;
+    }
+    if (!pk) pk = c->packed;       // sums of the last epx_site_sums on this rank
+    c->last_df = df;
+    if (launch_global(c, pk, df, 0)) return -1;
+    int h[4] = {0, 0, -1, 0};
+    HIPCHK(hipMemcpyAsync(h, c->iflags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *global_pd = h[0];
+    *cav_pd = 0;
+    if (first_bad) *first_bad = -1;
+    if (!h[0]) return 0;
+    if (launch_cavity(c, c->Qi, c->ri, c->dQi, c->dri, df, 0, c->K)) return -1;
+    hipLaunchKernelGGL(k_all_flags, dim3(1), dim3(256), 0, c->stream, c->flags, 0, c->K, c->iflags + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h + 1, c->iflags + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *cav_pd = h[1];
+    if (first_bad) *first_bad = h[2];
+    return 0;
+}
+
+int epx_accept(epx_ctx *c, double df) {
+    CTX(c);
+    const size_t K = c->K, d = c->d;
+    hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, c->stream, c->Qi, c->Qi, c->dQi, df, K * d * d);
+    hipLaunchKernelGGL(k_axpy, dim3(64), dim3(256), 0, c->stream, c->ri, c->ri, c->dri, df, K * d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int epx_global_moments(epx_ctx *c, double *S, double *m) {
+    CTX(c);
+    if (launch_global(c, nullptr, 0.0, 1)) return -1;
+    int ok = 0;
+    HIPCHK(hipMemcpyAsync(&ok, c->iflags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!ok) return fail("global precision is not positive definite");
+    if (S) HIPCHK(hipMemcpy(S, c->S, (size_t)c->d * c->d * 8, hipMemcpyDeviceToHost));
+    if (m) HIPCHK(hipMemcpy(m, c->m, (size_t)c->d * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_force_pd(epx_ctx *c, double df, double thresh, double min_eig_target, uint8_t *forced) {
+    CTX(c);
+    ForceArgs a;
+    a.d = c->d; a.ld = ld_of(c->d);
+    size_t lds;
+    if (dense_ws(c, c->d, c->K, &a.ws, &lds)) return -1;
+    a.Qi = c->Qi; a.dQi = c->dQi; a.df = df; a.thresh = thresh; a.target = min_eig_target;
+    a.forced = c->flags; a.min_eig = c->tilt_mean;     // tilt_mean reused as scratch (K doubles <= K*d)
+    if (set_lds(k_force_pd, lds)) return -1;
+    hipLaunchKernelGGL(k_force_pd, dim3(c->K), dim3(256), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (forced) HIPCHK(hipMemcpy(forced, c->flags, c->K, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------ stand-alone util ops
+static int util_dense_ws(int d, int nb, DenseWs *ws, size_t *lds, double **owned) {
+    *owned = nullptr;
+    const size_t bytes = dense_slot_doubles(d) * 8;
+    if (bytes + 1024 <= LDS_CAP) { ws->use_lds = 1; ws->global = nullptr; *lds = bytes; return 0; }
+    ws->use_lds = 0; *lds = 0;
+    HIPCHK(dalloc(owned, dense_slot_doubles(d) * nb));
+    ws->global = *owned;
+    return 0;
+}
+
+static int need_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("no HIP device available: libepx has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("device %d out of range", device);
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+
+int epx_invert_normal_params(int device, int d, int nb, double *A, double *b, int cho_form, int32_t *info) {
+    if (need_device(device)) return -1;
+    if (d < 1 || nb < 1) return fail("bad sizes");
+    InvertArgs a;
+    a.d = d; a.ld = ld_of(d); a.cho_form = cho_form;
+    size_t lds; double *owned;
+    if (util_dense_ws(d, nb, &a.ws, &lds, &owned)) return -1;
+    double *Ad, *bd = nullptr; int32_t *infod;
+    HIPCHK(dalloc(&Ad, (size_t)nb * d * d));
+    HIPCHK(dalloc(&infod, nb));
+    HIPCHK(hipMemcpy(Ad, A, (size_t)nb * d * d * 8, hipMemcpyHostToDevice));
+    if (b) { HIPCHK(dalloc(&bd, (size_t)nb * d)); HIPCHK(hipMemcpy(bd, b, (size_t)nb * d * 8, hipMemcpyHostToDevice)); }
+    a.A = Ad; a.b = bd; a.info = infod;
+    if (set_lds(k_invert, lds)) return -1;
+    hipLaunchKernelGGL(k_invert, dim3(nb), dim3(256), lds, 0, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(A, Ad, (size_t)nb * d * d * 8, hipMemcpyDeviceToHost));
+    if (b) HIPCHK(hipMemcpy(b, bd, (size_t)nb * d * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(info, infod, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(Ad); (void)hipFree(infod); if (bd) (void)hipFree(bd); if (owned) (void)hipFree(owned);
+    return 0;
+}
+
+int epx_olse(int device, int d, int nb, double *S, int n, const double *P, int32_t *info) {
+    if (need_device(device)) return -1;
+    if (d < 1 || nb < 1) return fail("bad sizes");
+    OlseArgs a;
+    a.d = d; a.ld = ld_of(d); a.n = n;
+    size_t lds; double *owned;
+    if (util_dense_ws(d, nb, &a.ws, &lds, &owned)) return -1;
+    double *Sd, *Pd = nullptr; int32_t *infod;
+    HIPCHK(dalloc(&Sd, (size_t)nb * d * d));
+    HIPCHK(dalloc(&infod, nb));
+    HIPCHK(hipMemcpy(Sd, S, (size_t)nb * d * d * 8, hipMemcpyHostToDevice));
+    if (P) { HIPCHK(dalloc(&Pd, (size_t)nb * d * d)); HIPCHK(hipMemcpy(Pd, P, (size_t)nb * d * d * 8, hipMemcpyHostToDevice)); }
+    a.S = Sd; a.P = Pd; a.info = infod;
+    if (set_lds(k_olse, lds)) return -1;
+    hipLaunchKernelGGL(k_olse, dim3(nb), dim3(256), lds, 0, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(S, Sd, (size_t)nb * d * d * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(info, infod, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(Sd); (void)hipFree(infod); if (Pd) (void)hipFree(Pd); if (owned) (void)hipFree(owned);
+    return 0;
+}
+
+int epx_rng_probe(int device, uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a, uint32_t b,
+                  double *out4) {
+    if (need_device(device)) return -1;
+    double *od;
+    HIPCHK(dalloc(&od, 4));
+    hipLaunchKernelGGL(k_rng_probe, dim3(1), dim3(64), 0, 0, seed, chain, t, kind, a, b, od);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out4, od, 32, hipMemcpyDeviceToHost));
+    (void)hipFree(od);
+    return 0;
+}

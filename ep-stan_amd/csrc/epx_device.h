@@ -1,0 +1,124 @@
+// Device-side helpers shared by the HIP kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EPX_WAVE 64
+
+namespace epx {
+
+// ----------------------------------------------------------------------------
+// Philox4x32-10 counter-based stream; identical to oracle/nuts_oracle.c so the
+// device sampler and the CPU restatement take the same decisions.
+struct RngKey { uint32_t k0, k1; };
+
+__device__ __host__ inline RngKey make_key(uint64_t seed, int chain) {
+    RngKey k;
+    k.k0 = (uint32_t)seed;
+    k.k1 = (uint32_t)(seed >> 32) ^ (0x85EBCA6Bu * (uint32_t)(chain + 1));
+    return k;
+}
+
+__device__ inline void philox4x32(RngKey key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                  uint32_t out[4]) {
+    uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ inline double u01(uint32_t hi, uint32_t lo) {
+    uint64_t v = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__device__ inline void rng_u2(RngKey k, uint32_t t, uint32_t kind, uint32_t a, uint32_t b,
+                              double &u1, double &u2) {
+    uint32_t o[4];
+    philox4x32(k, t, kind, a, b, o);
+    u1 = u01(o[0], o[1]);
+    u2 = u01(o[2], o[3]);
+}
+
+__device__ inline double rng_uniform(RngKey k, uint32_t t, uint32_t kind, uint32_t a, uint32_t b) {
+    double u1, u2;
+    rng_u2(k, t, kind, a, b, u1, u2);
+    return u1;
+}
+
+// standard normal of vector element e (Box-Muller pair shared by e and e^1)
+__device__ inline double rng_normal(RngKey k, uint32_t t, uint32_t kind, int e, uint32_t b) {
+    double u1, u2;
+    rng_u2(k, t, kind, (uint32_t)(e >> 1), b, u1, u2);
+    double r = sqrt(-2.0 * log(u1));
+    double a = 6.283185307179586476925286766559 * u2;
+    double s, c;
+    sincos(a, &s, &c);
+    return (e & 1) ? r * s : r * c;
+}
+
+// ----------------------------------------------------------------------------
+// wave64 all-reduce sums (xor butterfly); every lane ends with the total.
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ inline void wave_sum2(double &a, double &b) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double ta = __shfl_xor(a, m, 64), tb = __shfl_xor(b, m, 64);
+        a += ta; b += tb;
+    }
+}
+__device__ inline void wave_sum3(double &a, double &b, double &c) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double ta = __shfl_xor(a, m, 64), tb = __shfl_xor(b, m, 64), tc = __shfl_xor(c, m, 64);
+        a += ta; b += tb; c += tc;
+    }
+}
+
+// make a value the compiler can keep in SGPRs (it is identical in all lanes)
+__device__ inline double uniform_d(double v) {
+    union { double d; uint32_t u[2]; } x;
+    x.d = v;
+    x.u[0] = __builtin_amdgcn_readfirstlane(x.u[0]);
+    x.u[1] = __builtin_amdgcn_readfirstlane(x.u[1]);
+    return x.d;
+}
+__device__ inline int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// value of lane `lane` (wave-uniform index) broadcast as a scalar
+__device__ inline double readlane_d(double v, int lane) {
+    union { double d; uint32_t u[2]; } x;
+    x.d = v;
+    x.u[0] = __builtin_amdgcn_readlane(x.u[0], lane);
+    x.u[1] = __builtin_amdgcn_readlane(x.u[1], lane);
+    return x.d;
+}
+
+__device__ inline double log_sum_exp2(double a, double b) {
+    if (a == -INFINITY) return b;
+    if (a == INFINITY && b == INFINITY) return INFINITY;
+    if (a > b) return a + log1p(exp(b - a));
+    return b + log1p(exp(a - b));
+}
+
+// y f - log(1+e^f) and y - sigmoid(f) sharing one exp (bernoulli_logit)
+__device__ inline void logistic_terms(double f, double y, double &ll, double &g) {
+    double e = exp(-fabs(f));
+    double l1p = log1p(e);
+    double inv = 1.0 / (1.0 + e);
+    double s = (f >= 0) ? inv : e * inv;
+    ll = y * f - (fmax(f, 0.0) + l1p);
+    g = y - s;
+}
+
+}  // namespace epx

@@ -1,0 +1,135 @@
+// Kernel argument blocks and launch entry points shared by the .hip files and
+// the C-ABI implementation (epx_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace epx {
+
+// Where a dense kernel keeps its two d x ld work matrices + 4 vectors.
+struct DenseWs {
+    int use_lds;        // 1: dynamic LDS, 0: global workspace
+    double *global;     // per-block slots of 2*d*ld + 4*ld doubles
+};
+
+struct CavityArgs {
+    int k0, d, ld;
+    DenseWs ws;
+    const double *Q, *r;               // global approximation (device)
+    const double *Qsite, *rsite;       // site array base
+    const double *dQsite, *drsite;     // optional update (proposal = site + df * update)
+    size_t site_stride, rsite_stride;
+    double df;
+    double *cav_Om, *cav_mu;           // K x d x d, K x d
+    uint8_t *flags;                    // K
+};
+
+struct MomentArgs {
+    int k0, d, ld, S, prec_estim;
+    DenseWs ws;
+    const double *draws;               // element (site, s, i) at site*stride_site + s*stride_s + i*stride_i
+    long draws_site0;
+    long stride_site, stride_s, stride_i;
+    const double *Q, *r;               // global approximation subtracted at method.py:457-458
+    double *dQi, *dri;                 // K x d x d, K x d
+    double *tilt_mean, *tilt_scatter;  // K x d, K x d x d
+    uint8_t *flags;
+};
+
+struct SumArgs {
+    int K, d, len, nslice;
+    const double *Qi, *ri, *dQi, *dri;
+    double *partial;                   // nslice x len
+    double *out;                       // len
+};
+
+struct GlobalArgs {
+    int d, ld, want_moments;
+    DenseWs ws;
+    const double *packed;              // [sum Qi, sum ri, sum dQi, sum dri] or NULL (use Q,r as they are)
+    const double *Q0, *r0;
+    double df;
+    double *Q, *r, *S, *m;
+    int *flag;
+};
+
+struct InvertArgs {
+    int d, ld, cho_form;
+    DenseWs ws;
+    double *A, *b;
+    int32_t *info;
+};
+
+struct OlseArgs {
+    int d, ld, n;
+    DenseWs ws;
+    double *S;
+    const double *P;
+    int32_t *info;
+};
+
+struct ForceArgs {
+    int d, ld;
+    DenseWs ws;
+    double *Qi;
+    const double *dQi;
+    double df, thresh, target;
+    uint8_t *forced;
+    double *min_eig;
+};
+
+__global__ void k_cavity(CavityArgs a);
+__global__ void k_moments(MomentArgs a);
+__global__ void k_site_sums_partial(SumArgs a);
+__global__ void k_site_sums_final(SumArgs a);
+__global__ void k_global(GlobalArgs a);
+__global__ void k_axpy(double *out, const double *x, const double *dx, double df, size_t n);
+__global__ void k_all_flags(const uint8_t *flags, int k0, int count, int *out);
+__global__ void k_invert(InvertArgs a);
+__global__ void k_olse(OlseArgs a);
+__global__ void k_force_pd(ForceArgs a);
+
+// ------------------------------------------------------------------ sampler
+enum { ST_STEPSIZE_MEAN = 0, ST_STEPSIZE_FINAL, ST_NLEAP, ST_NGRAD, ST_NDIV, ST_ACCEPT_MEAN,
+       ST_DEPTH_MEAN, ST_FAIL, ST_COUNT };
+enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
+enum { MAX_DEPTH_CAP = 12 };
+
+struct NutsArgs {
+    int model, D, d, P;
+    int k0;                       // first site of the batch
+    int chains, iter, warmup, thin, nkeep, max_depth, init_mode;
+    int cpb;                      // chains per block (waves per block = cpb * WPC)
+    const int64_t *k_lim;         // K+1 row limits
+    const double *X;              // N x D row-major
+    const uint8_t *y;             // N
+    const double *cav_Om;         // K x d x d
+    const double *cav_mu;         // K x d
+    const int64_t *seeds;         // per site of the batch (index k - k0)
+    double *draws;                // K x chains x nkeep x P
+    double *last;                 // K x chains x P (read when init_mode == PREV, always written)
+    double *chain_stats;          // K x chains x ST_COUNT
+    double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
+    double *stack;                // per (site of batch, chain): max_depth * (4P + 2) doubles, or NULL when in LDS
+    // dynamic LDS layout (byte offsets), computed on the host
+    int n_max;                    // rows reserved for X in LDS
+    int off_y, off_Om, off_mu, off_xch, off_stack, lds_bytes;
+    int stack_in_lds;
+    int om_in_lds;
+};
+
+// launch wrapper implemented in nuts.hip; returns hipError_t as int
+int launch_nuts(const NutsArgs &a, int count, int wpc, int dp, int nv, hipStream_t stream);
+size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
+
+struct RhatArgs {
+    int k0, chains, nkeep, P;
+    const double *draws;          // K x chains x nkeep x P
+    const double *chain_stats;    // K x chains x ST_COUNT
+    double *site_stats;           // count x EPX_ST_COUNT (batch-relative)
+};
+__global__ void k_site_stats(RhatArgs a);
+__global__ void k_rng_probe(uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a,
+                            uint32_t b, double *out4);
+
+}  // namespace epx

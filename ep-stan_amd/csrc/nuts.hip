@@ -1,0 +1,716 @@
+// On-GPU NUTS for the per-site tilted distributions of ep-stan's EP loop.
+//
+// Replaces the Stan subprocess of /root/reference/epstan/method.py:43-118,
+// 349-363 (PyStan 2.17 adapt_diag_e_nuts) for the hierarchical logistic
+// regression family experiment/models/m{1..5}b_sg.stan.  The algorithm is the
+// one restated in oracle/nuts_oracle.c (multinomial NUTS, diagonal metric,
+// Stan 2.17 adaptation); the decision sequence and the Philox stream are the
+// same so both can be compared draw by draw.
+//
+// Mapping to gfx950:
+//   * one site = one workgroup (layout 1): the site's rows of X are copied
+//     ONCE per site update from HBM into LDS (coalesced 16-B loads, XOR-swizzled
+//     16-B slots so the row-per-lane ds_read_b128 pattern is conflict free);
+//     every leapfrog gradient then runs out of LDS.  One wave = one chain.
+//   * small K (fewer sites than CUs, configs C1/C2): one workgroup per
+//     (site, chain) (layout 2); the 4 waves of the group split the rows and the
+//     cavity-precision mat-vec and exchange partial sums through LDS with one
+//     s_barrier per leapfrog.  All waves carry the chain state redundantly in
+//     registers and take identical decisions.
+//   * the whole NUTS state (position, momentum, gradient, tree ends, rho, ...)
+//     lives in VGPRs, element e of a length-P vector in lane e%64, register
+//     e/64; dot products are wave64 butterflies, no LDS round trips.
+//   * beta is broadcast through SGPRs (v_readlane), so the row loop is
+//     ds_read_b128 + v_fma_f64 only; the D partial sums of X'g are reduced
+//     with a transposing butterfly (DP-1 exchanges instead of 6*DP).
+#include "epx_device.h"
+#include "epx_kernels.h"
+
+namespace epx {
+
+template <int NV> struct Vec { double v[NV]; };
+
+#define FORV _Pragma("unroll") for (int i = 0; i < NV; ++i)
+
+template <int NV>
+__device__ inline double gatherV(const Vec<NV> &x, int e) {
+    double r = 0.0;
+    FORV {
+        const double t = __shfl(x.v[i], e & 63, 64);
+        if ((e >> 6) == i) r = t;
+    }
+    return r;
+}
+// element e (wave-uniform index) as a scalar
+template <int NV>
+__device__ inline double elemU(const Vec<NV> &x, int e) {
+    double r = 0.0;
+    FORV { if ((e >> 6) == i) r = readlane_d(x.v[i], e & 63); }
+    return r;
+}
+
+template <int DP> struct Log2 { static constexpr int v = 1 + Log2<DP / 2>::v; };
+template <> struct Log2<1> { static constexpr int v = 0; };
+
+enum { MODE_INIT = 0, MODE_SS = 1, MODE_TREE = 2 };
+
+template <int NV, int DP, int WPC>
+__global__ void __launch_bounds__(256)
+k_nuts(NutsArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    using V = Vec<NV>;
+    constexpr int LOG = Log2<DP>::v;
+    constexpr int SPR = DP / 2;                       // 16-B slots per row
+    constexpr int RPL = DP >= 32 ? 1 : 32 / DP;       // rows per 256-B bank line
+    constexpr int XREC = 64 * (1 + NV) + 2;           // per-wave exchange record (doubles)
+    constexpr int SREC = 4 * NV * 64 + 2;             // per-level stack record (doubles)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = wave / WPC, wt = wave % WPC;
+    const int bps = (a.chains + a.cpb - 1) / a.cpb;
+    const int sb = blockIdx.x / bps, cb = blockIdx.x % bps;
+    const int k = a.k0 + sb;
+    const int chain = cb * a.cpb + team;
+    const int D = a.D, d = a.d, P = a.P, model = a.model;
+    const int64_t row0 = a.k_lim[k];
+    const int n = (int)(a.k_lim[k + 1] - row0);
+
+    double *Xs = reinterpret_cast<double *>(smem);
+    uint8_t *ys = smem + a.off_y;
+    double *xch = reinterpret_cast<double *>(smem + a.off_xch);
+
+    // ---- stage the site's rows: HBM -> LDS, once per site update
+    {
+        const double *Xg = a.X + (size_t)row0 * D;
+        const int nslot = n * SPR;
+        for (int s = tid; s < nslot; s += blockDim.x) {
+            const int r = s / SPR, jp = s % SPR, c0 = 2 * jp;
+            double2 v;
+            if ((D & 1) == 0 && c0 + 1 < D) v = *reinterpret_cast<const double2 *>(Xg + (size_t)r * D + c0);
+            else {
+                v.x = c0 < D ? Xg[(size_t)r * D + c0] : 0.0;
+                v.y = c0 + 1 < D ? Xg[(size_t)r * D + c0 + 1] : 0.0;
+            }
+            const int sw = (r / RPL) & (SPR - 1);
+            *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
+        }
+        for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r];
+    }
+    const double *Om = a.cav_Om + (size_t)k * d * d;
+    if (a.om_in_lds) {
+        double *Oms = reinterpret_cast<double *>(smem + a.off_Om);
+        for (int idx = tid; idx < d * d; idx += blockDim.x) Oms[idx] = Om[idx];
+        Om = Oms;
+    }
+    __syncthreads();
+    if (chain >= a.chains) return;        // only possible when WPC == 1 (no later barriers)
+
+    double *stk;
+    if (a.stack_in_lds) stk = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
+    else stk = a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+
+    const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
+    const bool laplace = (model == 4);
+
+    // ------------------------------------------------------------- state
+    V mu, inv_e, qs, gs, zq, zp, zg, pq, pp, pg, mq, mp, mg, rho, psp, psm;
+    V n_rho, n_psl, n_pq, n_pg, psr, wmean, wm2;
+    double lps = 0, zlp = 0, plp = 0, mlp = 0, n_lw = 0, n_plp = 0;
+    FORV {
+        const int e = lane + 64 * i;
+        mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
+        inv_e.v[i] = 1.0;
+        wmean.v[i] = 0.0; wm2.v[i] = 0.0;
+        gs.v[i] = 0; zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
+        mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
+        n_rho.v[i] = 0; n_psl.v[i] = 0; n_pq.v[i] = 0; n_pg.v[i] = 0; psr.v[i] = 0;
+    }
+    // initial position (method.py:159 init / :404-406 init_prev)
+    {
+        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        FORV {
+            const int e = lane + 64 * i;
+            double q0 = 0.0;
+            if (e < P) {
+                if (a.init_mode == 2) q0 = lastp[e];
+                else if (a.init_mode == 0) {
+                    double u1, u2;
+                    rng_u2(key, 0, K_INIT, (uint32_t)(e >> 1), 0, u1, u2);
+                    q0 = -2.0 + 4.0 * ((e & 1) ? u2 : u1);
+                }
+            }
+            qs.v[i] = q0;
+        }
+    }
+    // adaptation state (stepsize_adaptation.hpp / windowed_adaptation.hpp @ Stan 2.17)
+    const double DELTA = 0.8, GAMMA = 0.05, T0 = 10.0, KAPPA = 0.75, LOG08 = -0.2231435513142097558;
+    double eps = 1.0, da_mu = log(10.0), s_bar = 0, x_bar = 0, da_count = 0;
+    int va_init_buf = 75, va_term = 50, va_base = 25;
+    if (va_init_buf + va_base + va_term > a.warmup && a.warmup >= 20) {
+        va_init_buf = (int)(0.15 * a.warmup);
+        va_term = (int)(0.1 * a.warmup);
+        va_base = a.warmup - (va_init_buf + va_term);
+    }
+    int va_counter = 0, va_wsize = va_base, va_next = va_init_buf + va_base - 1;
+    double va_n = 0;
+    // statistics
+    double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
+    int ndiv = 0, npost = 0, kept = 0, failed = 0;
+    // transition state
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
+    uint32_t ss_t = 0;
+    double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;
+    int parity = 0;
+
+    FORV { zq.v[i] = qs.v[i]; }
+
+    for (;;) {
+        // =================================================== leapfrog (single site of the gradient)
+        FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
+        FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
+        {
+            V eq;
+            FORV eq.v[i] = exp(zq.v[i]);
+            double alpha, sa, eta, sb2 = 0.0;
+            double beta_l;
+            if (model == 0) {
+                sa = elemU(eq, 0); eta = elemU(zq, d);
+                alpha = eta * sa; beta_l = gatherV(zq, 1 + lane);
+            } else if (model == 1) {
+                sa = elemU(eq, 0); sb2 = elemU(eq, 1); eta = elemU(zq, 2);
+                alpha = eta * sa; beta_l = gatherV(zq, 3 + lane) * sb2;
+            } else if (model == 2) {
+                sa = elemU(eq, 0); eta = elemU(zq, d);
+                alpha = eta * sa; beta_l = gatherV(zq, d + 1 + lane) * gatherV(eq, 1 + lane);
+            } else {
+                sa = elemU(eq, 1); eta = elemU(zq, d);
+                alpha = elemU(zq, 0) + eta * sa;
+                beta_l = gatherV(zq, 2 + lane) + gatherV(zq, d + 1 + lane) * gatherV(eq, 2 + D + lane);
+            }
+            if (lane >= D) beta_l = 0.0;
+            double bs[DP];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
+            alpha = uniform_d(alpha);
+
+            // ---- fused row pass: f = alpha + x.beta, g = y - sigmoid(f), acc += g x
+            double acc[DP];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) acc[j] = 0.0;
+            double da = 0.0, ll = 0.0;
+            for (int r = wt * 64 + lane; r < n; r += 64 * WPC) {
+                const double2 *rowp = reinterpret_cast<const double2 *>(Xs + (size_t)r * DP);
+                const int sw = (r / RPL) & (SPR - 1);
+                double x[DP];
+#pragma unroll
+                for (int jp = 0; jp < SPR; ++jp) {
+                    const double2 v = rowp[jp ^ sw];
+                    x[2 * jp] = v.x; x[2 * jp + 1] = v.y;
+                }
+                double f = alpha;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) f = fma(x[j], bs[j], f);
+                double l, g;
+                logistic_terms(f, (double)ys[r], l, g);
+                ll += l; da += g;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) acc[j] = fma(g, x[j], acc[j]);
+            }
+            // ---- transposing butterfly: lane ends with sum over lanes of acc[lane >> (6-LOG)]
+            {
+                int mask = 32;
+#pragma unroll
+                for (int cnt = DP; cnt > 1; cnt >>= 1, mask >>= 1) {
+                    const bool upper = (lane & mask) != 0;
+#pragma unroll
+                    for (int j = 0; j < cnt / 2; ++j) {
+                        const double send = upper ? acc[j] : acc[j + cnt / 2];
+                        const double keep = upper ? acc[j + cnt / 2] : acc[j];
+                        acc[j] = keep + __shfl_xor(send, mask, 64);
+                    }
+                }
+#pragma unroll
+                for (int m = 32 >> LOG; m >= 1; m >>= 1) acc[0] += __shfl_xor(acc[0], m, 64);
+            }
+            wave_sum2(da, ll);
+            double dbl = acc[0];
+
+            // ---- cavity term: Ov = Omega (phi - mu), this wave's share of the columns
+            V vv, Ov;
+            FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? zq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
+            {
+                const int jb = (wt * d) / WPC, je = ((wt + 1) * d) / WPC;
+#pragma unroll
+                for (int ii = 0; ii < NV; ++ii) {
+                    const int lo = jb > 64 * ii ? jb : 64 * ii;
+                    const int hi = je < 64 * (ii + 1) ? je : 64 * (ii + 1);
+                    for (int j = lo; j < hi; ++j) {
+                        const double vj = readlane_d(vv.v[ii], j & 63);
+                        const double *col = Om + (size_t)j * d;
+                        FORV { const int e = lane + 64 * i; if (e < d) Ov.v[i] = fma(col[e], vj, Ov.v[i]); }
+                    }
+                }
+            }
+            if (WPC > 1) {
+                double *rec = xch + ((size_t)parity * WPC + wt) * XREC;
+                rec[lane] = dbl;
+                FORV rec[64 * (1 + i) + lane] = Ov.v[i];
+                if (lane == 0) { rec[64 * (1 + NV)] = da; rec[64 * (1 + NV) + 1] = ll; }
+                __syncthreads();
+                dbl = 0.0; da = 0.0; ll = 0.0;
+                FORV Ov.v[i] = 0.0;
+#pragma unroll
+                for (int w = 0; w < WPC; ++w) {
+                    const double *rw = xch + ((size_t)parity * WPC + w) * XREC;
+                    dbl += rw[lane];
+                    FORV Ov.v[i] += rw[64 * (1 + i) + lane];
+                    da += rw[64 * (1 + NV)];
+                    ll += rw[64 * (1 + NV) + 1];
+                }
+                parity ^= 1;
+            }
+            da = uniform_d(da); ll = uniform_d(ll);
+            // ---- lp and the chain rule back to (phi, eta, etb)
+            auto dbat = [&](int j) { return __shfl(dbl, (j << (6 - LOG)) & 63, 64); };
+            double dot = 0.0;
+            if (model == 1) {
+                double tsum = 0.0;
+                FORV { const int e = lane + 64 * i; const double t2 = dbat(e - 3); if (e >= 3 && e < P) tsum += t2 * zq.v[i]; }
+                dot = wave_sum(tsum);
+            }
+            double lpt = 0.0;
+            FORV {
+                const int e = lane + 64 * i;
+                const double q = zq.v[i];
+                double g = 0.0;
+                if (e < d) { g = -Ov.v[i]; lpt += -0.5 * vv.v[i] * Ov.v[i]; }
+                else if (e < P) lpt -= laplace ? fabs(q) : 0.5 * q * q;
+                const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;    // d/dq of the N(0,1)/Laplace term
+                if (model == 0) {
+                    const double db = dbat(e - 1);
+                    if (e == 0) g += da * eta * sa;
+                    else if (e <= D) g += db;
+                    else if (e == d) g = da * sa - pr;
+                } else if (model == 1) {
+                    const double db = dbat(e - 3);
+                    if (e == 0) g += da * eta * sa;
+                    else if (e == 1) g += dot * sb2;
+                    else if (e == 2) g = da * sa - pr;
+                    else if (e < P) g = db * sb2 - pr;
+                } else if (model == 2) {
+                    const int j = e <= D ? e - 1 : e - d - 1;
+                    const double db = dbat(j);
+                    const double etb = gatherV(zq, d + 1 + j);
+                    const double sbj = gatherV(eq, 1 + j);
+                    if (e == 0) g += da * eta * sa;
+                    else if (e <= D) g += db * etb * eq.v[i];
+                    else if (e == d) g = da * sa - pr;
+                    else if (e < P) g = db * sbj - pr;
+                } else {
+                    const int j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
+                    const double db = dbat(j);
+                    const double etb = gatherV(zq, d + 1 + j);
+                    const double sbj = gatherV(eq, 2 + D + j);
+                    if (e == 0) g += da;
+                    else if (e == 1) g += da * eta * sa;
+                    else if (e < 2 + D) g += db;
+                    else if (e < d) g += db * etb * eq.v[i];
+                    else if (e == d) g = da * sa - pr;
+                    else if (e < P) g = db * sbj - pr;
+                }
+                zg.v[i] = e < P ? g : 0.0;
+            }
+            zlp = uniform_d(wave_sum(lpt) + ll);
+        }
+        FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
+        ngrad += 1.0;
+
+        // =================================================== state machine
+        bool do_begin_ss = false, do_ss_setup = false, do_begin_transition = false;
+        bool do_begin_doubling = false, do_end_doubling = false, do_end_transition = false;
+        int valid = 1;
+
+        double kin = 0.0;
+        {
+            double s = 0.0;
+            FORV s += inv_e.v[i] * zp.v[i] * zp.v[i];
+            kin = 0.5 * uniform_d(wave_sum(s));
+        }
+        double h = -zlp + kin;
+        if (isnan(h)) h = INFINITY;
+
+        if (mode == MODE_INIT) {
+            FORV { gs.v[i] = zg.v[i]; }
+            lps = zlp;
+            int fin = isfinite(zlp) ? 1 : 0;
+            FORV { if (!isfinite(zg.v[i])) fin = 0; }
+            fin = __all(fin);
+            if (a.dbg) {
+                if (wt == 0) {
+                    if (lane == 0) a.dbg[0] = zlp;
+                    FORV { const int e = lane + 64 * i; if (e < P) a.dbg[1 + e] = zg.v[i]; }
+                }
+                return;
+            }
+            if (!fin) { failed = 1; break; }
+            ss_t = 0; ss_after_update = 0;
+            do_begin_ss = true;
+        } else if (mode == MODE_SS) {
+            const double dH = H0 - h;
+            bool done = false;
+            if (ss_trial == 0) ss_dir = dH > LOG08 ? 1 : -1;
+            else {
+                if (ss_dir == 1 && !(dH > LOG08)) done = true;
+                else if (ss_dir == -1 && !(dH < LOG08)) done = true;
+                else eps = ss_dir == 1 ? 2.0 * eps : 0.5 * eps;
+                if (!done && (eps > 1e7 || eps == 0.0)) done = true;
+                if (!done && ss_trial > 200) done = true;
+            }
+            if (done) {
+                if (ss_after_update) { da_mu = log(10.0 * eps); da_count = 0; s_bar = 0; x_bar = 0; }
+                if (ss_after_update && t == a.warmup) { /* unreachable: update windows end before warm-up does */ }
+                do_begin_transition = true;
+            } else { ++ss_trial; do_ss_setup = true; }
+        } else {
+            // ---------------- one new leaf of the subtree being built (base_nuts::build_tree, depth 0)
+            ++nleap;
+            if (h - H0 > 1000.0) divergent = 1;
+            const double dH = H0 - h;
+            sum_metro += dH > 0 ? 1.0 : exp(dH);
+            if (divergent) { valid = 0; do_end_doubling = true; }
+            else {
+                FORV {
+                    n_rho.v[i] = zp.v[i];
+                    psr.v[i] = inv_e.v[i] * zp.v[i];
+                    n_psl.v[i] = psr.v[i];
+                    n_pq.v[i] = zq.v[i]; n_pg.v[i] = zg.v[i];
+                }
+                n_plp = zlp; n_lw = dH;
+                int l = 0, ii = leaf;
+                while (ii & 1) {
+                    const double *rec = stk + (size_t)l * SREC;
+                    const double st_lw = rec[4 * NV * 64], st_plp = rec[4 * NV * 64 + 1];
+                    const double lw_new = log_sum_exp2(st_lw, n_lw);
+                    const double u = rng_uniform(key, (uint32_t)(t + 1), K_MERGE,
+                                                 ((uint32_t)depth << 16) | (uint32_t)leaf, (uint32_t)l);
+                    const bool take_right = (n_lw > lw_new) || (u < exp(n_lw - lw_new));
+                    double c1 = 0.0, c2 = 0.0;
+                    FORV {
+                        const double Lrho = rec[(0 * NV + i) * 64 + lane];
+                        const double Lpsl = rec[(1 * NV + i) * 64 + lane];
+                        if (!take_right) {
+                            n_pq.v[i] = rec[(2 * NV + i) * 64 + lane];
+                            n_pg.v[i] = rec[(3 * NV + i) * 64 + lane];
+                        }
+                        n_rho.v[i] += Lrho;
+                        n_psl.v[i] = Lpsl;
+                        c1 += psr.v[i] * n_rho.v[i];
+                        c2 += n_psl.v[i] * n_rho.v[i];
+                    }
+                    if (!take_right) n_plp = st_plp;
+                    n_lw = lw_new;
+                    wave_sum2(c1, c2);
+                    if (!(c1 > 0 && c2 > 0)) { valid = 0; break; }
+                    ii >>= 1; ++l;
+                }
+                if (!valid) do_end_doubling = true;
+                else if (leaf != nleaf - 1) {
+                    double *rec = stk + (size_t)l * SREC;
+                    FORV {
+                        rec[(0 * NV + i) * 64 + lane] = n_rho.v[i];
+                        rec[(1 * NV + i) * 64 + lane] = n_psl.v[i];
+                        rec[(2 * NV + i) * 64 + lane] = n_pq.v[i];
+                        rec[(3 * NV + i) * 64 + lane] = n_pg.v[i];
+                    }
+                    if (lane == 0) { rec[4 * NV * 64] = n_lw; rec[4 * NV * 64 + 1] = n_plp; }
+                    ++leaf;               // continue integrating from z
+                } else do_end_doubling = true;
+            }
+        }
+
+        if (do_end_doubling) {
+            if (fwd) { FORV { pq.v[i] = zq.v[i]; pp.v[i] = zp.v[i]; pg.v[i] = zg.v[i]; } plp = zlp; }
+            else     { FORV { mq.v[i] = zq.v[i]; mp.v[i] = zp.v[i]; mg.v[i] = zg.v[i]; } mlp = zlp; }
+            if (!valid) do_end_transition = true;
+            else {
+                ++depth;
+                bool take;
+                if (n_lw > lsw) take = true;
+                else take = rng_uniform(key, (uint32_t)(t + 1), K_TOP, (uint32_t)(depth - 1), 0) < exp(n_lw - lsw);
+                if (take) { FORV { qs.v[i] = n_pq.v[i]; gs.v[i] = n_pg.v[i]; } lps = n_plp; }
+                lsw = log_sum_exp2(lsw, n_lw);
+                double c1 = 0.0, c2 = 0.0;
+                FORV {
+                    rho.v[i] += n_rho.v[i];
+                    if (fwd) psp.v[i] = psr.v[i]; else psm.v[i] = psr.v[i];
+                    c1 += psp.v[i] * rho.v[i];
+                    c2 += psm.v[i] * rho.v[i];
+                }
+                wave_sum2(c1, c2);
+                if (!(c1 > 0 && c2 > 0)) do_end_transition = true;
+                else if (depth >= a.max_depth) do_end_transition = true;
+                else do_begin_doubling = true;
+            }
+        }
+
+        if (do_end_transition) {
+            const double accept = sum_metro / (double)nleap;
+            eps_sum += eps;
+            nleap_tot += nleap;
+            bool metric_updated = false;
+            if (t < a.warmup) {
+                // stepsize_adaptation::learn_stepsize
+                da_count += 1.0;
+                const double as = accept > 1.0 ? 1.0 : accept;
+                const double eta_da = 1.0 / (da_count + T0);
+                s_bar = (1.0 - eta_da) * s_bar + eta_da * (DELTA - as);
+                const double x = da_mu - s_bar * sqrt(da_count) / GAMMA;
+                const double x_eta = pow(da_count, -KAPPA);
+                x_bar = (1.0 - x_eta) * x_bar + x_eta * x;
+                eps = exp(x);
+                // var_adaptation::learn_variance
+                const bool in_win = (va_counter >= va_init_buf) && (va_counter < a.warmup - va_term) &&
+                                    (va_counter != a.warmup);
+                if (in_win) {
+                    va_n += 1.0;
+                    FORV {
+                        const double delta = qs.v[i] - wmean.v[i];
+                        wmean.v[i] += delta / va_n;
+                        wm2.v[i] += (qs.v[i] - wmean.v[i]) * delta;
+                    }
+                }
+                const bool end_win = (va_counter == va_next) && (va_counter != a.warmup);
+                if (end_win) {
+                    if (va_next != a.warmup - va_term - 1) {
+                        va_wsize *= 2;
+                        va_next = va_counter + va_wsize;
+                        if (va_next != a.warmup - va_term - 1) {
+                            const int boundary = va_next + 2 * va_wsize;
+                            if (boundary >= a.warmup - va_term) va_next = a.warmup - va_term - 1;
+                        }
+                    }
+                    FORV {
+                        const double s2 = va_n > 1.0 ? wm2.v[i] / (va_n - 1.0) : 0.0;
+                        inv_e.v[i] = (va_n / (va_n + 5.0)) * s2 + 1e-3 * (5.0 / (va_n + 5.0));
+                        wmean.v[i] = 0.0; wm2.v[i] = 0.0;
+                    }
+                    va_n = 0;
+                    metric_updated = true;
+                }
+                ++va_counter;
+                if (t == a.warmup - 1 && !metric_updated) eps = exp(x_bar);     // complete_adaptation
+            } else {
+                acc_sum += accept; depth_sum += depth; ndiv += divergent; ++npost;
+                if ((t - a.warmup) % a.thin == 0) {
+                    if (wt == 0) {
+                        double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kept) * P;
+                        FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
+                    }
+                    ++kept;
+                }
+            }
+            ++t;
+            if (metric_updated) { ss_t = (uint32_t)t; ss_after_update = 1; do_begin_ss = true; }
+            else do_begin_transition = true;
+        }
+
+        if (do_begin_ss) {
+            if (eps == 0.0 || eps > 1e7 || isnan(eps)) {
+                if (ss_after_update) { da_mu = log(10.0 * eps); da_count = 0; s_bar = 0; x_bar = 0; }
+                do_begin_ss = false; do_begin_transition = true;
+            }
+            else { ss_trial = 0; ss_dir = 0; do_ss_setup = true; mode = MODE_SS; }
+        }
+        if (do_ss_setup) {
+            double s = 0.0;
+            FORV {
+                const int e = lane + 64 * i;
+                zp.v[i] = e < P ? rng_normal(key, ss_t, K_SSMOM, e, (uint32_t)ss_trial) / sqrt(inv_e.v[i]) : 0.0;
+                zq.v[i] = qs.v[i]; zg.v[i] = gs.v[i];
+                s += inv_e.v[i] * zp.v[i] * zp.v[i];
+            }
+            H0 = -lps + 0.5 * uniform_d(wave_sum(s));
+            eps_l = eps;
+        }
+        if (do_begin_transition) {
+            if (t >= a.iter) break;
+            double s = 0.0;
+            FORV {
+                const int e = lane + 64 * i;
+                pp.v[i] = e < P ? rng_normal(key, (uint32_t)(t + 1), K_MOM, e, 0) / sqrt(inv_e.v[i]) : 0.0;
+                pq.v[i] = qs.v[i]; pg.v[i] = gs.v[i];
+                mq.v[i] = qs.v[i]; mg.v[i] = gs.v[i]; mp.v[i] = pp.v[i];
+                psp.v[i] = inv_e.v[i] * pp.v[i]; psm.v[i] = psp.v[i];
+                rho.v[i] = pp.v[i];
+                s += inv_e.v[i] * pp.v[i] * pp.v[i];
+            }
+            plp = lps; mlp = lps;
+            H0 = -lps + 0.5 * uniform_d(wave_sum(s));
+            lsw = 0.0; sum_metro = 0.0; depth = 0; nleap = 0; divergent = 0;
+            mode = MODE_TREE;
+            do_begin_doubling = true;
+        }
+        if (do_begin_doubling) {
+            fwd = rng_uniform(key, (uint32_t)(t + 1), K_DIR, (uint32_t)depth, 0) > 0.5 ? 1 : 0;
+            eps_l = fwd ? eps : -eps;
+            if (fwd) { FORV { zq.v[i] = pq.v[i]; zp.v[i] = pp.v[i]; zg.v[i] = pg.v[i]; } zlp = plp; }
+            else     { FORV { zq.v[i] = mq.v[i]; zp.v[i] = mp.v[i]; zg.v[i] = mg.v[i]; } zlp = mlp; }
+            leaf = 0; nleaf = 1 << depth;
+        }
+    }
+
+    // ------------------------------------------------------------- epilogue
+    if (wt == 0) {
+        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
+        if (failed) {
+            for (int kk = 0; kk < a.nkeep; ++kk) {
+                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * P;
+                FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
+            }
+        }
+        if (lane == 0) {
+            double *st = a.chain_stats + ((size_t)k * a.chains + chain) * ST_COUNT;
+            st[ST_STEPSIZE_MEAN] = a.iter > 0 && !failed ? eps_sum / a.iter : 0.0;
+            st[ST_STEPSIZE_FINAL] = eps;
+            st[ST_NLEAP] = nleap_tot;
+            st[ST_NGRAD] = ngrad;
+            st[ST_NDIV] = ndiv;
+            st[ST_ACCEPT_MEAN] = npost ? acc_sum / npost : 0.0;
+            st[ST_DEPTH_MEAN] = npost ? depth_sum / npost : 0.0;
+            st[ST_FAIL] = failed;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side: LDS layout + dispatch over the instantiated shapes
+size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
+    const int nv = (a.P + 63) / 64;
+    size_t off = (size_t)n_max * dp * 8;
+    a.n_max = n_max;
+    a.off_y = (int)off; off += ((size_t)n_max + 15) & ~(size_t)15;
+    a.off_xch = (int)off;
+    if (wpc > 1) off += (size_t)2 * wpc * (64 * (1 + nv) + 2) * 8;
+    off = (off + 15) & ~(size_t)15;
+    const size_t cap = 160 * 1024;
+    const size_t om = (size_t)a.d * a.d * 8;
+    a.om_in_lds = 0; a.off_Om = (int)off;
+    if (off + om <= cap) { a.om_in_lds = 1; off += om; off = (off + 15) & ~(size_t)15; }
+    const size_t stack = (size_t)a.cpb * a.max_depth * (4 * nv * 64 + 2) * 8;
+    a.stack_in_lds = 0; a.off_stack = (int)off;
+    if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
+    a.lds_bytes = (int)off;
+    return off;
+}
+
+template <int NV, int DP, int WPC>
+static int launch_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
+    auto kern = k_nuts<NV, DP, WPC>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    const int threads = 64 * WPC * a.cpb;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), a.lds_bytes, stream, a);
+    return (int)hipGetLastError();
+}
+
+template <int NV, int DP>
+static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t stream) {
+    if (wpc == 1) return launch_one<NV, DP, 1>(a, nblocks, stream);
+    if (wpc == 4) return launch_one<NV, DP, 4>(a, nblocks, stream);
+    return -1;
+}
+
+template <int NV>
+static int launch_dp(const NutsArgs &a, int nblocks, int wpc, int dp, hipStream_t stream) {
+    switch (dp) {
+    case 4: return launch_wpc<NV, 4>(a, nblocks, wpc, stream);
+    case 8: return launch_wpc<NV, 8>(a, nblocks, wpc, stream);
+    case 16: return launch_wpc<NV, 16>(a, nblocks, wpc, stream);
+    case 32: return launch_wpc<NV, 32>(a, nblocks, wpc, stream);
+    }
+    return -1;
+}
+
+int launch_nuts(const NutsArgs &a, int count, int wpc, int dp, int nv, hipStream_t stream) {
+    const int bps = (a.chains + a.cpb - 1) / a.cpb;
+    const int nblocks = count * bps;
+    if (nv == 1) return launch_dp<1>(a, nblocks, wpc, dp, stream);
+    if (nv == 2) return launch_dp<2>(a, nblocks, wpc, dp, stream);
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// per-site statistics: mean step size over chains (method.py:99-102) and the
+// max split-Rhat over the sampled coordinates (PyStan 2.17 _chains.pyx form,
+// method.py:104), one block per site.
+__global__ void __launch_bounds__(256)
+k_site_stats(RhatArgs a) {
+    __shared__ double red[16];
+    const int sbk = blockIdx.x, k = a.k0 + sbk, tid = threadIdx.x;
+    const int C = a.chains, P = a.P;
+    const int n = a.nkeep - (a.nkeep % 2), hlen = n / 2;
+    double rmax = 0.0;
+    for (int e = tid; e < P; e += blockDim.x) {
+        if (hlen < 2) break;
+        double mean_of_means = 0.0, var_within = 0.0;
+        // two passes per half chain (numerically plain, like NumPy var)
+        double hm[32];
+        const int H = 2 * C;
+        for (int hc = 0; hc < H && hc < 32; ++hc) {
+            const int c = hc >> 1, second = hc & 1;
+            const double *base = a.draws + (((size_t)k * C + c) * a.nkeep + (second ? a.nkeep - hlen : 0)) * P + e;
+            double s = 0.0;
+            for (int t = 0; t < hlen; ++t) s += base[(size_t)t * P];
+            const double m = s / hlen;
+            double v = 0.0;
+            for (int t = 0; t < hlen; ++t) { const double dlt = base[(size_t)t * P] - m; v += dlt * dlt; }
+            hm[hc] = m;
+            var_within += v / (hlen - 1);
+            mean_of_means += m;
+        }
+        mean_of_means /= H; var_within /= H;
+        double vb = 0.0;
+        for (int hc = 0; hc < H && hc < 32; ++hc) vb += (hm[hc] - mean_of_means) * (hm[hc] - mean_of_means);
+        const double var_between = hlen * vb / (H - 1);
+        const double rh = sqrt((var_between / var_within + hlen - 1) / hlen);
+        rmax = fmax(rmax, rh);
+        if (isnan(rh)) rmax = NAN;
+    }
+    // block max (NaN propagates like np.max)
+    double v = rmax;
+    int isn = isnan(v) ? 1 : 0;
+    if (isn) v = 0.0;
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    isn = __syncthreads_or(isn);
+    if (tid == 0) {
+        double r = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = fmax(r, red[w]);
+        double *out = a.site_stats + (size_t)sbk * 8;
+        double step = 0, nleap = 0, ngrad = 0, ndiv = 0, acc = 0, dep = 0, fail = 0;
+        for (int c = 0; c < C; ++c) {
+            const double *st = a.chain_stats + ((size_t)k * C + c) * ST_COUNT;
+            step += st[ST_STEPSIZE_MEAN]; nleap += st[ST_NLEAP]; ngrad += st[ST_NGRAD];
+            ndiv += st[ST_NDIV]; acc += st[ST_ACCEPT_MEAN]; dep += st[ST_DEPTH_MEAN]; fail += st[ST_FAIL];
+        }
+        out[0] = step / C; out[1] = isn ? NAN : r; out[2] = nleap; out[3] = ngrad;
+        out[4] = ndiv; out[5] = acc / C; out[6] = dep / C; out[7] = fail;
+    }
+}
+
+__global__ void k_rng_probe(uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a,
+                            uint32_t b, double *out4) {
+    if (threadIdx.x == 0) {
+        RngKey key = make_key(seed, chain);
+        double u1, u2;
+        rng_u2(key, t, kind, a, b, u1, u2);
+        out4[0] = u1; out4[1] = u2;
+        out4[2] = rng_normal(key, t, kind, (int)(2 * a), b);
+        out4[3] = rng_normal(key, t, kind, (int)(2 * a + 1), b);
+    }
+}
+
+}  // namespace epx

@@ -1,0 +1,253 @@
+"""Device engine: one `epx_ctx` (one rank's sites on one MI355X) behind ctypes.
+
+`HipEngine` is the only engine the package ships.  It raises when libepx.so or
+a HIP device is missing -- there is no CPU path.  (Tests drive `Master`'s host
+logic on CPU with an oracle-backed engine that lives under tests/.)
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SamplerOpts, check, dptr
+
+MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4}
+PREC_ESTIM_IDS = {'sample': 0, 'olse': 1}
+QI, QI2, DQI = 0, 1, 2
+INIT_IDS = {'random': 0, '0': 1, 0: 1, 'prev': 2}
+N_STAT = 8
+
+
+def model_dims(model, D):
+    """(dphi, P) of a single-group logistic model (m*b_sg.stan)."""
+    lib = _lib.load()
+    d, P = ctypes.c_int(), ctypes.c_int()
+    check(lib.epx_model_dims(MODEL_IDS[model], int(D), ctypes.byref(d), ctypes.byref(P)))
+    return d.value, P.value
+
+
+def _f64(a, order='F'):
+    return np.require(a, dtype=np.float64, requirements=['F' if order == 'F' else 'C', 'A'])
+
+
+class HipEngine(object):
+    """Sites k = 0..K_local-1 of one rank, resident in HBM."""
+
+    def __init__(self, model, X, y, k_lim, device=0):
+        self.lib = _lib.load()
+        if model not in MODEL_IDS:
+            raise ValueError('unknown site model {!r}; built-in models: {}'
+                             .format(model, sorted(MODEL_IDS)))
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError('the built-in site models need a two dimensional X')
+        y32 = np.ascontiguousarray(y, dtype=np.int32)
+        k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
+        self.model = model
+        self.K = k_lim.shape[0] - 1
+        self.D = X.shape[1]
+        self.d, self.P = model_dims(model, self.D)
+        self.device = device
+        ctx = ctypes.c_void_p()
+        check(self.lib.epx_ctx_create(
+            device, MODEL_IDS[model], self.K, self.D,
+            k_lim.ctypes.data_as(_lib.c_int64_p), dptr(X),
+            y32.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ctx)))
+        self.ctx = ctx
+        n = ctypes.c_int()
+        check(self.lib.epx_packed_len(self.ctx, ctypes.byref(n)))
+        self.packed_len = n.value
+        self._packed = None
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.epx_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state transfer
+    def set_prior(self, Q0, r0):
+        check(self.lib.epx_set_prior(self.ctx, dptr(_f64(Q0)), dptr(_f64(r0))))
+
+    def set_sites(self, which, Q=None, r=None):
+        Qa = _f64(Q) if Q is not None else None
+        ra = _f64(r) if r is not None else None
+        check(self.lib.epx_set_sites(self.ctx, which, dptr(Qa), dptr(ra)))
+
+    def get_sites(self, which, Q=None, r=None):
+        """Copy into the given F-ordered arrays (allocated when None)."""
+        d, K = self.d, self.K
+        if Q is None:
+            Q = np.empty((d, d, K), order='F')
+        if r is None:
+            r = np.empty((d, K), order='F')
+        assert Q.flags['F_CONTIGUOUS'] and r.flags['F_CONTIGUOUS']
+        check(self.lib.epx_get_sites(self.ctx, which, dptr(Q), dptr(r)))
+        return Q, r
+
+    def set_site(self, which, k, Q=None, r=None):
+        Qa = _f64(Q) if Q is not None else None
+        ra = _f64(r) if r is not None else None
+        check(self.lib.epx_set_site(self.ctx, which, int(k), dptr(Qa), dptr(ra)))
+
+    def get_site(self, which, k):
+        Q = np.empty((self.d, self.d), order='F')
+        r = np.empty(self.d)
+        check(self.lib.epx_get_site(self.ctx, which, int(k), dptr(Q), dptr(r)))
+        return Q, r
+
+    def set_global(self, Q, r):
+        check(self.lib.epx_set_global(self.ctx, dptr(_f64(Q)), dptr(_f64(r))))
+
+    def get_global(self):
+        Q = np.empty((self.d, self.d), order='F')
+        r = np.empty(self.d)
+        check(self.lib.epx_get_global(self.ctx, dptr(Q), dptr(r)))
+        return Q, r
+
+    # ---- cavity
+    def cavity_batch(self, which, k0=0, count=None):
+        count = self.K - k0 if count is None else count
+        flags = np.zeros(count, dtype=np.uint8)
+        check(self.lib.epx_cavity_batch(self.ctx, which, k0, count,
+                                        flags.ctypes.data_as(_lib.c_uint8_p)))
+        return flags.astype(bool)
+
+    def cavity_site(self, k, Q, r, Qi, ri):
+        flag = ctypes.c_uint8()
+        check(self.lib.epx_cavity_site(self.ctx, int(k), dptr(_f64(Q)), dptr(_f64(r)),
+                                       dptr(_f64(Qi)), dptr(_f64(ri)), ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def get_cavity(self, k):
+        Mat = np.empty((self.d, self.d), order='F')
+        vec = np.empty(self.d)
+        check(self.lib.epx_get_cavity(self.ctx, int(k), dptr(Mat), dptr(vec)))
+        return Mat, vec
+
+    # ---- tilted
+    @staticmethod
+    def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random',
+                     max_depth=10, layout=0):
+        o = SamplerOpts()
+        o.chains, o.iter, o.thin = int(chains), int(iter), int(thin)
+        o.warmup = -1 if warmup is None else int(warmup)
+        if init not in INIT_IDS:
+            raise ValueError("init must be 'random', '0' or 'prev' for the GPU sampler")
+        o.init = INIT_IDS[init]
+        o.max_depth, o.layout = int(max_depth), int(layout)
+        return o
+
+    def tilted_batch(self, seeds, opts, prec_estim, k0=0, count=None):
+        """Returns (posdef bool[count], stats (count, 8), sampling kernel ms)."""
+        count = self.K - k0 if count is None else count
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        assert seeds.shape[0] == count
+        flags = np.zeros(count, dtype=np.uint8)
+        stats = np.zeros((count, N_STAT))
+        ms = ctypes.c_double()
+        check(self.lib.epx_tilted_batch(
+            self.ctx, k0, count, seeds.ctypes.data_as(_lib.c_int64_p), ctypes.byref(opts),
+            PREC_ESTIM_IDS[prec_estim], flags.ctypes.data_as(_lib.c_uint8_p), dptr(stats),
+            ctypes.byref(ms)))
+        return flags.astype(bool), stats, ms.value
+
+    def sample_batch(self, seeds, opts, k0=0, count=None):
+        count = self.K - k0 if count is None else count
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        stats = np.zeros((count, N_STAT))
+        ms = ctypes.c_double()
+        check(self.lib.epx_sample_batch(self.ctx, k0, count, seeds.ctypes.data_as(_lib.c_int64_p),
+                                        ctypes.byref(opts), dptr(stats), ctypes.byref(ms)))
+        return stats, ms.value
+
+    def moments_batch(self, samples, prec_estim, k0=0, count=None):
+        """samples: (S, d, count) F-order -- the injected-draws test hook."""
+        count = self.K - k0 if count is None else count
+        samples = _f64(samples)
+        S = samples.shape[0]
+        assert samples.shape[1] == self.d
+        flags = np.zeros(count, dtype=np.uint8)
+        check(self.lib.epx_moments_batch(self.ctx, k0, count, dptr(samples), S,
+                                         PREC_ESTIM_IDS[prec_estim],
+                                         flags.ctypes.data_as(_lib.c_uint8_p)))
+        return flags.astype(bool)
+
+    def get_tilted(self, k):
+        Mat = np.empty((self.d, self.d), order='F')
+        vec = np.empty(self.d)
+        n = ctypes.c_int()
+        check(self.lib.epx_get_tilted(self.ctx, int(k), dptr(Mat), dptr(vec), ctypes.byref(n)))
+        return Mat, vec, n.value
+
+    def num_draws(self):
+        n = ctypes.c_int()
+        check(self.lib.epx_num_draws(self.ctx, ctypes.byref(n)))
+        return n.value
+
+    def get_draws(self, k, all_params=False):
+        S = self.num_draws()
+        out = np.empty((S, self.P if all_params else self.d), order='F')
+        check(self.lib.epx_get_draws(self.ctx, int(k), 1 if all_params else 0, dptr(out)))
+        return out
+
+    def get_chain_stats(self, chains, k0=0, count=None):
+        count = self.K - k0 if count is None else count
+        out = np.zeros((count, chains, N_STAT))
+        check(self.lib.epx_get_chain_stats(self.ctx, k0, count, dptr(out)))
+        return out
+
+    def logdensity_grad(self, k, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        lp = ctypes.c_double()
+        g = np.zeros(self.P)
+        check(self.lib.epx_logdensity_grad(self.ctx, int(k), dptr(theta), ctypes.byref(lp), dptr(g)))
+        return lp.value, g
+
+    # ---- global update
+    def site_sums(self, out_tensor=None):
+        """Packed [sum Qi, sum ri, sum dQi, sum dri] of the local sites.
+
+        With a CUDA/HIP torch tensor the sums are written in place on the
+        device (for the RCCL all-reduce); otherwise a NumPy array is returned."""
+        if out_tensor is not None:
+            assert out_tensor.is_cuda and out_tensor.numel() == self.packed_len
+            check(self.lib.epx_site_sums(self.ctx, None, ctypes.c_void_p(out_tensor.data_ptr())))
+            return out_tensor
+        out = np.zeros(self.packed_len)
+        check(self.lib.epx_site_sums(self.ctx, dptr(out), None))
+        return out
+
+    def damped_trial(self, df, packed):
+        """packed: NumPy array (host) or CUDA torch tensor (device)."""
+        g, c, fb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if isinstance(packed, np.ndarray):
+            packed = np.ascontiguousarray(packed, dtype=np.float64)
+            check(self.lib.epx_damped_trial(self.ctx, float(df), dptr(packed), None,
+                                            ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb)))
+        else:
+            check(self.lib.epx_damped_trial(self.ctx, float(df), None,
+                                            ctypes.c_void_p(packed.data_ptr()),
+                                            ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb)))
+        return bool(g.value), bool(c.value), fb.value
+
+    def accept(self, df):
+        check(self.lib.epx_accept(self.ctx, float(df)))
+
+    def global_moments(self):
+        S = np.empty((self.d, self.d), order='F')
+        m = np.empty(self.d)
+        check(self.lib.epx_global_moments(self.ctx, dptr(S), dptr(m)))
+        return S, m
+
+    def force_pd(self, df, thresh, target):
+        forced = np.zeros(self.K, dtype=np.uint8)
+        check(self.lib.epx_force_pd(self.ctx, float(df), float(thresh), float(target),
+                                    forced.ctypes.data_as(_lib.c_uint8_p)))
+        return forced.astype(bool)

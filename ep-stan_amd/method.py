@@ -1,0 +1,759 @@
+"""Distributed EP driver with the API of /root/reference/epstan/method.py.
+
+`Master` and `Worker` keep the reference's constructor arguments, public
+attributes (`S m Q r Qi ri Qi2 ri2 dQi dri Q0 r0 K workers iter`, Fortran-ordered
+`(d,d,K)` site arrays), methods (`run`, `cur_approx`, `Worker.cavity`,
+`Worker.tilted`), return codes and error behaviour (method.py:121-1247), but
+every numerical step runs on the GPU through libepx.so:
+
+  reference (CPU)                                   here (MI355X)
+  ------------------------------------------------  ------------------------------------
+  for k: Worker.tilted -> Stan subprocess (:1005)   ONE batched NUTS kernel over all sites
+  mean / dgeqrf / potri per site (:413-437)         batched scatter(MFMA f64)+Cholesky kernel
+  Qi2 = Qi + df dQi ; Q = sum_k Qi2 + Q0 (:1071)    site sums once per iteration (affine in df)
+                                                    + one all-reduce across GPUs
+  cho_factor(Q) (:1080), for k: Worker.cavity       one small kernel + one batched cavity kernel
+  invert_normal_params(cho_Q, r) (:1215)            one small kernel
+
+The host mirrors (`master.Qi` ...) are refreshed when `run` returns; inside `run`
+the device copies are authoritative.  Sites are sharded contiguously over the
+ranks of an optional torch.distributed group (`comm=`).
+"""
+
+__all__ = ['Worker', 'Master']
+
+import os
+import sys
+import time
+
+import numpy as np
+from numpy.linalg import LinAlgError
+
+from . import dist as _dist
+from . import engine as _engine
+from .seeds import MAX_UINT, run_seeds, stan_seed, stan_seeds
+from .util import invert_normal_params
+
+
+def _model_name(site_model):
+    """'.../m4b_sg', 'm4b_sg.stan' or 'm4b_sg.pkl' -> 'm4b_sg' (util.load_stan
+    accepts all three spellings, util.py:642-689)."""
+    if not isinstance(site_model, str):
+        raise TypeError('site_model has to be a path/name string selecting a built-in '
+                        'GPU site model (StanModel instances cannot run on the GPU)')
+    base = os.path.basename(site_model)
+    for ext in ('.stan', '.pkl'):
+        if base.endswith(ext):
+            base = base[:-len(ext)]
+    return base
+
+
+class Worker(object):
+    """Per-site state and the per-site entry points `cavity` / `tilted`.
+
+    Same constructor and attributes as the reference's Worker
+    (method.py:121-265).  `Mat`/`vec` hold the cavity precision / MEAN after
+    `cavity` (phase 1) and the unnormalised scatter matrix / tilted mean after
+    `tilted` (phase 2); they are fetched from the device on access.
+    """
+
+    DEFAULT_OPTIONS = {
+        'init_prev'       : True,
+        'prec_estim'      : 'sample',
+        'prec_estim_skip' : 0,
+        'verbose'         : False
+    }
+
+    DEFAULT_STAN_PARAMS = {
+        'chains'          : 4,
+        'iter'            : 1000,
+        'warmup'          : None,
+        'thin'            : 1,
+        'init'            : 'random'
+    }
+
+    PREC_ESTIM_OPTIONS = ('sample', 'olse')
+
+    RESERVED_STAN_PARAMETER_NAMES = ['X', 'y', 'N', 'D', 'mu_phi', 'Omega_phi']
+
+    def __init__(self, index, stan_model, dphi, X, y, A=None, _master=None, **options):
+        for (kw, default) in self.DEFAULT_OPTIONS.items():
+            if kw not in options:
+                options[kw] = default
+        for (kw, default) in self.DEFAULT_STAN_PARAMS.items():
+            if kw not in options:
+                options[kw] = default
+        self.stan_params = {}
+        for (kw, val) in options.items():
+            if kw in self.DEFAULT_STAN_PARAMS:
+                self.stan_params[kw] = val
+            elif kw not in self.DEFAULT_OPTIONS:
+                raise TypeError("Unexpected option '{}'".format(kw))
+        if A is None:
+            A = {}
+        self._Mat = np.zeros((dphi, dphi), order='F')
+        self._vec = np.zeros(dphi)
+        self._stale = False
+        self.phase = 0
+        self.nsamp = None
+        self.Q = None
+        self.r = None
+        self.data = dict(N=X.shape[0], X=X, y=y, **A)
+        if len(X.shape) == 2:
+            self.data['D'] = X.shape[1]
+        self.index = index
+        self.stan_model = stan_model
+        self.dphi = dphi
+        self.iteration = 0
+        self.last_time = None
+        self.last_msteps = None
+        self.last_mrhat = None
+        self.saved_samples = None
+        self.init_prev = options['init_prev']
+        if self.init_prev:
+            self.init_orig = self.stan_params['init']
+            if not isinstance(self.init_orig, str):
+                raise ValueError("Arg. `init` has to be a string if "
+                                 "`init_prev` is True")
+        self.prec_estim = options['prec_estim']
+        if self.prec_estim not in self.PREC_ESTIM_OPTIONS:
+            raise ValueError("Invalid value for option `prec_estim`")
+        if self.prec_estim != 'sample':
+            self.prec_estim_skip = options['prec_estim_skip']
+        else:
+            self.prec_estim_skip = 0
+        self.verbose = options['verbose']
+        # binding to the device engine (a stand-alone Worker owns a 1-site engine)
+        self._master = _master
+        self._eng = None
+        self._k = None           # local site index inside the engine
+        self._has_sampled = False
+        if _master is None:
+            name = _model_name(stan_model)
+            self._eng = _engine.HipEngine(name, np.ascontiguousarray(X), y,
+                                          np.array([0, X.shape[0]], dtype=np.int64))
+            self._k = 0
+            if self._eng.d != dphi:
+                raise ValueError('dphi = {} does not match model {} (dphi {})'
+                                 .format(dphi, name, self._eng.d))
+
+    # ---- lazily mirrored device state
+    def _refresh(self):
+        if self._stale and self._eng is not None:
+            if self.phase == 1:
+                M, v = self._eng.get_cavity(self._k)
+            elif self.phase == 2:
+                M, v, _ = self._eng.get_tilted(self._k)
+            else:
+                M = v = None
+            if M is not None:
+                self._Mat[...] = M
+                self._vec[...] = v
+        self._stale = False
+
+    @property
+    def Mat(self):
+        self._refresh()
+        return self._Mat
+
+    @property
+    def vec(self):
+        self._refresh()
+        return self._vec
+
+    def _sampler_opts(self):
+        sp = self.stan_params
+        init = sp['init']
+        if not isinstance(init, str) and init != 0:
+            init = 'prev'          # list of last draws in the reference (method.py:404-406)
+        m = self._master
+        return _engine.HipEngine.sampler_opts(
+            chains=sp['chains'], iter=sp['iter'], warmup=sp['warmup'], thin=sp['thin'],
+            init=init, max_depth=m.max_treedepth if m is not None else 10,
+            layout=m.layout if m is not None else 0)
+
+    def _cur_estim(self):
+        if self.prec_estim == 'sample' or self.prec_estim_skip > 0:
+            return 'sample'
+        return self.prec_estim
+
+    def cavity(self, Q, r, Qi, ri):
+        """Form the cavity distribution (method.py:267-302).
+
+        Returns True if the cavity precision Q - Qi is positive definite."""
+        if self._eng is None:
+            raise RuntimeError('this site belongs to another rank')
+        self.Q = Q
+        self.r = r
+        ok = self._eng.cavity_site(self._k, Q, r, Qi, ri)
+        self._stale = True
+        self.phase = 1 if ok else 0
+        if not ok:
+            # the reference leaves Mat = Q - Qi, vec = r - ri behind (:288-289)
+            self._Mat[...], self._vec[...] = self._eng.get_cavity(self._k)
+            self._stale = False
+        return ok
+
+    def tilted(self, dQi, dri, save_samples=None, seed=None):
+        """Estimate the tilted distribution and write the site parameter update
+        into `dQi`, `dri` (method.py:305-475).  Returns False if the precision
+        estimate is not positive definite (then dQi, dri are zero)."""
+        if self.phase != 1:
+            raise RuntimeError('Cavity has to be calculated before tilted.')
+        if self._eng is None:
+            raise RuntimeError('this site belongs to another rank')
+        self.stan_params['seed'] = stan_seed(seed)
+        m = self._master
+        injector = m._sample_injector if m is not None else None
+        if self.Q is not None:
+            self._eng.set_global(self.Q, self.r)      # dQi -= Q, dri -= r use the aliased arrays (:457-458)
+        if injector is not None:
+            self._refresh_for_injection()
+            samp = np.asfortranarray(injector(self.data, self.stan_params))
+            ok = bool(self._eng.moments_batch(samp[:, :, None], self._cur_estim(),
+                                              k0=self._k, count=1)[0])
+            self.last_time, self.last_msteps, self.last_mrhat = 0.25, 0.125, 1.0625
+            lastsamp = [{}] * self.stan_params['chains']
+        else:
+            flags, stats, ms = self._eng.tilted_batch(
+                np.array([self.stan_params['seed']]), self._sampler_opts(), self._cur_estim(),
+                k0=self._k, count=1)
+            ok = bool(flags[0])
+            self.last_time = ms * 1e-3
+            self.last_msteps = stats[0, 0]
+            self.last_mrhat = stats[0, 1]
+            lastsamp = 'prev'
+            self._has_sampled = True
+            if save_samples:
+                self.saved_samp = {'phi': self._eng.get_draws(self._k)}
+        if self.verbose:
+            print('\n   sampling runtime: {:.4}'.format(self.last_time))
+            print('    mean stepsize: {:.4}'.format(self.last_msteps))
+            print('    max Rhat: {:.4}'.format(self.last_mrhat))
+        if self.init_prev:
+            self.stan_params['init'] = lastsamp
+        self._finish_tilted(ok)
+        dQ, dr = self._eng.get_site(_engine.DQI, self._k)
+        dQi[...] = dQ
+        dri[...] = dr
+        return ok
+
+    def _refresh_for_injection(self):
+        """Expose the device cavity as the Stan data of method.py:221-222."""
+        M, v = self._eng.get_cavity(self._k)
+        self.data['mu_phi'] = v
+        self.data['Omega_phi'] = M.T
+
+    def _finish_tilted(self, ok):
+        self.nsamp = self._eng.get_tilted(self._k)[2]
+        if self.prec_estim_skip > 0:
+            self.prec_estim_skip -= 1
+        if ok:
+            self.phase = 2
+        else:
+            self.phase = 0
+            if self.init_prev:
+                self.init = self.init_orig        # sic: the reference does not reset stan_params (:468)
+        self._stale = True
+        self.iteration += 1
+
+
+class Master(object):
+    """Manages the distributed EP algorithm (method.py:478-1247).
+
+    Parameters are those of the reference (site_model, X, y, A, A_n, A_k,
+    site_ind, site_ind_ord, site_sizes, dphi, prior, init_site, df0, df_decay,
+    df_treshold, overwrite_model, plus the worker options chains, iter, warmup,
+    thin, init, init_prev, prec_estim, prec_estim_skip, verbose).  `site_model`
+    is a path or name whose basename selects a built-in GPU site model
+    (`m1b_sg` ... `m5b_sg`).
+
+    GPU-only keyword arguments: `device` (HIP device index, default: rank's
+    LOCAL_RANK or 0), `comm` (a `dist.TorchComm` to shard the sites over several
+    GPUs), `max_treedepth` (default 10), `layout` (0 auto, 1 block per site,
+    2 block per (site, chain)), `sync_sites` (gather the site arrays of all
+    ranks into the host mirrors when `run` returns, default True).
+    """
+
+    INFO_OK = 0
+    INFO_INVALID_PRIOR = 1
+    INFO_DF_TRESHOLD_REACHED_GLOBAL = 2
+    INFO_DF_TRESHOLD_REACHED_CAVITY = 3
+    INFO_ALL_SITES_FAIL = 4
+
+    MIN_EIG_TRESHOLD = 1e-5
+    MIN_EIG = 0.5
+
+    DEFAULT_KWARGS = dict(
+        A                 = {},
+        A_n               = {},
+        A_k               = {},
+        site_ind          = None,
+        site_ind_ord      = None,
+        site_sizes        = None,
+        dphi              = None,
+        prior             = None,
+        init_site         = None,
+        df0               = None,
+        df_decay          = 0.8,
+        df_treshold       = 1e-6,
+        overwrite_model   = False
+    )
+
+    GPU_KWARGS = dict(
+        device            = None,
+        comm              = None,
+        max_treedepth     = 10,
+        layout            = 0,
+        sync_sites        = True,
+        _engine_factory   = None,
+    )
+
+    def __init__(self, site_model, X, y, **kwargs):
+        self.worker_options = {}
+        gpu = dict(self.GPU_KWARGS)
+        for (kw, val) in list(kwargs.items()):
+            if kw in Worker.DEFAULT_OPTIONS or kw in Worker.DEFAULT_STAN_PARAMS:
+                self.worker_options[kw] = val
+            elif kw in self.GPU_KWARGS:
+                gpu[kw] = kwargs.pop(kw)
+            elif kw not in self.DEFAULT_KWARGS:
+                raise TypeError("Unexpected keyword argument '{}'".format(kw))
+        for (kw, default) in self.DEFAULT_KWARGS.items():
+            if kw not in kwargs:
+                kwargs[kw] = default
+        for (kw, default) in Worker.DEFAULT_OPTIONS.items():
+            if kw not in self.worker_options:
+                self.worker_options[kw] = default
+        for (kw, default) in Worker.DEFAULT_STAN_PARAMS.items():
+            if kw not in self.worker_options:
+                self.worker_options[kw] = default
+
+        self.site_model = site_model
+        self.max_treedepth = gpu['max_treedepth']
+        self.layout = gpu['layout']
+        self.sync_sites = gpu['sync_sites']
+        self.comm = gpu['comm'] if gpu['comm'] is not None else _dist.LocalComm()
+        self._sample_injector = None        # test hook: f(data, stan_params) -> (S, d) draws
+
+        # ---- validate X, y (method.py:674-689)
+        self.N = X.shape[0]
+        if len(X.shape) == 2:
+            self.D = X.shape[1]
+        elif len(X.shape) == 1:
+            self.D = None
+        else:
+            raise ValueError("Argument `X` should be one or two dimensional")
+        self.X = X
+        if len(y.shape) != 1:
+            raise ValueError("Argument `y` should be one dimensional")
+        if y.shape[0] != self.N:
+            raise ValueError("The shapes of `y` and `X` does not match")
+        self.y = y
+
+        # ---- site partition (method.py:696-730)
+        if kwargs['site_sizes'] is not None:
+            self.Nk = kwargs['site_sizes']
+            self.K = len(self.Nk)
+            self.k_lim = np.concatenate(([0], np.cumsum(self.Nk)))
+            self.k_ind = np.empty(self.N, dtype=np.int64)
+            for k in range(self.K):
+                self.k_ind[self.k_lim[k]:self.k_lim[k+1]] = k
+        elif kwargs['site_ind_ord'] is not None:
+            self.k_ind = kwargs['site_ind_ord']
+            self.Nk = np.bincount(self.k_ind)
+            self.K = len(self.Nk)
+            self.k_lim = np.concatenate(([0], np.cumsum(self.Nk)))
+        elif kwargs['site_ind'] is not None:
+            k_ind = kwargs['site_ind']
+            k_sort = k_ind.argsort(kind='mergesort')
+            self.k_ind = k_ind[k_sort]
+            self.Nk = np.bincount(self.k_ind)
+            self.K = len(self.Nk)
+            self.k_lim = np.concatenate(([0], np.cumsum(self.Nk)))
+            self.X = self.X[k_sort]
+            self.y = self.y[k_sort]
+        else:
+            raise NotImplementedError("Auto clustering not yet implemented")
+        if self.k_lim[-1] != self.N:
+            raise ValueError("Site definition does not match with `X`")
+        if np.any(np.asarray(self.Nk) == 0):
+            raise ValueError("Empty sites: {}. Index the sites from 1 to K-1"
+                             .format(np.nonzero(np.asarray(self.Nk) == 0)[0]))
+        if self.K < 2:
+            raise ValueError("Distributed EP should be run with at least "
+                             "two sites.")
+        self.X = np.ascontiguousarray(self.X)
+        self.y = np.ascontiguousarray(self.y)
+
+        # ---- additional data (method.py:736-769); kept for API parity
+        self.A = kwargs['A']
+        for key in self.A.keys():
+            if key in Worker.RESERVED_STAN_PARAMETER_NAMES:
+                raise ValueError("Additional data name {} clashes.".format(key))
+        self.A_n = kwargs['A_n'].copy()
+        for (key, val) in kwargs['A_n'].items():
+            if val.shape[0] != self.N:
+                raise ValueError("The shapes of `A_n[{}]` and `X` does not "
+                                 "match".format(repr(key)))
+            if key in Worker.RESERVED_STAN_PARAMETER_NAMES or key in self.A:
+                raise ValueError("Additional data name {} clashes.".format(key))
+            if not val.flags['CARRAY']:
+                self.A_n[key] = np.ascontiguousarray(val)
+        self.A_k = kwargs['A_k']
+        for (key, val) in self.A_k.items():
+            if len(val) != self.K:
+                raise ValueError("Array-like length mismatch in `A_k` "
+                                 "(should be: {}, found: {})"
+                                 .format(self.K, len(val)))
+            if (key in Worker.RESERVED_STAN_PARAMETER_NAMES or key in self.A
+                    or key in self.A_n):
+                raise ValueError("Additional data name {} clashes.".format(key))
+
+        # ---- prior (method.py:772-797)
+        prior = kwargs['prior']
+        self.dphi = kwargs['dphi']
+        if prior is None:
+            if self.dphi is None:
+                raise ValueError("If arg. `prior` is not provided, "
+                                 "arg. `dphi` has to be given")
+            self.Q0 = np.eye(self.dphi).T
+            self.r0 = np.zeros(self.dphi)
+        else:
+            if not isinstance(prior, dict):
+                raise TypeError("Argument `prior` is of wrong type")
+            if 'Q' in prior and 'r' in prior:
+                self.Q0 = np.asfortranarray(prior['Q'], dtype=np.float64)
+                self.r0 = np.asarray(prior['r'], dtype=np.float64)
+            elif 'S' in prior and 'm' in prior:
+                try:
+                    self.Q0, self.r0 = invert_normal_params(
+                        np.asarray(prior['S'], dtype=np.float64),
+                        np.asarray(prior['m'], dtype=np.float64))
+                except LinAlgError as ex:
+                    raise ValueError("Argument `prior` is not appropriate") from ex
+            else:
+                raise ValueError("Argument `prior` is not appropriate")
+            if self.dphi is None:
+                self.dphi = self.Q0.shape[0]
+            if self.Q0.shape[0] != self.dphi or self.r0.shape[0] != self.dphi:
+                raise ValueError("Arg. `dphi` does not match with `prior`")
+
+        # ---- damping (method.py:800-814)
+        self.df_decay = kwargs['df_decay']
+        self.df_treshold = kwargs['df_treshold']
+        if kwargs['df0'] is None:
+            default_df = 1/self.K
+            self.df0 = lambda i: default_df
+        elif isinstance(kwargs['df0'], (float, int)):
+            if kwargs['df0'] <= 0 or kwargs['df0'] > 1:
+                raise ValueError("Constant initial damping factor has to be "
+                                 "in (0,1]")
+            self.df0 = lambda i: kwargs['df0']
+        else:
+            self.df0 = kwargs['df0']
+
+        # ---- this rank's contiguous block of sites + its device engine
+        self.model_name = _model_name(site_model)
+        self.k_lo, self.k_hi = _dist.site_range(self.K, self.comm.rank, self.comm.world)
+        self.K_local = self.k_hi - self.k_lo
+        if self.K_local < 1:
+            raise ValueError("more ranks ({}) than sites ({})".format(self.comm.world, self.K))
+        r0w, r1w = int(self.k_lim[self.k_lo]), int(self.k_lim[self.k_hi])
+        k_lim_local = np.asarray(self.k_lim[self.k_lo:self.k_hi + 1], dtype=np.int64) - r0w
+        factory = gpu['_engine_factory']
+        device = gpu['device']
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0')) if self.comm.world > 1 else 0
+        if factory is None:
+            self.engine = _engine.HipEngine(self.model_name, self.X[r0w:r1w], self.y[r0w:r1w],
+                                            k_lim_local, device=device)
+        else:
+            self.engine = factory(self.model_name, self.X[r0w:r1w], self.y[r0w:r1w], k_lim_local)
+        if self.engine.d != self.dphi:
+            raise ValueError("Arg. `dphi`/`prior` ({}) does not match site model {} (dphi {})"
+                             .format(self.dphi, self.model_name, self.engine.d))
+
+        # ---- workers (method.py:817-834); slices of the ORIGINAL X, y like the reference
+        self.workers = []
+        for k in range(self.K):
+            A = dict((key, val[self.k_lim[k]:self.k_lim[k+1]])
+                     for (key, val) in self.A_n.items())
+            A.update(self.A)
+            for (key, val) in self.A_k.items():
+                A[key] = val[k]
+            w = Worker(k, self.site_model, self.dphi,
+                       X[self.k_lim[k]:self.k_lim[k+1]],
+                       y[self.k_lim[k]:self.k_lim[k+1]],
+                       A=A, _master=self, **self.worker_options)
+            if self.k_lo <= k < self.k_hi:
+                w._eng = self.engine
+                w._k = k - self.k_lo
+            self.workers.append(w)
+
+        # ---- host mirrors (method.py:838-851)
+        d, K = self.dphi, self.K
+        self.S = np.empty((d, d), order='F')
+        self.m = np.empty(d)
+        self.Q = self.Q0.copy(order='F')
+        self.r = self.r0.copy()
+        self.Qi = np.zeros((d, d, K), order='F')
+        self.ri = np.zeros((d, K), order='F')
+        self.Qi2 = np.zeros((d, d, K), order='F')
+        self.ri2 = np.zeros((d, K), order='F')
+        self.dQi = np.zeros((d, d, K), order='F')
+        self.dri = np.zeros((d, K), order='F')
+        if kwargs['init_site'] is not None:
+            if isinstance(kwargs['init_site'], np.ndarray):
+                for k in range(K):
+                    np.copyto(self.Qi[:, :, k], kwargs['init_site'])
+            else:
+                diag_elem = K / (kwargs['init_site']**2)
+                for k in range(K):
+                    self.Qi[:, :, k].flat[::d+1] = diag_elem
+        self.iter = 0
+
+        # ---- initial global approximation and cavities on the device (method.py:867-882)
+        self.engine.set_prior(self.Q0, self.r0)
+        self._upload_sites()
+        self._packed = self._new_packed()
+        packed = self.comm.allreduce_sum(self.engine.site_sums(self._packed))
+        g_pd, c_pd, first_bad = self.engine.damped_trial(0.0, packed)
+        if not g_pd:
+            raise ValueError("Initial approximation is not pos.def.")
+        if not self.comm.allreduce_min_int(1 if c_pd else 0):
+            raise ValueError("Initial cavity is not pos.def.")
+        self.Q[...], self.r[...] = self.engine.get_global()
+        for k in range(self.k_lo, self.k_hi):
+            w = self.workers[k]
+            w.Q, w.r = self.Q, self.r
+            w.phase = 1
+            w._stale = True
+
+    # ------------------------------------------------------------------
+    def _new_packed(self):
+        """Buffer of the packed site sums: a CUDA tensor when the all-reduce runs
+        over RCCL, otherwise None (the engine returns a NumPy array)."""
+        dev = getattr(self.comm, 'device', None)
+        if dev is None:
+            return None
+        import torch
+        return torch.zeros(self.engine.packed_len, dtype=torch.float64, device=dev)
+
+    def _upload_sites(self):
+        lo, hi = self.k_lo, self.k_hi
+        self.engine.set_sites(_engine.QI, np.asfortranarray(self.Qi[:, :, lo:hi]),
+                              np.asfortranarray(self.ri[:, lo:hi]))
+        self.engine.set_sites(_engine.DQI, np.asfortranarray(self.dQi[:, :, lo:hi]),
+                              np.asfortranarray(self.dri[:, lo:hi]))
+
+    def _download_sites(self):
+        lo, hi = self.k_lo, self.k_hi
+        for which, (Qa, ra) in ((_engine.QI, (self.Qi, self.ri)),
+                                (_engine.QI2, (self.Qi2, self.ri2)),
+                                (_engine.DQI, (self.dQi, self.dri))):
+            Ql, rl = self.engine.get_sites(which)
+            if self.comm.world > 1 and self.sync_sites:
+                Qa[...] = self.comm.allgather_sites(Ql, self.K)
+                ra[...] = self.comm.allgather_sites(rl, self.K)
+            else:
+                Qa[:, :, lo:hi] = Ql
+                ra[:, lo:hi] = rl
+        self.Q[...], self.r[...] = self.engine.get_global()
+
+    def cur_approx(self):
+        """Current posterior approximation moments (S, m) (method.py:884-896)."""
+        return invert_normal_params(self.Q, self.r)
+
+    def _ret(self, info, calc_moments, return_analytics, moments, analytics, as_tuple=False):
+        out = [info]
+        if calc_moments:
+            out.append(moments)
+        if return_analytics:
+            out.append(analytics)
+        if len(out) == 1:
+            return out[0]
+        return tuple(out) if as_tuple else out
+
+    def run(self, niter, calc_moments=True, save_last_param=None, verbose=True,
+            return_analytics=False, seed=None):
+        """Run the distributed EP algorithm (method.py:899-1247).
+
+        Returns `info`, optionally followed by `(m_phi_s, cov_phi_s)` and
+        `(stimes, msteps, mrhats, othertimes)` exactly like the reference
+        (a list on the early-exit paths, a tuple on the normal path)."""
+        if niter < 1:
+            if verbose:
+                print("Nothing to do here as provided arg. `niter` is {}".format(niter))
+            return self._ret(self.INFO_OK, calc_moments, return_analytics,
+                             (None, None), (None, None, None))
+
+        seeds = run_seeds(seed, niter, self.K)                    # :956-960
+        eng, comm = self.engine, self.comm
+        lo, hi, K = self.k_lo, self.k_hi, self.K
+        local_workers = self.workers[lo:hi]
+
+        # host mirrors -> device (the caller may have edited them between runs)
+        self._upload_sites()
+        eng.set_global(self.Q, self.r)
+
+        m_phi_s = cov_phi_s = None
+        if calc_moments:
+            m_phi_s = np.zeros((niter, self.dphi))
+            cov_phi_s = np.zeros((niter, self.dphi, self.dphi))
+        stimes = np.zeros(niter)
+        msteps = np.zeros(niter)
+        mrhats = np.zeros(niter)
+        othertimes = np.zeros(niter)
+        moments = (m_phi_s, cov_phi_s)
+        analytics = (stimes, msteps, mrhats, othertimes)
+
+        for cur_iter in range(niter):
+            self.iter += 1
+            if verbose:
+                print("Iter {} starting. Process tilted distributions".format(self.iter))
+
+            # ---- tilted distributions: ONE batched launch over this rank's sites (:1005-1023)
+            w0 = local_workers[0]
+            for w in local_workers:
+                if w.phase != 1:
+                    raise RuntimeError('Cavity has to be calculated before tilted.')
+            sseeds = stan_seeds(seeds[cur_iter, lo:hi])             # :342-346
+            estim = w0._cur_estim()
+            if self._sample_injector is not None:
+                posdefs_l, tl, ml, rl = self._tilted_injected(sseeds, estim)
+            else:
+                opts = w0._sampler_opts()
+                posdefs_l, stats, ms = eng.tilted_batch(sseeds, opts, estim)
+                tl = np.full(self.K_local, ms * 1e-3)
+                ml, rl = stats[:, 0], stats[:, 1]
+            for j, w in enumerate(local_workers):
+                w.stan_params['seed'] = int(sseeds[j])
+                w.last_time, w.last_msteps, w.last_mrhat = tl[j], ml[j], rl[j]
+                if w.init_prev:
+                    w.stan_params['init'] = 'prev' if self._sample_injector is None \
+                        else [{}] * w.stan_params['chains']
+                w.nsamp = eng.get_tilted(0)[2] if j == 0 else local_workers[0].nsamp
+                if w.prec_estim_skip > 0:
+                    w.prec_estim_skip -= 1
+                w.phase = 2 if posdefs_l[j] else 0
+                if not posdefs_l[j] and w.init_prev:
+                    w.init = w.init_orig                            # sic (:468)
+                w._stale = True
+                w.iteration += 1
+            n_ok = int(np.sum(posdefs_l))
+            red = comm.allreduce_max(np.array([1.0 if n_ok > 0 else 0.0,
+                                               0.0 if n_ok == self.K_local else 1.0,
+                                               np.max(tl), np.max(ml), np.max(rl)]))
+            if verbose:
+                if red[1] == 0.0:
+                    print("\rAll sites ok")
+                elif red[0] > 0:
+                    print("\rSome sites failed and are not updated")
+                else:
+                    print("\rEvery site failed")
+            if red[0] == 0.0:                                       # :1033-1040
+                self._download_sites()
+                return self._ret(self.INFO_ALL_SITES_FAIL, calc_moments, return_analytics,
+                                 moments, analytics)
+            stimes[cur_iter], msteps[cur_iter], mrhats[cur_iter] = red[2], red[3], red[4]   # :1043-1045
+            if verbose:
+                print("Sampling done, max sampling time {}".format(stimes[cur_iter]))
+            start_othertime = time.time()
+
+            # ---- the one reduction per iteration (:1073-1074, affine in df)
+            packed = comm.allreduce_sum(eng.site_sums(self._packed))
+
+            df = self.df0(self.iter)                                # :1060
+            if verbose:
+                print("Iter {}, starting df {:.3g}".format(self.iter, df))
+            fail_printline = False
+            failed_force_pos_def = False
+            while True:                                             # :1067
+                g_pd, c_pd, first_bad = eng.damped_trial(df, packed)
+                if g_pd:
+                    if comm.world > 1:
+                        c_pd = bool(comm.allreduce_min_int(1 if c_pd else 0))
+                    if c_pd:                                        # :1145-1158 accept
+                        eng.accept(df)
+                        for w in local_workers:
+                            w.Q, w.r = self.Q, self.r
+                            w.phase = 1
+                            w._stale = True
+                        break
+                df *= self.df_decay                                 # :1083 / :1163
+                if verbose:
+                    fail_printline = True
+                    if not g_pd:
+                        sys.stdout.write("\rNon pos. def. posterior cov, " +
+                                         "reducing df to {:.3}".format(df) + " "*5 + "\b"*5)
+                    else:
+                        sys.stdout.write("\rNon pos. def. cavity, " +
+                                         "(first encountered in site {}), ".format(first_bad + lo) +
+                                         "reducing df to {:.3}".format(df) + " "*5 + "\b"*5)
+                    sys.stdout.flush()
+                if not g_pd and self.iter == 1:                     # :1092-1101
+                    if verbose:
+                        print("\nInvalid prior.")
+                    self._download_sites()
+                    return self._ret(self.INFO_INVALID_PRIOR, calc_moments, return_analytics,
+                                     moments, analytics)
+                if df < self.df_treshold:                           # :1102-1132 / :1177-1207
+                    if verbose:
+                        print("\nDamping factor reached minimum.")
+                    df = self.df0(self.iter)
+                    if failed_force_pos_def:
+                        if verbose:
+                            print("Failed to force pos_def.")
+                        self._download_sites()
+                        return self._ret(self.INFO_DF_TRESHOLD_REACHED_CAVITY, calc_moments,
+                                         return_analytics, moments, analytics)
+                    failed_force_pos_def = True
+                    forced = eng.force_pd(df, self.MIN_EIG_TRESHOLD, self.MIN_EIG)
+                    if verbose:
+                        print("Force sites {} pos_def.".format(np.nonzero(forced)[0] + lo))
+                    # the shift changed Qi: refresh the sums
+                    packed = comm.allreduce_sum(eng.site_sums(self._packed))
+            if verbose and fail_printline:
+                print()
+
+            if calc_moments:                                        # :1211-1219
+                S, m = eng.global_moments()
+                self.S[...] = S
+                self.m[...] = m
+                np.copyto(m_phi_s[cur_iter], m)
+                np.copyto(cov_phi_s[cur_iter], S.T)
+                if verbose:
+                    print("Mean and std of phi[0]: {:.3}, {:.3}".format(
+                        m_phi_s[cur_iter, 0], np.sqrt(cov_phi_s[cur_iter, 0, 0])))
+            othertimes[cur_iter] = time.time() - start_othertime   # :1230
+            if verbose:
+                print("Iter {} done.".format(self.iter))
+
+        if save_last_param:
+            for w in local_workers:
+                w.saved_samp = {'phi': eng.get_draws(w._k)}
+        self._download_sites()
+        if verbose:
+            print("{} iterations done\nTotal limiting sampling time: {}"
+                  .format(niter, stimes.sum()))
+        return self._ret(self.INFO_OK, calc_moments, return_analytics, moments, analytics,
+                         as_tuple=True)
+
+    # ------------------------------------------------------------------
+    def _tilted_injected(self, sseeds, estim):
+        """Test hook: draws come from `self._sample_injector(data, stan_params)`
+        (same role as the reference's `_sample_stan`, method.py:43) and go
+        through the device moment kernel."""
+        eng = self.engine
+        samples = None
+        for j, w in enumerate(self.workers[self.k_lo:self.k_hi]):
+            w.stan_params['seed'] = int(sseeds[j])
+            w._refresh_for_injection()
+            samp = np.asarray(self._sample_injector(w.data, w.stan_params), dtype=np.float64)
+            if samples is None:
+                samples = np.empty((samp.shape[0], samp.shape[1], self.K_local), order='F')
+            samples[:, :, j] = samp
+        posdefs = eng.moments_batch(samples, estim)
+        n = self.K_local
+        return posdefs, np.full(n, 0.25), np.full(n, 0.125), np.full(n, 1.0625)

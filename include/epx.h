@@ -1,0 +1,208 @@
+/*
+ * epx.h -- C ABI of libepx.so: the MI355X (gfx950) engine behind ep-stan's
+ * data-parallel EP inner loop.
+ *
+ * Every entry point replaces one piece of /root/reference/epstan (cited per
+ * function as file:line) and is what a ctypes binding in the reference's
+ * epstan/method.py would call instead of PyStan + SciPy/LAPACK (INTEGRATION.md
+ * shows that binding).  Conventions:
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - every function returns 0 on success, <0 on error; the message is kept
+ *     per thread and read with epx_last_error();
+ *   - the caller owns host buffers, the library owns device buffers behind an
+ *     opaque epx_ctx bound to ONE HIP device; a ctx is not thread-safe; calls
+ *     are synchronous on return (the stream is drained);
+ *   - all reals are float64; matrices are column-major ("F order") exactly as
+ *     the reference lays them out: site arrays (d,d,K) / (d,K) with the site
+ *     index slowest (method.py:838-851), so site k is one contiguous d*d block;
+ *   - pointers named *_dev are DEVICE addresses (e.g. torch tensor.data_ptr()),
+ *     used for the RCCL all-reduce that torch.distributed performs between
+ *     epx_site_sums() and epx_damped_trial().
+ */
+#ifndef EPX_H
+#define EPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct epx_ctx epx_ctx;
+
+/* Site log-density families: the reference's single-group Stan programs
+ * experiment/models/m{1,2,3,4,5}b_sg.stan (selected by the basename of the
+ * `site_model` path given to Master, method.py:647,672). */
+enum epx_model { EPX_M1B_SG = 0, EPX_M2B_SG = 1, EPX_M3B_SG = 2, EPX_M4B_SG = 3, EPX_M5B_SG = 4 };
+
+/* Worker.PREC_ESTIM_OPTIONS, method.py:163 */
+enum epx_prec_estim { EPX_PREC_SAMPLE = 0, EPX_PREC_OLSE = 1 };
+
+/* which site array an accessor addresses (method.py:844-851) */
+enum epx_which { EPX_QI = 0, EPX_QI2 = 1, EPX_DQI = 2 };
+
+/* init modes of the sampler: Stan's init='random' / '0' (method.py:159, 579-583)
+ * or the last draw of each chain of the previous call (init_prev, :404-406). */
+enum epx_init { EPX_INIT_RANDOM = 0, EPX_INIT_ZERO = 1, EPX_INIT_PREV = 2 };
+
+/* Sampler settings = Worker.DEFAULT_STAN_PARAMS (method.py:154-160) plus the
+ * Stan 2.17 control defaults the reference leaves untouched. */
+typedef struct epx_sampler_opts {
+    int32_t chains;      /* default 4 */
+    int32_t iter;        /* default 1000; fit.py uses 200 */
+    int32_t warmup;      /* <0 means iter/2 (warmup=None, method.py:157,567-569) */
+    int32_t thin;        /* default 1 */
+    int32_t init;        /* enum epx_init */
+    int32_t max_depth;   /* Stan max_treedepth, default 10 */
+    int32_t layout;      /* 0 auto, 1 one block per site, 2 one block per (site,chain) */
+    int32_t reserved;
+} epx_sampler_opts;
+
+/* per-site sampler statistics written by epx_tilted_batch (doubles) */
+enum epx_site_stat {
+    EPX_ST_STEPSIZE = 0,   /* mean over chains of mean stepsize__ (method.py:99-102) */
+    EPX_ST_RHAT = 1,       /* max split-Rhat over sampled coordinates (method.py:104) */
+    EPX_ST_NLEAP = 2,      /* leapfrogs in trees, all chains */
+    EPX_ST_NGRAD = 3,      /* gradient evaluations, all chains */
+    EPX_ST_NDIV = 4,       /* divergent post-warm-up transitions */
+    EPX_ST_ACCEPT = 5,     /* mean post-warm-up accept_stat */
+    EPX_ST_DEPTH = 6,      /* mean post-warm-up tree depth */
+    EPX_ST_FAIL = 7,       /* >0: a chain started at a non-finite density */
+    EPX_ST_COUNT = 8
+};
+
+const char *epx_last_error(void);
+int epx_device_count(int *count);
+
+/* dphi and number of sampled coordinates P of a model (m*b_sg.stan parameter blocks). */
+int epx_model_dims(int model, int D, int *dphi, int *npar);
+
+/*
+ * Context = the K_local sites of one rank: replaces Master.__init__'s worker
+ * construction and array allocation (method.py:817-851).  X is the rank's
+ * (N_local, D) row-major block (C-contiguous, method.py:733), y its 0/1
+ * responses, k_lim[K_local+1] the row limits of the sites (method.py:700).
+ * Sites are ordered; site k owns rows k_lim[k]..k_lim[k+1].
+ */
+int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim,
+                   const double *X, const int32_t *y, epx_ctx **out);
+int epx_ctx_destroy(epx_ctx *ctx);
+
+/* prior natural parameters Q0 (d,d) F-order, r0 (d): method.py:772-797 */
+int epx_set_prior(epx_ctx *ctx, const double *Q0, const double *r0);
+
+/* host <-> device copies of the site arrays, F-order (d,d,K_local) / (d,K_local)
+ * (method.py:844-851); either pointer may be NULL. */
+int epx_set_sites(epx_ctx *ctx, int which, const double *QF, const double *rF);
+int epx_get_sites(epx_ctx *ctx, int which, double *QF, double *rF);
+
+/* one site's (d,d) / (d) block of a site array: the NumPy views dQi[:,:,k], dri[:,k]
+ * that Worker.tilted / Worker.cavity take (method.py:1012-1023, find_damp.py:139,160) */
+int epx_set_site(epx_ctx *ctx, int which, int k, const double *Q, const double *r);
+int epx_get_site(epx_ctx *ctx, int which, int k, double *Q, double *r);
+
+/* global approximation Q (d,d), r (d) held by the context (method.py:841-842) */
+int epx_set_global(epx_ctx *ctx, const double *Q, const double *r);
+int epx_get_global(epx_ctx *ctx, double *Q, double *r);
+
+/*
+ * Worker.cavity for sites k0..k0+count (method.py:267-302), batched:
+ * Mat_k = Q - A_k, vec_k = Mat_k^-1 (r - a_k), posdef[k] = Cholesky succeeded,
+ * where (A_k, a_k) = site array `which`; for which == EPX_QI2 the proposal
+ * Qi + df*dQi is formed on the fly (method.py:1071-1072) with the df of the
+ * last epx_damped_trial.  The results stay on the device as the sampler's
+ * Omega_phi / mu_phi (method.py:221-222).
+ */
+int epx_cavity_batch(epx_ctx *ctx, int which, int k0, int count, uint8_t *posdef);
+/* cavity of ONE site from caller-supplied arrays (the find_damp.py:160 pattern) */
+int epx_cavity_site(epx_ctx *ctx, int k, const double *Q, const double *r, const double *Qi,
+                    const double *ri, uint8_t *posdef);
+/* Worker.Mat / Worker.vec of site k after cavity (phase 1) */
+int epx_get_cavity(epx_ctx *ctx, int k, double *Mat, double *vec);
+
+/*
+ * Worker.tilted for sites k0..k0+count (method.py:305-475), batched: on-GPU
+ * NUTS draws from each site's tilted distribution (replaces _sample_stan,
+ * method.py:43-118), then mean / scatter / precision estimate / site delta
+ * (:410-458) into the device dQi, dri.  seeds[count] are the per-site Stan
+ * seeds of method.py:346.  The global (Q, r) subtracted at :457-458 is the one
+ * held by the context.  posdef[count] out; stats[count*EPX_ST_COUNT] out (may
+ * be NULL); elapsed_ms out (may be NULL): device time of the sampling kernel.
+ */
+int epx_tilted_batch(epx_ctx *ctx, int k0, int count, const int64_t *seeds,
+                     const epx_sampler_opts *opts, int prec_estim, uint8_t *posdef,
+                     double *stats, double *elapsed_ms);
+/*
+ * TEST HOOK: the moment stage alone on injected draws.  samples is
+ * (S, d, count) F-order, i.e. per site an (S,d) column-major block like the
+ * `samp` array of method.py:362.
+ */
+int epx_moments_batch(epx_ctx *ctx, int k0, int count, const double *samples, int S,
+                      int prec_estim, uint8_t *posdef);
+/* Worker.vec (tilted mean) and Worker.Mat (unnormalised scatter C'C) of site k
+ * after tilted (phase 2); nsamp out (method.py:408) */
+int epx_get_tilted(epx_ctx *ctx, int k, double *Mat, double *vec, int *nsamp);
+/* phi draws of site k in the reference's layout: (S, dphi) F-order, chains
+ * concatenated chain-major (util.py:475-484); all sampled coordinates with
+ * npar_out = 1: (S, P) F-order. */
+int epx_get_draws(epx_ctx *ctx, int k, int all_params, double *out);
+int epx_num_draws(epx_ctx *ctx, int *S);
+
+/*
+ * Local part of the reduction of method.py:1073-1074:
+ * packed = [sum_k Qi (d*d), sum_k ri (d), sum_k dQi (d*d), sum_k dri (d)] over
+ * this rank's sites.  Because Q(df) = Q0 + sum Qi + df * sum dQi is affine in
+ * df, ONE all-reduce of this buffer per EP iteration serves every damping
+ * trial.  Exactly one of packed_host / packed_dev may be non-NULL.
+ */
+int epx_site_sums(epx_ctx *ctx, double *packed_host, double *packed_dev);
+int epx_packed_len(epx_ctx *ctx, int *len);
+
+/*
+ * One trial of the damping loop (method.py:1067-1143) with damping factor df:
+ * forms Q, r from the (all-reduced) packed sums, Cholesky-checks Q
+ * (global_pd), and if positive definite runs the cavities of all local sites
+ * against Qi + df*dQi (cav_pd = 1 iff all local cavities are pos.def.,
+ * first_bad = first failing local site or -1).
+ */
+int epx_damped_trial(epx_ctx *ctx, double df, const double *packed_host,
+                     const double *packed_dev, int *global_pd, int *cav_pd, int *first_bad);
+/* accept: Qi <- Qi + df*dQi, ri <- ri + df*dri (the swap of method.py:1145-1158) */
+int epx_accept(epx_ctx *ctx, double df);
+/* moments of the accepted global approximation (method.py:1211-1219):
+ * S = Q^-1 (d,d), m = S r */
+int epx_global_moments(epx_ctx *ctx, double *S, double *m);
+/* force-pd fallback, method.py:1119-1129: min eigenvalue of Qi + df*dQi per
+ * local site; where it is < thresh, adds (min_eig_target - min_eig) to the
+ * diagonal of Qi.  forced[K_local] out. */
+int epx_force_pd(epx_ctx *ctx, double df, double thresh, double min_eig_target, uint8_t *forced);
+
+/* TEST HOOK: log density and gradient of site k at theta (P) against the
+ * cavity currently held for that site (Appendix A of SURVEY.md). */
+int epx_logdensity_grad(epx_ctx *ctx, int k, const double *theta, double *lp, double *grad);
+/* TEST HOOK: sampler only (no moment stage) for sites k0..k0+count */
+int epx_sample_batch(epx_ctx *ctx, int k0, int count, const int64_t *seeds,
+                     const epx_sampler_opts *opts, double *stats, double *elapsed_ms);
+/* chain stats of the last sampling call: (count, chains, EPX_ST_COUNT) */
+int epx_get_chain_stats(epx_ctx *ctx, int k0, int count, double *out);
+/* TEST HOOK: uniforms/normals of the device random stream */
+int epx_rng_probe(int device, uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a,
+                  uint32_t b, double *out4);
+
+/*
+ * Stand-alone batched forms of epstan/util.py on device (no context needed):
+ * util.invert_normal_params (util.py:51-125): (A,b) -> (A^-1, A^-1 b), A given
+ * as SPD matrices or, with cho_form, as UPPER Cholesky factors; nb matrices of
+ * order d, F-order, in place; b may be NULL; info[nb]: 0 ok, 1 not pos.def.
+ */
+int epx_invert_normal_params(int device, int d, int nb, double *A, double *b, int cho_form,
+                             int32_t *info);
+/* util.olse (util.py:128-194): shrinkage precision estimate of sample
+ * covariances S (nb of order d, in place) from n draws with prior matrix P
+ * (nb matrices, or NULL for the naive I/d prior). */
+int epx_olse(int device, int d, int nb, double *S, int n, const double *P, int32_t *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPX_H */
