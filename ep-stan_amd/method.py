@@ -335,6 +335,9 @@ class Master(object):
         self.sync_sites = gpu['sync_sites']
         self.comm = gpu['comm'] if gpu['comm'] is not None else _dist.LocalComm()
         self._sample_injector = None        # test hook: f(data, stan_params) -> (S, d) draws
+        self.last_site_stats = None         # sampler statistics of the last iteration (local sites)
+        self.sampling_ms = []               # device time of every sampling launch (this rank)
+        self.ngrad_log = []                 # gradient evaluations of every sampling launch (this rank)
 
         # ---- validate X, y (method.py:674-689)
         self.N = X.shape[0]
@@ -625,6 +628,9 @@ class Master(object):
             else:
                 opts = w0._sampler_opts()
                 posdefs_l, stats, ms = eng.tilted_batch(sseeds, opts, estim)
+                self.last_site_stats = stats        # (K_local, 8): see epx_site_stat in include/epx.h
+                self.sampling_ms.append(ms)
+                self.ngrad_log.append(float(stats[:, 3].sum()))
                 tl = np.full(self.K_local, ms * 1e-3)
                 ml, rl = stats[:, 0], stats[:, 1]
             for j, w in enumerate(local_workers):

@@ -1,0 +1,388 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle and
+the golden vectors captured from the reference.  Need a real MI355X."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import epstan_amd                                    # noqa: E402
+from epstan_amd import _lib, models, util            # noqa: E402
+from epstan_amd.engine import HipEngine, QI, QI2, DQI   # noqa: E402
+from epstan_amd.method import Master, Worker         # noqa: E402
+from oracle import ep_oracle as eo                   # noqa: E402
+from oracle import nuts_oracle as no                 # noqa: E402
+import injectors                                     # noqa: E402
+
+# deterministic stages: SURVEY.md §8c tolerance (QR vs Cholesky-of-scatter and
+# reduction order differ by cond * eps)
+RTOL, ATOL = 1e-9, 1e-10
+
+
+@pytest.fixture(scope='module')
+def alg(golden_dir):
+    return np.load(os.path.join(golden_dir, 'algebra.npz'))
+
+
+@pytest.fixture(scope='module')
+def runs(golden_dir):
+    return np.load(os.path.join(golden_dir, 'master_run.npz'))
+
+
+def test_native_library_is_loaded():
+    lib = _lib.load()
+    assert _lib.device_count() >= 1
+    with open('/proc/self/maps') as f:
+        assert 'libepx.so' in f.read()
+
+
+# ------------------------------------------------------------------ RNG
+def test_rng_stream_matches_oracle():
+    import ctypes
+    lib = _lib.load()
+    out = np.zeros(4)
+    for (seed, chain, t, kind, a, b) in [(1, 0, 0, 0, 0, 0), (327741615, 3, 17, 4, (5 << 16) | 13, 2),
+                                         (2**31 - 2, 1, 200, 1, 25, 0), (12345678901, 2, 7, 5, 3, 9)]:
+        _lib.check(lib.epx_rng_probe(0, seed, chain, t, kind, a, b, _lib.dptr(out)))
+        ref = no.rng_probe(seed, chain, t, kind, a, b)
+        assert out[0] == ref[0] and out[1] == ref[1]          # Philox + u01: bit exact
+        np.testing.assert_allclose(out[2:], ref[2:], rtol=1e-13, atol=1e-15)   # libm vs ocml
+
+
+# ------------------------------------------------------------------ util
+@pytest.mark.parametrize('d', [5, 17, 33, 66])
+def test_invert_normal_params_golden(alg, d):
+    Q, r = util.invert_normal_params(alg['g1_S_%d' % d], alg['g1_m_%d' % d])
+    assert Q.flags['F_CONTIGUOUS']
+    np.testing.assert_allclose(Q, alg['g1_Q_%d' % d], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(r, alg['g1_r_%d' % d], rtol=RTOL, atol=ATOL)
+    np.testing.assert_array_equal(Q, Q.T)                     # copy_triu_to_tril
+    Q, r = util.invert_normal_params(alg['g1_U_%d' % d], alg['g1_m_%d' % d], cho_form=True)
+    np.testing.assert_allclose(Q, alg['g1_Qc_%d' % d], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(r, alg['g1_rc_%d' % d], rtol=RTOL, atol=ATOL)
+    # in-place / out_ forms (util.py:88-108)
+    A = alg['g1_S_%d' % d].copy(order='F'); b = alg['g1_m_%d' % d].copy()
+    oA, ob = util.invert_normal_params(A, b, out_A='in-place', out_b='in-place')
+    assert oA is A and ob is b
+    np.testing.assert_allclose(A, alg['g1_Q_%d' % d], rtol=RTOL, atol=ATOL)
+    C = np.ascontiguousarray(alg['g1_S_%d' % d])              # C-order input is transposed
+    np.testing.assert_allclose(util.invert_normal_params(C)[0], alg['g1_Q_%d' % d], rtol=RTOL, atol=ATOL)
+
+
+def test_invert_not_posdef_raises(alg):
+    with pytest.raises(np.linalg.LinAlgError):
+        util.invert_normal_params(alg['g1_bad'], np.zeros(6))
+    with pytest.raises(np.linalg.LinAlgError):
+        util.invert_normal_params(np.zeros((3, 3), order='F'), cho_form=True)
+    big = np.asfortranarray(np.eye(140) * 2.0 + 0.01)         # d = 140: global-workspace path
+    Q, _ = util.invert_normal_params(big)
+    np.testing.assert_allclose(Q, np.linalg.inv(big), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('d', [5, 17, 33])
+@pytest.mark.parametrize('n', [100, 400])
+def test_olse_golden(alg, d, n):
+    key = '%d_%d' % (d, n)
+    np.testing.assert_allclose(util.olse(alg['g2_S_' + key], n), alg['g2_none_' + key], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(util.olse(alg['g2_S_' + key], n, P=alg['g2_P_' + key]),
+                               alg['g2_prior_' + key], rtol=RTOL, atol=ATOL)
+
+
+# ------------------------------------------------------------------ Worker
+def test_worker_cavity_golden(alg):
+    rng = np.random.RandomState(13)
+    X = rng.randn(20, 4); y = (rng.rand(20) < 0.5).astype(int)
+    w = Worker(0, 'none/m4b_sg', 10, X, y)
+    assert w.cavity(alg['g3_Q'], alg['g3_r'], alg['g3_Qi'], alg['g3_ri']) == bool(alg['g3_flag'])
+    assert w.phase == int(alg['g3_phase'])
+    np.testing.assert_allclose(w.Mat, alg['g3_Mat'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(w.vec, alg['g3_vec'], rtol=RTOL, atol=ATOL)
+    assert not w.cavity(alg['g3_Q'], alg['g3_r'], alg['g3_Qi_bad'], alg['g3_ri'])
+    assert w.phase == int(alg['g3_phase_bad']) == 0
+    with pytest.raises(RuntimeError):
+        w.tilted(np.zeros((10, 10), order='F'), np.zeros(10))
+
+
+def g4_samples(seed, S, d):
+    rng = np.random.RandomState(seed)
+    mix = np.eye(d) + 0.3 * rng.randn(d, d) / np.sqrt(d)
+    shift = rng.randn(d)
+    return np.asfortranarray(rng.randn(S, d).dot(mix) + shift)
+
+
+@pytest.mark.parametrize('d,model,D', [(5, 'm1b_sg', 4), (10, 'm4b_sg', 4), (17, 'm1b_sg', 16), (34, 'm4b_sg', 16)])
+@pytest.mark.parametrize('est', ['sample', 'olse'])
+def test_tilted_moment_stage_golden(alg, d, model, D, est):
+    """Worker.tilted's moment stage with the reference's injected draws (G4)."""
+    rng = np.random.RandomState(14)
+    X = rng.randn(40, D); y = (rng.rand(40) < 0.5).astype(int)
+    eng = HipEngine(model, X, y, np.array([0, 20, 40]))
+    assert eng.d == d
+    eng.set_global(alg['g4_Q_%d' % d], alg['g4_r_%d' % d])
+    samp = g4_samples(int(alg['g4_seed_%d' % d]), 400, d)
+    both = np.asfortranarray(np.stack([samp, samp[::-1]], axis=2))
+    flags = eng.moments_batch(both, est)
+    key = '%s_%d' % (est, d)
+    assert flags.tolist() == [bool(alg['g4_flag_' + key])] * 2
+    for k in range(2):      # reversing the draw order must not matter beyond rounding
+        dQ, dr = eng.get_site(DQI, k)
+        np.testing.assert_allclose(dQ, alg['g4_dQi_' + key], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(dr, alg['g4_dri_' + key], rtol=RTOL, atol=1e-9)
+        Mat, vec, nsamp = eng.get_tilted(k)
+        np.testing.assert_allclose(vec, alg['g4_vec_' + key], rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(Mat, alg['g4_scatter_%d' % d], rtol=RTOL, atol=1e-9)
+        assert nsamp == int(alg['g4_nsamp_' + key])
+
+
+def test_tilted_singular_scatter_fails_softly():
+    rng = np.random.RandomState(3)
+    X = rng.randn(20, 4); y = (rng.rand(20) < 0.5).astype(int)
+    eng = HipEngine('m1b_sg', X, y, np.array([0, 10, 20]))
+    eng.set_global(np.eye(5), np.zeros(5))
+    samp = rng.randn(400, 5, 2)
+    samp[:, 0, 1] = 1.25                                    # constant column -> singular (method.py:460-465)
+    flags = eng.moments_batch(np.asfortranarray(samp), 'sample')
+    assert flags.tolist() == [True, False]
+    dQ, dr = eng.get_site(DQI, 1)
+    assert not dQ.any() and not dr.any()
+
+
+# ------------------------------------------------------------------ Master.run trajectories (G6)
+def _master(runs, scenario, df0, nsites=4, prec_estim='sample', factor=60.0, **kw):
+    Nj = runs['g6_Nj'][:nsites]
+    nrow = int(Nj.sum())
+    M = Master('some/dir/m1b_sg', runs['g6_X'][:nrow], runs['g6_y'][:nrow], site_sizes=Nj,
+               prior={'Q': runs['g6_Q0'], 'r': runs['g6_r0']},
+               A_k={'site_id': np.arange(nsites)}, chains=4, iter=200, df0=df0,
+               prec_estim=prec_estim, **kw)
+    M._sample_injector = injectors.GaussianTilted(scenario, factor=factor)
+    return M
+
+
+@pytest.mark.parametrize('tag,scenario,niter,df0,nsites,est,factor', [
+    ('smooth', 'smooth', 12, 0.5, 4, 'sample', 60.0),
+    ('smooth_olse', 'smooth', 6, 0.5, 4, 'olse', 60.0),
+    ('decay', 'wide_first', 4, 1.0, 3, 'sample', 60.0),
+    ('allfail', 'degenerate', 3, 0.5, 4, 'sample', 60.0),
+    ('badprior', 'wide_all', 3, 1.0, 4, 'sample', 400.0),
+])
+def test_master_run_reference_trajectory_on_gpu(runs, tag, scenario, niter, df0, nsites, est, factor):
+    M = _master(runs, scenario, df0, nsites, est, factor)
+    assert isinstance(M.engine, HipEngine)
+    info, (m_s, S_s), (st, ms, rh, ot) = M.run(niter, verbose=False, return_analytics=True, seed=1)
+    assert info == int(runs['g6_%s_info' % tag])
+    assert M.iter == int(runs['g6_%s_iter' % tag])
+    np.testing.assert_allclose(m_s, runs['g6_%s_m' % tag], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(S_s, runs['g6_%s_S' % tag], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(M.Qi, runs['g6_%s_Qi' % tag], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(M.ri, runs['g6_%s_ri' % tag], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(M.Q, runs['g6_%s_Q' % tag], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(M.r, runs['g6_%s_r' % tag], rtol=1e-8, atol=1e-9)
+    np.testing.assert_array_equal([w.phase for w in M.workers], runs['g6_%s_phase' % tag])
+
+
+def test_master_resume_and_force_pd_on_gpu(runs):
+    M = _master(runs, 'smooth', 0.5)
+    M.run(2, verbose=False, seed=5)
+    info, (m_s, S_s) = M.run(2, verbose=False, seed=6)
+    np.testing.assert_allclose(m_s, runs['g6_resume_m'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(S_s, runs['g6_resume_S'], rtol=1e-8, atol=1e-10)
+    S, m = M.cur_approx()
+    np.testing.assert_allclose(S, S_s[-1].T, rtol=1e-9)
+    # force-pd branch vs the oracle restatement
+    Mf = _master(runs, 'wide_first', 1.0, nsites=3, df_treshold=0.9)
+    info = Mf.run(2, verbose=False, calc_moments=False, seed=1)
+    inj = injectors.GaussianTilted('wide_first')
+    Nj = runs['g6_Nj'][:3]; nrow = int(Nj.sum())
+    O = eo.OracleMaster(runs['g6_X'][:nrow], runs['g6_y'][:nrow], Nj,
+                        lambda data, sp: (inj(data, sp), [{}] * 4, 0.25, 0.125, 1.0625),
+                        prior={'Q': runs['g6_Q0'], 'r': runs['g6_r0']},
+                        A_k={'site_id': np.arange(3)}, chains=4, iter=200, df0=1.0, df_treshold=0.9)
+    assert O.run(2, seed=1)[0] == info == 0
+    np.testing.assert_allclose(Mf.Qi, O.Qi, rtol=1e-8, atol=1e-9)
+
+
+def test_find_damp_access_pattern_on_gpu(runs):
+    M = _master(runs, 'smooth', 0.5)
+    posdefs = [w.tilted(M.dQi[:, :, k], M.dri[:, k], seed=11 + k) for k, w in enumerate(M.workers)]
+    assert all(posdefs)
+    df = 0.3
+    np.add(M.Qi, np.multiply(df, M.dQi, out=M.Qi2), out=M.Qi2)
+    np.add(M.ri, np.multiply(df, M.dri, out=M.ri2), out=M.ri2)
+    np.add(M.Qi2.sum(2, out=M.Q), M.Q0, out=M.Q)
+    np.add(M.ri2.sum(1, out=M.r), M.r0, out=M.r)
+    for k, w in enumerate(M.workers):
+        assert w.cavity(M.Q, M.r, M.Qi2[:, :, k], M.ri2[:, k])
+        Mat, vec, ok = eo.cavity(M.Q, M.r, M.Qi2[:, :, k], M.ri2[:, k])
+        np.testing.assert_allclose(w.Mat, Mat, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(w.vec, vec, rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------ site log-density
+def _site_problem(model, D, n, seed, K=2):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(K * n, D) * 1.5
+    y = (rng.rand(K * n) < 0.6).astype(int)
+    d, P = no.dims(model, D)
+    Oms, mus = [], []
+    for k in range(K):
+        A = rng.randn(d, d + 3)
+        Oms.append(A.dot(A.T) / (d + 3) + 0.5 * np.eye(d))
+        mus.append(0.5 * rng.randn(d))
+    return X, y, np.arange(K + 1) * n, np.array(Oms), np.array(mus), d, P
+
+
+def _engine_with_cavity(model, X, y, k_lim, Oms, mus):
+    """Engine whose device cavities are exactly (Oms[k], mus[k])."""
+    eng = HipEngine(model, X, y, k_lim)
+    d = eng.d
+    for k in range(eng.K):
+        # cavity = Q - Qi with Q = Om + I, Qi = I ; mean = Om^-1 (r - ri)
+        Q = Oms[k] + np.eye(d)
+        r = Oms[k].dot(mus[k])
+        ok = eng.cavity_site(k, Q, r, np.eye(d), np.zeros(d))
+        assert ok
+    return eng
+
+
+@pytest.mark.parametrize('model', ['m1b_sg', 'm2b_sg', 'm3b_sg', 'm4b_sg', 'm5b_sg'])
+@pytest.mark.parametrize('D,n', [(3, 7), (4, 50), (16, 200), (21, 333), (32, 500)])
+def test_logdensity_gradient_matches_oracle(model, D, n):
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 100 + D)
+    eng = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    rng = np.random.RandomState(5)
+    for k in range(2):
+        Om_dev, mu_dev = eng.get_cavity(k)
+        for trial in range(3):
+            theta = rng.randn(P) * (0.2 + 0.4 * trial)
+            lp, g = eng.logdensity_grad(k, theta)
+            lo, hi = k_lim[k], k_lim[k + 1]
+            lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev, Om_dev, theta)
+            assert abs(lp - lp_o) <= 1e-11 * max(1.0, abs(lp_o))
+            np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
+
+
+# ------------------------------------------------------------------ sampler vs oracle, draw by draw
+@pytest.mark.parametrize('model,D,n,layout', [
+    ('m1b_sg', 4, 50, 2), ('m4b_sg', 4, 50, 2), ('m4b_sg', 4, 50, 1), ('m5b_sg', 4, 50, 1),
+    ('m2b_sg', 6, 80, 2), ('m3b_sg', 6, 80, 1), ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1),
+    ('m4b_sg', 32, 120, 1), ('m1b_sg', 32, 300, 2),
+])
+def test_nuts_draws_match_oracle(model, D, n, layout):
+    """Same Philox stream, same decisions: the device draws follow the C
+    restatement through warm-up (step-size search, dual averaging, metric
+    window) and sampling.  Tolerance 1e-6: trajectories amplify the ~1e-16
+    differences of reduction order and libm/ocml over ~10^3 leapfrogs."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3)
+    eng = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(3)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(3)])
+    seeds = np.array([101, 202, 303], dtype=np.int64)
+    opts = HipEngine.sampler_opts(chains=4, iter=60, warmup=None, init='random', layout=layout)
+    stats, ms = eng.sample_batch(seeds, opts)
+    draws_o, last_o, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=4, iter=60)
+    cs = eng.get_chain_stats(4)
+    for k in range(3):
+        dev = eng.get_draws(k, all_params=True)
+        ref = draws_o[k].reshape(-1, P)
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(dev - ref).max() < 1e-6 * scale, (k, np.abs(dev - ref).max())
+        np.testing.assert_array_equal(cs[k, :, 2], st_o[k, :, 2])          # same leapfrog counts
+        np.testing.assert_allclose(cs[k, :, 0], st_o[k, :, 0], rtol=1e-7)  # same step-size path
+        phi = eng.get_draws(k)
+        np.testing.assert_array_equal(phi, dev[:, :d])                     # (S, dphi) F-order view
+        assert phi.flags['F_CONTIGUOUS'] and phi.shape == (4 * 30, d)
+    np.testing.assert_allclose(stats[:, 2], st_o[:, :, 2].sum(1))
+    rh = [max(no.split_rhat(draws_o[k, :, :, e]) for e in range(P)) for k in range(3)]
+    np.testing.assert_allclose(stats[:, 1], rh, rtol=1e-5)
+
+
+def test_nuts_layouts_agree_and_are_deterministic():
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 8, 90, 3, K=2)
+    eng = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    seeds = np.array([5, 6], dtype=np.int64)
+    out = {}
+    for layout in (1, 2, 1):
+        opts = HipEngine.sampler_opts(chains=4, iter=80, init='random', layout=layout)
+        eng.sample_batch(seeds, opts)
+        out.setdefault(layout, []).append(np.stack([eng.get_draws(k, True) for k in range(2)]))
+    np.testing.assert_array_equal(out[1][0], out[1][1])                    # bitwise reproducible
+    assert np.abs(out[1][0] - out[2][0]).max() < 1e-6                      # 1 wave/chain vs 4 waves/chain
+
+
+def test_nuts_warm_start_and_thin():
+    """init_prev (method.py:404-406): the next call starts at the last draws."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m1b_sg', 4, 60, 9, K=2)
+    eng = _engine_with_cavity('m1b_sg', X, y, k_lim, Oms, mus)
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(2)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(2)])
+    seeds = np.array([1, 2], dtype=np.int64)
+    with pytest.raises(_lib.EpxError):
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=2, iter=40, init='prev'))
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=2, iter=40, init='0'))
+    d0, last0, _ = no.nuts_sites('m1b_sg', X, y, k_lim, mu_dev, Om_dev, seeds, chains=2, iter=40,
+                                 init=np.zeros((2, 2, P)))
+    assert np.abs(eng.get_draws(0, True) - d0[0].reshape(-1, P)).max() < 1e-6
+    seeds2 = np.array([8, 9], dtype=np.int64)
+    eng.sample_batch(seeds2, HipEngine.sampler_opts(chains=2, iter=40, thin=1, init='prev'))
+    d1, _, _ = no.nuts_sites('m1b_sg', X, y, k_lim, mu_dev, Om_dev, seeds2, chains=2, iter=40, init=last0)
+    assert np.abs(eng.get_draws(1, True) - d1[1].reshape(-1, P)).max() < 1e-5
+
+
+def test_nuts_long_run_moments_match_oracle_statistically():
+    """Independent seeds: GPU and oracle estimate the same tilted moments within
+    Monte-Carlo error (4 sigma of the MCSE from split chains)."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 4, 50, 21, K=2)
+    eng = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(2)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(2)])
+    opts = HipEngine.sampler_opts(chains=4, iter=3000, warmup=500, init='random')
+    stats, _ = eng.sample_batch(np.array([1, 2], dtype=np.int64), opts)
+    draws_o, _, _ = no.nuts_sites('m4b_sg', X, y, k_lim, mu_dev, Om_dev, np.array([77, 78]),
+                                  chains=4, iter=3000, warmup=500)
+    assert stats[:, 1].max() < 1.05
+    for k in range(2):
+        g = eng.get_draws(k, True)
+        o = draws_o[k].reshape(-1, P)
+        sd = o.std(0)
+        ess = 2000.0                                        # conservative for 10000 NUTS draws
+        assert np.all(np.abs(g.mean(0) - o.mean(0)) < 4 * sd * np.sqrt(2 / ess))
+        assert np.all(np.abs(g.std(0) / sd - 1) < 4 * np.sqrt(1.0 / ess))
+
+
+# ------------------------------------------------------------------ full pipeline at BASELINE sizes
+@pytest.mark.parametrize('name,J,D,n', [('m4b', 64, 16, 200)])
+def test_ep_iterations_at_c2_properties(name, J, D, n):
+    """Size-independent invariants of the hot path at config C2 (too large for a
+    draw-by-draw oracle run): symmetry, Q = Q0 + sum_k Qi (checksum of the
+    reduction), damping linearity of the packed sums, pos.def. moments, R-hat."""
+    mod = models.MODELS[name](J, D, n)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+               chains=4, iter=200, df0=models.default_df0(J))
+    info, (m_s, S_s), (st, ms, rh, ot) = M.run(3, verbose=False, return_analytics=True, seed=1)
+    assert info == 0
+    np.testing.assert_allclose(M.Qi, np.swapaxes(M.Qi, 0, 1), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(M.Q, M.Qi.sum(2) + M.Q0, rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(M.r, M.ri.sum(1) + M.r0, rtol=1e-10, atol=1e-9)
+    packed = M.engine.site_sums()
+    d = M.dphi
+    np.testing.assert_allclose(packed[:d * d].reshape(d, d, order='F'), M.Qi.sum(2), rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(packed[d * d + d:2 * d * d + d].reshape(d, d, order='F'), M.dQi.sum(2),
+                               rtol=1e-11, atol=1e-9)
+    for i in range(3):
+        assert np.all(np.linalg.eigvalsh(S_s[i]) > 0)
+    assert np.all(st > 0) and np.all(rh < 1.5) and np.all(ms > 0)
+    # one site of the same iteration against the oracle moment stage
+    k = 17
+    samp = M.engine.get_draws(k)
+    w = M.workers[k]
+    # tilted was computed against the PREVIOUS global (Q,r); recompute the moment stage alone
+    dQ, dr, mt, scatter, ok = eo.tilted_moments(samp, np.zeros((d, d)), np.zeros(d), 'sample')
+    Mat, vec, nsamp = M.engine.get_tilted(k)
+    np.testing.assert_allclose(vec, mt, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(Mat, scatter, rtol=1e-9, atol=1e-9)
+    assert nsamp == 400
