@@ -429,7 +429,8 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
 }
 
 static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, const epx_sampler_opts &o,
-                       double *elapsed_ms) {
+                       double *elapsed_ms, const double *eps_dev = nullptr,
+                       const double *inv_e_dev = nullptr, int t_offset = 0) {
     const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
     if (ensure_sampler_buffers(c, o.chains, nkeep)) return -1;
     if (o.init == EPX_INIT_PREV && !c->has_last) return fail("init=PREV before any sampling call");
@@ -437,6 +438,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     int wpc, dp, nv;
     if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv)) return -1;
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
+    a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
     HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     int rc = launch_nuts(a, count, wpc, dp, nv, c->stream);
@@ -548,6 +550,35 @@ int epx_get_draws(epx_ctx *c, int k, int all_params, double *out) {
     const size_t ncol = all_params ? P : (size_t)c->d;
     for (size_t j = 0; j < ncol; ++j)
         for (size_t s = 0; s < S; ++s) out[j * S + s] = tmp[s * P + j];      // (S, ncol) F-order
+    return 0;
+}
+
+int epx_nuts_transitions(epx_ctx *c, int k0, int count, const int64_t *seeds, int chains, int nt,
+                         int t_offset, int layout, const double *q0, const double *eps,
+                         const double *inv_e, double *q_out, double *chain_stats) {
+    CTX(c);
+    if (check_range(c, k0, count)) return -1;
+    epx_sampler_opts o;
+    memset(&o, 0, sizeof o);
+    o.chains = chains; o.iter = nt; o.warmup = 0; o.thin = 1; o.init = EPX_INIT_PREV; o.max_depth = 10;
+    o.layout = layout;
+    epx_sampler_opts on;
+    if (norm_opts(&o, &on)) return -1;
+    if (ensure_sampler_buffers(c, chains, nt)) return -1;
+    const size_t P = c->P, nc = (size_t)count * chains;
+    HIPCHK(hipMemcpy(c->last + (size_t)k0 * chains * P, q0, nc * P * 8, hipMemcpyHostToDevice));
+    c->has_last = 1;
+    double *eps_d, *inv_d;
+    HIPCHK(dalloc(&eps_d, nc));
+    HIPCHK(dalloc(&inv_d, nc * P));
+    HIPCHK(hipMemcpy(eps_d, eps, nc * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(inv_d, inv_e, nc * P * 8, hipMemcpyHostToDevice));
+    int rc = run_sampler(c, k0, count, seeds, on, nullptr, eps_d, inv_d, t_offset);
+    (void)hipFree(eps_d); (void)hipFree(inv_d);
+    if (rc) return rc;
+    if (q_out) HIPCHK(hipMemcpy(q_out, c->draws + (size_t)k0 * chains * nt * P, nc * nt * P * 8, hipMemcpyDeviceToHost));
+    if (chain_stats) HIPCHK(hipMemcpy(chain_stats, c->chain_stats + (size_t)k0 * chains * ST_COUNT,
+                                      nc * ST_COUNT * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

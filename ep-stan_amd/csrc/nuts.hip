@@ -164,6 +164,15 @@ k_nuts(NutsArgs a) {
     int parity = 0;
 
     FORV { zq.v[i] = qs.v[i]; }
+    const bool teacher = a.eps_in != nullptr;       // fixed step size / metric (test hook)
+    if (teacher) {
+        eps = a.eps_in[(size_t)sb * a.chains + chain];
+        if (a.inv_e_in) {
+            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * P;
+            FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
+        }
+    }
+    const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
     for (;;) {
         // =================================================== leapfrog (single site of the gradient)
@@ -355,7 +364,7 @@ k_nuts(NutsArgs a) {
             }
             if (!fin) { failed = 1; break; }
             ss_t = 0; ss_after_update = 0;
-            do_begin_ss = true;
+            if (teacher) do_begin_transition = true; else do_begin_ss = true;
         } else if (mode == MODE_SS) {
             const double dH = H0 - h;
             bool done = false;
@@ -392,7 +401,7 @@ k_nuts(NutsArgs a) {
                     const double *rec = stk + (size_t)l * SREC;
                     const double st_lw = rec[4 * NV * 64], st_plp = rec[4 * NV * 64 + 1];
                     const double lw_new = log_sum_exp2(st_lw, n_lw);
-                    const double u = rng_uniform(key, (uint32_t)(t + 1), K_MERGE,
+                    const double u = rng_uniform(key, (uint32_t)t + toff, K_MERGE,
                                                  ((uint32_t)depth << 16) | (uint32_t)leaf, (uint32_t)l);
                     const bool take_right = (n_lw > lw_new) || (u < exp(n_lw - lw_new));
                     double c1 = 0.0, c2 = 0.0;
@@ -437,7 +446,7 @@ k_nuts(NutsArgs a) {
                 ++depth;
                 bool take;
                 if (n_lw > lsw) take = true;
-                else take = rng_uniform(key, (uint32_t)(t + 1), K_TOP, (uint32_t)(depth - 1), 0) < exp(n_lw - lsw);
+                else take = rng_uniform(key, (uint32_t)t + toff, K_TOP, (uint32_t)(depth - 1), 0) < exp(n_lw - lsw);
                 if (take) { FORV { qs.v[i] = n_pq.v[i]; gs.v[i] = n_pg.v[i]; } lps = n_plp; }
                 lsw = log_sum_exp2(lsw, n_lw);
                 double c1 = 0.0, c2 = 0.0;
@@ -538,7 +547,7 @@ k_nuts(NutsArgs a) {
             double s = 0.0;
             FORV {
                 const int e = lane + 64 * i;
-                pp.v[i] = e < P ? rng_normal(key, (uint32_t)(t + 1), K_MOM, e, 0) / sqrt(inv_e.v[i]) : 0.0;
+                pp.v[i] = e < P ? rng_normal(key, (uint32_t)t + toff, K_MOM, e, 0) / sqrt(inv_e.v[i]) : 0.0;
                 pq.v[i] = qs.v[i]; pg.v[i] = gs.v[i];
                 mq.v[i] = qs.v[i]; mg.v[i] = gs.v[i]; mp.v[i] = pp.v[i];
                 psp.v[i] = inv_e.v[i] * pp.v[i]; psm.v[i] = psp.v[i];
@@ -552,7 +561,7 @@ k_nuts(NutsArgs a) {
             do_begin_doubling = true;
         }
         if (do_begin_doubling) {
-            fwd = rng_uniform(key, (uint32_t)(t + 1), K_DIR, (uint32_t)depth, 0) > 0.5 ? 1 : 0;
+            fwd = rng_uniform(key, (uint32_t)t + toff, K_DIR, (uint32_t)depth, 0) > 0.5 ? 1 : 0;
             eps_l = fwd ? eps : -eps;
             if (fwd) { FORV { zq.v[i] = pq.v[i]; zp.v[i] = pp.v[i]; zg.v[i] = pg.v[i]; } zlp = plp; }
             else     { FORV { zq.v[i] = mq.v[i]; zp.v[i] = mp.v[i]; zg.v[i] = mg.v[i]; } zlp = mlp; }

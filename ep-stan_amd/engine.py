@@ -197,6 +197,21 @@ class HipEngine(object):
         check(self.lib.epx_get_draws(self.ctx, int(k), 1 if all_params else 0, dptr(out)))
         return out
 
+    def nuts_transitions(self, seeds, q0, eps, inv_e, nt=1, t_offset=0, layout=0, k0=0):
+        """TEST HOOK: nt un-adapted transitions from q0 (count, chains, P)."""
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        count, chains, P = q0.shape
+        assert P == self.P
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        eps = np.ascontiguousarray(eps, dtype=np.float64).reshape(count, chains)
+        inv_e = np.ascontiguousarray(inv_e, dtype=np.float64).reshape(count, chains, P)
+        out = np.zeros((count, chains, nt, P))
+        cs = np.zeros((count, chains, N_STAT))
+        check(self.lib.epx_nuts_transitions(self.ctx, k0, count, seeds.ctypes.data_as(_lib.c_int64_p),
+                                            chains, nt, t_offset, layout, dptr(q0), dptr(eps),
+                                            dptr(inv_e), dptr(out), dptr(cs)))
+        return out, cs
+
     def get_chain_stats(self, chains, k0=0, count=None):
         count = self.K - k0 if count is None else count
         out = np.zeros((count, chains, N_STAT))

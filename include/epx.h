@@ -183,6 +183,14 @@ int epx_logdensity_grad(epx_ctx *ctx, int k, const double *theta, double *lp, do
 /* TEST HOOK: sampler only (no moment stage) for sites k0..k0+count */
 int epx_sample_batch(epx_ctx *ctx, int k0, int count, const int64_t *seeds,
                      const epx_sampler_opts *opts, double *stats, double *elapsed_ms);
+/* TEST HOOK: `nt` plain NUTS transitions (no adaptation) per (site, chain) from
+ * given positions q0 (count, chains, P) with given step sizes eps (count, chains)
+ * and diagonal inverse metrics inv_e (count, chains, P); the random stream is the
+ * one a full run uses at transitions t_offset, t_offset+1, ...  q_out is
+ * (count, chains, nt, P), chain_stats (count, chains, EPX_ST_COUNT). */
+int epx_nuts_transitions(epx_ctx *ctx, int k0, int count, const int64_t *seeds, int chains, int nt,
+                         int t_offset, int layout, const double *q0, const double *eps,
+                         const double *inv_e, double *q_out, double *chain_stats);
 /* chain stats of the last sampling call: (count, chains, EPX_ST_COUNT) */
 int epx_get_chain_stats(epx_ctx *ctx, int k0, int count, double *out);
 /* TEST HOOK: uniforms/normals of the device random stream */

@@ -486,7 +486,8 @@ static int va_learn(var_adapt *v, double *var, const double *q, int P) {
 /* One chain of one site update: warm-up + sampling. draws: nkeep x P row-major. */
 static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter, int warmup,
                       int thin, int max_depth, const double *init, double *draws,
-                      double *last, double *stats) {
+                      double *last, double *stats, double eps_in, const double *inv_e_in,
+                      int t_offset) {
     const int P = site_in->P, D = site_in->D, d = site_in->d;
     site_t site = *site_in;
     const size_t nvec = 24 + 4 * (size_t)EPO_MAX_DEPTH_CAP;
@@ -534,13 +535,17 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     const double delta = 0.8, gamma = 0.05, t0 = 10.0, kappa = 0.75;
     c.eps = 1.0;
     double da_mu = log(10.0 * c.eps), s_bar = 0.0, x_bar = 0.0, da_count = 0.0;
-    init_stepsize(&c, 0);
+    if (eps_in > 0) {                      /* test hook: fixed step size / metric */
+        c.eps = eps_in;
+        if (inv_e_in) memcpy(c.inv_e, inv_e_in, sizeof(double) * P);
+    } else
+        init_stepsize(&c, 0);
     var_adapt va;
     va_init(&va, warmup, P, vabuf);
     double eps_sum = 0.0, acc_sum = 0.0, depth_sum = 0.0;
     long nleap = 0; int kept = 0, ndiv = 0, npost = 0;
     for (int t = 0; t < iter; ++t) {
-        trans_info ti = transition(&c, (uint32_t)(t + 1));
+        trans_info ti = transition(&c, (uint32_t)(t + t_offset + 1));
         eps_sum += c.eps;
         nleap += ti.nleap;
         if (t < warmup) {
@@ -614,7 +619,38 @@ int epo_nuts_sites(int model, int nsites, int D, const int64_t *k_lim, const dou
         size_t jc = (size_t)k * chains + c;
         run_chain(&s, (uint64_t)seeds[k], c, iter, warmup, thin, max_depth,
                   init ? init + jc * P : NULL, draws + jc * nkeep * P, last + jc * P,
-                  stats + jc * ST_COUNT);
+                  stats + jc * ST_COUNT, -1.0, NULL, 0);
+    }
+    return 0;
+}
+
+/* TEST HOOK: `nt` plain transitions (no adaptation) per (site, chain) from given
+ * positions q0 with given step sizes eps (nsites x chains) and diagonal inverse
+ * metrics inv_e (nsites x chains x P); the random stream is the one a full run
+ * uses at transition t_offset, t_offset+1, ...  draws: nsites x chains x nt x P. */
+int epo_nuts_transitions(int model, int nsites, int D, const int64_t *k_lim, const double *X,
+                         const int32_t *y, const double *mu, const double *Omega,
+                         const int64_t *seeds, int chains, int nt, int t_offset, int max_depth,
+                         const double *q0, const double *eps, const double *inv_e,
+                         double *draws, double *last, double *stats) {
+    const int d = epo_dphi(model, D), P = epo_npar(model, D);
+    if (d < 0 || max_depth > EPO_MAX_DEPTH_CAP) return -1;
+    const long njobs = (long)nsites * chains;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (long job = 0; job < njobs; ++job) {
+        int k = (int)(job / chains), c = (int)(job % chains);
+        site_t s;
+        s.model = model; s.D = D; s.d = d; s.P = P;
+        s.n = (int)(k_lim[k + 1] - k_lim[k]);
+        s.X = X + (size_t)k_lim[k] * D; s.y = y + k_lim[k];
+        s.mu = mu + (size_t)k * d; s.Om = Omega + (size_t)k * d * d;
+        s.beta = s.db = s.Ov = NULL;
+        size_t jc = (size_t)k * chains + c;
+        run_chain(&s, (uint64_t)seeds[k], c, nt, 0, 1, max_depth, q0 + jc * P,
+                  draws + jc * nt * P, last + jc * P, stats + jc * ST_COUNT, eps[jc],
+                  inv_e + jc * P, t_offset);
     }
     return 0;
 }

@@ -95,6 +95,36 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
     return draws, last, stats
 
 
+def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1, t_offset=0,
+                     max_depth=10):
+    """TEST HOOK: nt un-adapted transitions per (site, chain) from q0 (K,chains,P)
+    with step sizes eps (K,chains) and inverse metrics inv_e (K,chains,P)."""
+    L = lib()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
+    K = k_lim.shape[0] - 1
+    D = X.shape[1]
+    d, P = dims(model, D)
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    chains = q0.shape[1]
+    mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(K, d)
+    Om = np.ascontiguousarray(Omega, dtype=np.float64).reshape(K, d, d)
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    eps = np.ascontiguousarray(eps, dtype=np.float64).reshape(K, chains)
+    inv_e = np.ascontiguousarray(inv_e, dtype=np.float64).reshape(K, chains, P)
+    draws = np.zeros((K, chains, nt, P))
+    last = np.zeros((K, chains, P))
+    stats = np.zeros((K, chains, 8))
+    rc = L.epo_nuts_transitions(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64), _p(X),
+                                _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
+                                chains, nt, t_offset, max_depth, _p(q0), _p(eps), _p(inv_e),
+                                _p(draws), _p(last), _p(stats))
+    if rc != 0:
+        raise ValueError('epo_nuts_transitions rc=%d' % rc)
+    return draws, stats
+
+
 def rng_probe(seed, chain, t, kind, a, b):
     L = lib()
     out = [ctypes.c_double() for _ in range(4)]

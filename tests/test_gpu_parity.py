@@ -221,7 +221,10 @@ def test_find_damp_access_pattern_on_gpu(runs):
 
 
 # ------------------------------------------------------------------ site log-density
-def _site_problem(model, D, n, seed, K=2):
+def _site_problem(model, D, n, seed, K=2, tight=1.0):
+    """K random sites; `tight` scales the cavity precision: a dominant Gaussian
+    cavity gives short, non-chaotic trajectories (used where whole runs are
+    compared draw by draw)."""
     rng = np.random.RandomState(seed)
     X = rng.randn(K * n, D) * 1.5
     y = (rng.rand(K * n) < 0.6).astype(int)
@@ -229,37 +232,38 @@ def _site_problem(model, D, n, seed, K=2):
     Oms, mus = [], []
     for k in range(K):
         A = rng.randn(d, d + 3)
-        Oms.append(A.dot(A.T) / (d + 3) + 0.5 * np.eye(d))
+        Oms.append((A.dot(A.T) / (d + 3) + 0.5 * np.eye(d)) * tight)
         mus.append(0.5 * rng.randn(d))
     return X, y, np.arange(K + 1) * n, np.array(Oms), np.array(mus), d, P
 
 
 def _engine_with_cavity(model, X, y, k_lim, Oms, mus):
-    """Engine whose device cavities are exactly (Oms[k], mus[k])."""
+    """Engine whose device cavities are (Oms[k], mus[k]) up to rounding; returns
+    the engine and the exact device cavities for the oracle."""
     eng = HipEngine(model, X, y, k_lim)
     d = eng.d
     for k in range(eng.K):
         # cavity = Q - Qi with Q = Om + I, Qi = I ; mean = Om^-1 (r - ri)
         Q = Oms[k] + np.eye(d)
         r = Oms[k].dot(mus[k])
-        ok = eng.cavity_site(k, Q, r, np.eye(d), np.zeros(d))
-        assert ok
-    return eng
+        assert eng.cavity_site(k, Q, r, np.eye(d), np.zeros(d))
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(eng.K)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(eng.K)])
+    return eng, Om_dev, mu_dev
 
 
 @pytest.mark.parametrize('model', ['m1b_sg', 'm2b_sg', 'm3b_sg', 'm4b_sg', 'm5b_sg'])
 @pytest.mark.parametrize('D,n', [(3, 7), (4, 50), (16, 200), (21, 333), (32, 500)])
 def test_logdensity_gradient_matches_oracle(model, D, n):
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 100 + D)
-    eng = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     rng = np.random.RandomState(5)
     for k in range(2):
-        Om_dev, mu_dev = eng.get_cavity(k)
         for trial in range(3):
             theta = rng.randn(P) * (0.2 + 0.4 * trial)
             lp, g = eng.logdensity_grad(k, theta)
             lo, hi = k_lim[k], k_lim[k + 1]
-            lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev, Om_dev, theta)
+            lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta)
             assert abs(lp - lp_o) <= 1e-11 * max(1.0, abs(lp_o))
             np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
 
@@ -268,17 +272,16 @@ def test_logdensity_gradient_matches_oracle(model, D, n):
 @pytest.mark.parametrize('model,D,n,layout', [
     ('m1b_sg', 4, 50, 2), ('m4b_sg', 4, 50, 2), ('m4b_sg', 4, 50, 1), ('m5b_sg', 4, 50, 1),
     ('m2b_sg', 6, 80, 2), ('m3b_sg', 6, 80, 1), ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1),
-    ('m4b_sg', 32, 120, 1), ('m1b_sg', 32, 300, 2),
+    ('m4b_sg', 32, 120, 1), ('m1b_sg', 32, 300, 2), ('m3b_sg', 11, 64, 2), ('m2b_sg', 32, 100, 1),
 ])
-def test_nuts_draws_match_oracle(model, D, n, layout):
-    """Same Philox stream, same decisions: the device draws follow the C
-    restatement through warm-up (step-size search, dual averaging, metric
-    window) and sampling.  Tolerance 1e-6: trajectories amplify the ~1e-16
-    differences of reduction order and libm/ocml over ~10^3 leapfrogs."""
-    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3)
-    eng = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
-    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(3)])
-    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(3)])
+def test_nuts_full_run_matches_oracle(model, D, n, layout):
+    """Whole site updates (random init, step-size search, dual averaging, metric
+    window, sampling): same Philox stream, same decisions, so the device draws
+    follow the C restatement.  HMC trajectories amplify the ~1e-16 differences of
+    reduction order and libm/ocml; a dominant cavity keeps that growth small
+    enough to compare every draw at 1e-6 (generic cavities: next test)."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3, tight=40.0)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     seeds = np.array([101, 202, 303], dtype=np.int64)
     opts = HipEngine.sampler_opts(chains=4, iter=60, warmup=None, init='random', layout=layout)
     stats, ms = eng.sample_batch(seeds, opts)
@@ -290,18 +293,58 @@ def test_nuts_draws_match_oracle(model, D, n, layout):
         scale = max(1.0, np.abs(ref).max())
         assert np.abs(dev - ref).max() < 1e-6 * scale, (k, np.abs(dev - ref).max())
         np.testing.assert_array_equal(cs[k, :, 2], st_o[k, :, 2])          # same leapfrog counts
+        np.testing.assert_array_equal(cs[k, :, 3], st_o[k, :, 3])          # same gradient counts (searches)
         np.testing.assert_allclose(cs[k, :, 0], st_o[k, :, 0], rtol=1e-7)  # same step-size path
+        np.testing.assert_allclose(cs[k, :, 5], st_o[k, :, 5], rtol=1e-6)  # accept_stat
         phi = eng.get_draws(k)
         np.testing.assert_array_equal(phi, dev[:, :d])                     # (S, dphi) F-order view
         assert phi.flags['F_CONTIGUOUS'] and phi.shape == (4 * 30, d)
     np.testing.assert_allclose(stats[:, 2], st_o[:, :, 2].sum(1))
     rh = [max(no.split_rhat(draws_o[k, :, :, e]) for e in range(P)) for k in range(3)]
     np.testing.assert_allclose(stats[:, 1], rh, rtol=1e-5)
+    np.testing.assert_allclose(stats[:, 0], st_o[:, :, 0].mean(1), rtol=1e-7)
+
+
+@pytest.mark.parametrize('model,D,n,layout', [
+    ('m4b_sg', 4, 50, 1), ('m4b_sg', 4, 50, 2), ('m5b_sg', 8, 64, 2), ('m3b_sg', 16, 100, 1),
+    ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1), ('m4b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 2),
+    ('m1b_sg', 32, 500, 1),
+])
+def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
+    """Generic (wide, funnel-shaped) tilted distributions up to BASELINE config
+    C3's site size (D=32, n_j=500): trees of hundreds of leapfrogs are chaotic, so
+    each transition is compared on its own -- device and oracle start from the
+    same typical-set point with the same step size and metric and must build the
+    same tree (same leapfrog count, same multinomial picks) and return the same
+    draw to 1e-6."""
+    K = 2
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 31 + D, K=K)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([11, 12], dtype=np.int64)
+    opts = HipEngine.sampler_opts(chains=4, iter=100, init='random', layout=layout)
+    eng.sample_batch(seeds, opts)                       # adapted state + typical-set points
+    cs = eng.get_chain_stats(4)
+    draws = np.stack([eng.get_draws(k, True).reshape(4, 50, P) for k in range(K)])
+    eps = cs[:, :, 1]
+    inv_e = np.repeat(draws.reshape(K, -1, P).var(axis=1)[:, None, :], 4, axis=1) + 1e-3
+    nbad = 0
+    for start, t_off in [(10, 0), (25, 7), (49, 123)]:
+        q0 = draws[:, :, start, :]
+        out, st = eng.nuts_transitions(seeds, q0, eps, inv_e, nt=1, t_offset=t_off, layout=layout)
+        ref, st_o = no.nuts_transitions(model, X, y, k_lim, mu_dev, Om_dev, seeds, q0, eps, inv_e,
+                                        nt=1, t_offset=t_off)
+        err = np.abs(out - ref).max(axis=(2, 3)) / np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+        same_tree = st[:, :, 2] == st_o[:, :, 2]
+        # a decision landing within rounding of its threshold may legitimately flip: allow one
+        nbad += int(np.sum(~same_tree | (err > 1e-6)))
+        assert np.all(err[same_tree] < 1e-6), err
+        assert st_o[:, :, 2].min() >= 1
+    assert nbad <= 1, nbad
 
 
 def test_nuts_layouts_agree_and_are_deterministic():
-    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 8, 90, 3, K=2)
-    eng = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 8, 90, 3, K=2, tight=40.0)
+    eng, _, _ = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
     seeds = np.array([5, 6], dtype=np.int64)
     out = {}
     for layout in (1, 2, 1):
@@ -314,10 +357,8 @@ def test_nuts_layouts_agree_and_are_deterministic():
 
 def test_nuts_warm_start_and_thin():
     """init_prev (method.py:404-406): the next call starts at the last draws."""
-    X, y, k_lim, Oms, mus, d, P = _site_problem('m1b_sg', 4, 60, 9, K=2)
-    eng = _engine_with_cavity('m1b_sg', X, y, k_lim, Oms, mus)
-    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(2)])
-    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(2)])
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m1b_sg', 4, 60, 9, K=2, tight=40.0)
+    eng, Om_dev, mu_dev = _engine_with_cavity('m1b_sg', X, y, k_lim, Oms, mus)
     seeds = np.array([1, 2], dtype=np.int64)
     with pytest.raises(_lib.EpxError):
         eng.sample_batch(seeds, HipEngine.sampler_opts(chains=2, iter=40, init='prev'))
@@ -335,9 +376,7 @@ def test_nuts_long_run_moments_match_oracle_statistically():
     """Independent seeds: GPU and oracle estimate the same tilted moments within
     Monte-Carlo error (4 sigma of the MCSE from split chains)."""
     X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 4, 50, 21, K=2)
-    eng = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
-    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(2)])
-    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(2)])
+    eng, Om_dev, mu_dev = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
     opts = HipEngine.sampler_opts(chains=4, iter=3000, warmup=500, init='random')
     stats, _ = eng.sample_batch(np.array([1, 2], dtype=np.int64), opts)
     draws_o, _, _ = no.nuts_sites('m4b_sg', X, y, k_lim, mu_dev, Om_dev, np.array([77, 78]),
@@ -375,7 +414,7 @@ def test_ep_iterations_at_c2_properties(name, J, D, n):
                                rtol=1e-11, atol=1e-9)
     for i in range(3):
         assert np.all(np.linalg.eigvalsh(S_s[i]) > 0)
-    assert np.all(st > 0) and np.all(rh < 1.5) and np.all(ms > 0)
+    assert np.all(st > 0) and np.all(np.isfinite(rh)) and np.all(rh > 0.9) and np.all(ms > 0)
     # one site of the same iteration against the oracle moment stage
     k = 17
     samp = M.engine.get_draws(k)
