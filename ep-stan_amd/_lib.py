@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libepx.so')
+LIB_PATH = os.environ.get('EPX_LIB', os.path.join(HERE, 'libepx.so'))   # EPX_LIB: diagnostic builds only
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)

@@ -15,3 +15,10 @@ done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libepx.so build/dense.o build/nuts.o build/epx_api.o
 echo "built $(cd .. && pwd)/libepx.so"
+if [ "$EPX_STAMPS" = "1" ]; then
+  # diagnostic variant with in-kernel cycle stamps (scripts/stamps.py); never benchmarked
+  mkdir -p build_stamps
+  for f in dense nuts epx_api; do $HIPCC $FLAGS -DEPX_STAMPS -c $f.hip -o build_stamps/$f.o & done; wait
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_out/libepx_stamps.so build_stamps/dense.o build_stamps/nuts.o build_stamps/epx_api.o
+  echo "built diagnostic gpurun_out/libepx_stamps.so"
+fi

@@ -67,6 +67,8 @@ struct epx_ctx {
     int nsamp;                // draws per site of the last tilted/moments call
     double last_df;
     hipEvent_t ev0, ev1;
+    unsigned long long *stamps;
+    size_t stamps_n, stamps_last;
 };
 
 const char *epx_last_error(void) { return g_err.c_str(); }
@@ -155,6 +157,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
     c->draws = c->last = c->chain_stats = c->site_stats = c->stack = nullptr;
     c->seeds_d = nullptr; c->inj = nullptr; c->inj_elems = 0; c->stack_elems = 0;
     c->s_chains = 0; c->s_nkeep = 0; c->has_last = 0; c->nsamp = 0; c->last_df = 0.0;
+    c->stamps = nullptr; c->stamps_n = 0; c->stamps_last = 0;
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -439,6 +442,19 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv)) return -1;
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
     a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
+#ifdef EPX_STAMPS
+    {
+        const int nblk = count * ((o.chains + a.cpb - 1) / a.cpb);
+        if (c->stamps_n < (size_t)nblk) {
+            if (c->stamps) (void)hipFree(c->stamps);
+            HIPCHK(dalloc(&c->stamps, (size_t)nblk * 8));
+            c->stamps_n = nblk;
+        }
+        HIPCHK(hipMemset(c->stamps, 0, (size_t)nblk * 64));
+        a.stamps = c->stamps;
+        c->stamps_last = nblk;
+    }
+#endif
     HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     int rc = launch_nuts(a, count, wpc, dp, nv, c->stream);
@@ -581,6 +597,16 @@ int epx_nuts_transitions(epx_ctx *c, int k0, int count, const int64_t *seeds, in
                                       nc * ST_COUNT * 8, hipMemcpyDeviceToHost));
     return 0;
 }
+
+#ifdef EPX_STAMPS
+// diagnostic build only: cycle sums of the last sampler launch, (nblocks, 8)
+extern "C" int epx_dbg_get_stamps(epx_ctx *c, unsigned long long *out, int max_blocks) {
+    CTX(c);
+    size_t nb = c->stamps_last < (size_t)max_blocks ? c->stamps_last : (size_t)max_blocks;
+    HIPCHK(hipMemcpy(out, c->stamps, nb * 64, hipMemcpyDeviceToHost));
+    return (int)nb;
+}
+#endif
 
 int epx_get_chain_stats(epx_ctx *c, int k0, int count, double *out) {
     CTX(c);

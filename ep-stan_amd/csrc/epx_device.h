@@ -65,25 +65,78 @@ __device__ inline double rng_normal(RngKey k, uint32_t t, uint32_t kind, int e, 
 }
 
 // ----------------------------------------------------------------------------
-// wave64 all-reduce sums (xor butterfly); every lane ends with the total.
-__device__ inline double wave_sum(double v) {
+// Cross-lane movement without LDS round trips.  DPP moves have VALU latency
+// (the ds_bpermute path behind __shfl costs an LDS-crossbar round trip per
+// dependent step, ~10x more on a serial reduction chain).
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ inline double dpp_d(double x) {
+    union { double d; int u[2]; } a, r;
+    a.d = x;
+    r.u[0] = __builtin_amdgcn_update_dpp(0, a.u[0], CTRL, ROW_MASK, 0xF, true);
+    r.u[1] = __builtin_amdgcn_update_dpp(0, a.u[1], CTRL, ROW_MASK, 0xF, true);
+    return r.d;
+}
+enum { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_QUAD_REV = 0x1B, DPP_ROW_MIRROR = 0x140,
+       DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
+
+// value of a partner lane whose lane-index bit B differs from this lane's:
+//   B=5: lane^32 (v_permlane32_swap)   B=4: lane^16 (v_permlane16_swap)
+//   B=3: lane^15 (row_mirror)          B=2: lane^7  (row_half_mirror)
+//   B=1: lane^3  (quad reverse)        B=0: lane^1
+template <int B>
+__device__ inline double partner_d(double x, int lane) {
+    if constexpr (B == 5 || B == 4) {
+        union { double d; unsigned u[2]; } a, r;
+        a.d = x;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+        for (int h = 0; h < 2; ++h) {
+            v2u_t s;
+            if constexpr (B == 5) s = __builtin_amdgcn_permlane32_swap(a.u[h], a.u[h], false, false);
+            else s = __builtin_amdgcn_permlane16_swap(a.u[h], a.u[h], false, false);
+            // s.x = this lane's old "vdst" view, s.y = "src0" view (see ISA: the halves / odd-even
+            // rows are swapped between the two registers)
+            r.u[h] = (lane & (1 << B)) ? s.x : s.y;
+        }
+        return r.d;
+    } else if constexpr (B == 3) return dpp_d<DPP_ROW_MIRROR>(x);
+    else if constexpr (B == 2) return dpp_d<DPP_ROW_HALF_MIRROR>(x);
+    else if constexpr (B == 1) return dpp_d<DPP_QUAD_REV>(x);
+    else return dpp_d<DPP_QUAD_XOR1>(x);
+}
+
+// value of lane `lane` (wave-uniform index) broadcast as a scalar
+__device__ inline double readlane_d(double v, int lane) {
+    union { double d; uint32_t u[2]; } x;
+    x.d = v;
+    x.u[0] = __builtin_amdgcn_readlane(x.u[0], lane);
+    x.u[1] = __builtin_amdgcn_readlane(x.u[1], lane);
+    return x.d;
+}
+
+// wave64 sums: DPP row reduction, result broadcast from lane 63 through SGPRs.
+__device__ inline double wave_sum(double v) {
+    v += dpp_d<DPP_QUAD_XOR1>(v);
+    v += dpp_d<DPP_QUAD_XOR2>(v);
+    v += dpp_d<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_d<DPP_ROW_MIRROR>(v);
+    v += dpp_d<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_d<DPP_ROW_BCAST31, 0xC>(v);
+    return readlane_d(v, 63);
 }
 __device__ inline void wave_sum2(double &a, double &b) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double ta = __shfl_xor(a, m, 64), tb = __shfl_xor(b, m, 64);
-        a += ta; b += tb;
-    }
+    a += dpp_d<DPP_QUAD_XOR1>(a); b += dpp_d<DPP_QUAD_XOR1>(b);
+    a += dpp_d<DPP_QUAD_XOR2>(a); b += dpp_d<DPP_QUAD_XOR2>(b);
+    a += dpp_d<DPP_ROW_HALF_MIRROR>(a); b += dpp_d<DPP_ROW_HALF_MIRROR>(b);
+    a += dpp_d<DPP_ROW_MIRROR>(a); b += dpp_d<DPP_ROW_MIRROR>(b);
+    a += dpp_d<DPP_ROW_BCAST15, 0xA>(a); b += dpp_d<DPP_ROW_BCAST15, 0xA>(b);
+    a += dpp_d<DPP_ROW_BCAST31, 0xC>(a); b += dpp_d<DPP_ROW_BCAST31, 0xC>(b);
+    a = readlane_d(a, 63); b = readlane_d(b, 63);
 }
 __device__ inline void wave_sum3(double &a, double &b, double &c) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double ta = __shfl_xor(a, m, 64), tb = __shfl_xor(b, m, 64), tc = __shfl_xor(c, m, 64);
-        a += ta; b += tb; c += tc;
-    }
+    wave_sum2(a, b);
+    c = wave_sum(c);
 }
 
 // make a value the compiler can keep in SGPRs (it is identical in all lanes)
@@ -95,14 +148,6 @@ __device__ inline double uniform_d(double v) {
     return x.d;
 }
 __device__ inline int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// value of lane `lane` (wave-uniform index) broadcast as a scalar
-__device__ inline double readlane_d(double v, int lane) {
-    union { double d; uint32_t u[2]; } x;
-    x.d = v;
-    x.u[0] = __builtin_amdgcn_readlane(x.u[0], lane);
-    x.u[1] = __builtin_amdgcn_readlane(x.u[1], lane);
-    return x.d;
-}
 
 __device__ inline double log_sum_exp2(double a, double b) {
     if (a == -INFINITY) return b;

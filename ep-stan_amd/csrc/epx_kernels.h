@@ -112,6 +112,7 @@ struct NutsArgs {
     const double *eps_in;         // test hook: per (site of batch, chain) fixed step size -> no step-size search
     const double *inv_e_in;       // test hook: per (site of batch, chain) x P diagonal inverse metric
     int t_offset;                 // test hook: transition index offset of the random stream
+    unsigned long long *stamps;   // diagnostic build (-DEPX_STAMPS): per block 8 cycle sums
     double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
     double *stack;                // per (site of batch, chain): max_depth * (4P + 2) doubles, or NULL when in LDS
     // dynamic LDS layout (byte offsets), computed on the host

@@ -54,6 +54,43 @@ template <> struct Log2<1> { static constexpr int v = 0; };
 
 enum { MODE_INIT = 0, MODE_SS = 1, MODE_TREE = 2 };
 
+// In-kernel cycle stamps exist only in the diagnostic build (-DEPX_STAMPS); its
+// run time is never quoted, only the shares of the segments.
+#ifdef EPX_STAMPS
+#define STAMP(i)                                                                   \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+        tacc[i] += t_ - tprev; tprev = t_;                                         \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// Transposing reduction of CNT per-lane partial sums over the 64 lanes of a wave:
+// each stage halves the values a lane carries and doubles the lanes summed, so
+// CNT values cost CNT-1 exchanges (not 6*CNT).  Stage with selector bit B keeps
+// the half of the values chosen by the lane's own bit B and receives the same
+// half from a partner lane whose bit B differs.  Fully static indexing.
+template <int CNT, int B>
+__device__ inline void butterfly(double *acc, int lane) {
+    if constexpr (CNT > 1) {
+        const bool upper = (lane >> B) & 1;
+#pragma unroll
+        for (int j = 0; j < CNT / 2; ++j) {
+            const double send = upper ? acc[j] : acc[j + CNT / 2];
+            const double keep = upper ? acc[j + CNT / 2] : acc[j];
+            acc[j] = keep + partner_d<B>(send, lane);
+        }
+        butterfly<CNT / 2, B - 1>(acc, lane);
+    } else if constexpr (B >= 0) {
+        acc[0] += partner_d<B>(acc[0], lane);
+        butterfly<1, B - 1>(acc, lane);
+    }
+}
+
 template <int NV, int DP, int WPC>
 __global__ void __launch_bounds__(256)
 k_nuts(NutsArgs a) {
@@ -174,7 +211,13 @@ k_nuts(NutsArgs a) {
     }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
+#ifdef EPX_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (;;) {
+        STAMP(6);
         // =================================================== leapfrog (single site of the gradient)
         FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
         FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
@@ -203,6 +246,7 @@ k_nuts(NutsArgs a) {
             for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
             alpha = uniform_d(alpha);
 
+            STAMP(0);
             // ---- fused row pass: f = alpha + x.beta, g = y - sigmoid(f), acc += g x
             double acc[DP];
 #pragma unroll
@@ -226,25 +270,13 @@ k_nuts(NutsArgs a) {
 #pragma unroll
                 for (int j = 0; j < DP; ++j) acc[j] = fma(g, x[j], acc[j]);
             }
-            // ---- transposing butterfly: lane ends with sum over lanes of acc[lane >> (6-LOG)]
-            {
-                int mask = 32;
-#pragma unroll
-                for (int cnt = DP; cnt > 1; cnt >>= 1, mask >>= 1) {
-                    const bool upper = (lane & mask) != 0;
-#pragma unroll
-                    for (int j = 0; j < cnt / 2; ++j) {
-                        const double send = upper ? acc[j] : acc[j + cnt / 2];
-                        const double keep = upper ? acc[j + cnt / 2] : acc[j];
-                        acc[j] = keep + __shfl_xor(send, mask, 64);
-                    }
-                }
-#pragma unroll
-                for (int m = 32 >> LOG; m >= 1; m >>= 1) acc[0] += __shfl_xor(acc[0], m, 64);
-            }
+            STAMP(1);
+            // ---- transposing butterfly: lane ends with the 64-lane sum of acc[lane >> (6-LOG)]
+            butterfly<DP, 5>(acc, lane);
             wave_sum2(da, ll);
             double dbl = acc[0];
 
+            STAMP(2);
             // ---- cavity term: Ov = Omega (phi - mu), this wave's share of the columns
             V vv, Ov;
             FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? zq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
@@ -261,6 +293,7 @@ k_nuts(NutsArgs a) {
                     }
                 }
             }
+            STAMP(3);
             if (WPC > 1) {
                 double *rec = xch + ((size_t)parity * WPC + wt) * XREC;
                 rec[lane] = dbl;
@@ -279,6 +312,7 @@ k_nuts(NutsArgs a) {
                 }
                 parity ^= 1;
             }
+            STAMP(4);
             da = uniform_d(da); ll = uniform_d(ll);
             // ---- lp and the chain rule back to (phi, eta, etb)
             auto dbat = [&](int j) { return __shfl(dbl, (j << (6 - LOG)) & 63, 64); };
@@ -334,6 +368,7 @@ k_nuts(NutsArgs a) {
         }
         FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
         ngrad += 1.0;
+        STAMP(5);
 
         // =================================================== state machine
         bool do_begin_ss = false, do_ss_setup = false, do_begin_transition = false;
@@ -570,6 +605,12 @@ k_nuts(NutsArgs a) {
     }
 
     // ------------------------------------------------------------- epilogue
+#ifdef EPX_STAMPS
+    if (a.stamps && wt == 0 && team == 0 && lane == 0) {
+        for (int i = 0; i < 7; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
+        a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)ngrad;
+    }
+#endif
     if (wt == 0) {
         double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
