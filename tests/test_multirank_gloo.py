@@ -1,0 +1,118 @@
+"""The N>1 path on CPU: world_size-2 gloo process group, sites sharded over the
+ranks, ONE all-reduce of the packed site sums per EP iteration.  The oracle
+stands in for the device engine; the host logic (epstan_amd.method / dist) is
+the code under test."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, outdir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'] = str(rank)
+    os.environ['WORLD_SIZE'] = str(world)
+    for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as tdist
+    from epstan_amd import dist, models
+    from epstan_amd.method import Master
+    from oracle.engine_oracle import OracleEngine
+    import injectors
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    comm = dist.TorchComm()
+    fac = lambda m, X, y, kl: OracleEngine(m, X, y, kl, nthreads=2)
+    runs = np.load(os.path.join(ROOT, 'tests', 'golden', 'master_run.npz'))
+    if mode == 'injected':
+        M = Master('m1b_sg', runs['g6_X'], runs['g6_y'], site_sizes=runs['g6_Nj'],
+                   prior={'Q': runs['g6_Q0'], 'r': runs['g6_r0']}, A_k={'site_id': np.arange(4)},
+                   chains=4, iter=200, df0=0.5, comm=comm, _engine_factory=fac)
+        M._sample_injector = injectors.GaussianTilted('smooth')
+        info, (m_s, S_s) = M.run(12, verbose=False, seed=1)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri,
+                 Q=M.Q, klo=M.k_lo, khi=M.k_hi)
+    elif mode == 'decay':
+        Nj = runs['g6_Nj'][:3]; nrow = int(Nj.sum())
+        M = Master('m1b_sg', runs['g6_X'][:nrow], runs['g6_y'][:nrow], site_sizes=Nj,
+                   prior={'Q': runs['g6_Q0'], 'r': runs['g6_r0']}, A_k={'site_id': np.arange(3)},
+                   chains=4, iter=200, df0=1.0, comm=comm, _engine_factory=fac)
+        M._sample_injector = injectors.GaussianTilted('wide_first')
+        info, (m_s, S_s) = M.run(4, verbose=False, seed=1)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri,
+                 Q=M.Q, klo=M.k_lo, khi=M.k_hi)
+    else:   # real sampler (C oracle NUTS), 6 sites of m4b
+        mod = models.m4b(6, 3, 60)
+        data = mod.simulate_data(Sigma_x='rand', rng=100)
+        _, _, Q0, r0 = mod.get_prior()
+        M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+                   chains=4, iter=120, df0=0.4, comm=comm, _engine_factory=fac)
+        info, (m_s, S_s), an = M.run(1, verbose=False, return_analytics=True, seed=3)
+        Qi1 = M.Qi.copy()
+        info2 = M.run(1, verbose=False, calc_moments=False, seed=4)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, info2=info2, m=m_s, S=S_s, Qi=Qi1,
+                 ri=M.ri, Q=M.Q, klo=M.k_lo, khi=M.k_hi, msteps=an[1], mrhats=an[2])
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def _spawn(mode, tmp_path, world=2):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    return [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize('mode,tag', [('injected', 'smooth'), ('decay', 'decay')])
+def test_two_ranks_reproduce_reference_trajectory(tmp_path, mode, tag):
+    runs = np.load(os.path.join(ROOT, 'tests', 'golden', 'master_run.npz'))
+    res = _spawn(mode, tmp_path)
+    K = runs['g6_%s_Qi' % tag].shape[2]
+    assert [(int(r['klo']), int(r['khi'])) for r in res] == [(0, K // 2), (K // 2, K)]
+    for r in res:       # every rank holds the same global state and the gathered site arrays
+        assert int(r['info']) == int(runs['g6_%s_info' % tag])
+        np.testing.assert_allclose(r['m'], runs['g6_%s_m' % tag], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['S'], runs['g6_%s_S' % tag], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['Qi'], runs['g6_%s_Qi' % tag], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(r['ri'], runs['g6_%s_ri' % tag], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(r['Q'], runs['g6_%s_Q' % tag], rtol=1e-8, atol=1e-9)
+
+
+def test_sharding_does_not_change_results_with_real_sampler(tmp_path):
+    """Seeds are indexed by GLOBAL site id, so 1 rank and 2 ranks sample the same
+    draws in the first iteration (identical cavities).  Later iterations see
+    cavities that differ by the summation order of the site reduction (1e-16),
+    which chaotic HMC trajectories amplify, so only iteration 1 is compared
+    exactly."""
+    sys.path.insert(0, ROOT)
+    from epstan_amd import models
+    from epstan_amd.method import Master
+    from oracle.engine_oracle import OracleEngine
+    res = _spawn('nuts', tmp_path)
+    mod = models.m4b(6, 3, 60)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+               chains=4, iter=120, df0=0.4,
+               _engine_factory=lambda m, X, y, kl: OracleEngine(m, X, y, kl, nthreads=2))
+    info, (m_s, S_s), an = M.run(1, verbose=False, return_analytics=True, seed=3)
+    for r in res:
+        assert int(r['info']) == info == 0 and int(r['info2']) == 0
+        np.testing.assert_allclose(r['m'], m_s, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['Qi'], M.Qi, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r['msteps'], an[1], rtol=1e-12)     # max over ALL sites (method.py:1044)
+        np.testing.assert_allclose(r['mrhats'], an[2], rtol=1e-12)
