@@ -269,24 +269,26 @@ def test_logdensity_gradient_matches_oracle(model, D, n):
 
 
 # ------------------------------------------------------------------ sampler vs oracle, draw by draw
-@pytest.mark.parametrize('model,D,n,layout', [
-    ('m1b_sg', 4, 50, 2), ('m4b_sg', 4, 50, 2), ('m4b_sg', 4, 50, 1), ('m5b_sg', 4, 50, 1),
-    ('m2b_sg', 6, 80, 2), ('m3b_sg', 6, 80, 1), ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1),
-    ('m4b_sg', 32, 120, 1), ('m1b_sg', 32, 300, 2), ('m3b_sg', 11, 64, 2), ('m2b_sg', 32, 100, 1),
+@pytest.mark.parametrize('model,D,n,layout,it,tight', [
+    ('m1b_sg', 4, 50, 2, 60, 100.), ('m4b_sg', 4, 50, 2, 60, 100.), ('m4b_sg', 4, 50, 1, 60, 100.),
+    ('m5b_sg', 4, 50, 1, 60, 100.), ('m2b_sg', 6, 80, 2, 60, 100.), ('m3b_sg', 6, 80, 1, 60, 100.),
+    ('m4b_sg', 16, 200, 2, 44, 1000.), ('m4b_sg', 16, 200, 1, 44, 1000.), ('m4b_sg', 32, 120, 1, 44, 1000.),
+    ('m1b_sg', 32, 300, 2, 60, 100.), ('m3b_sg', 11, 64, 2, 60, 100.), ('m2b_sg', 32, 100, 1, 44, 1000.),
 ])
-def test_nuts_full_run_matches_oracle(model, D, n, layout):
+def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
     """Whole site updates (random init, step-size search, dual averaging, metric
     window, sampling): same Philox stream, same decisions, so the device draws
     follow the C restatement.  HMC trajectories amplify the ~1e-16 differences of
     reduction order and libm/ocml; a dominant cavity keeps that growth small
     enough to compare every draw of the run at 2e-5 (a single differing decision
-    would give O(1) differences; generic cavities: next test)."""
-    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3, tight=100.0)
+    would give O(1) differences; generic cavities: next test).  iter >= 44 so that
+    the warm-up contains a metric window (update + second step-size search)."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3, tight=tight)
     eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     seeds = np.array([101, 202, 303], dtype=np.int64)
-    opts = HipEngine.sampler_opts(chains=4, iter=60, warmup=None, init='random', layout=layout)
+    opts = HipEngine.sampler_opts(chains=4, iter=it, warmup=None, init='random', layout=layout)
     stats, ms = eng.sample_batch(seeds, opts)
-    draws_o, last_o, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=4, iter=60)
+    draws_o, last_o, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=4, iter=it)
     cs = eng.get_chain_stats(4)
     for k in range(3):
         dev = eng.get_draws(k, all_params=True)
@@ -299,7 +301,7 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout):
         np.testing.assert_allclose(cs[k, :, 5], st_o[k, :, 5], rtol=1e-5)  # accept_stat
         phi = eng.get_draws(k)
         np.testing.assert_array_equal(phi, dev[:, :d])                     # (S, dphi) F-order view
-        assert phi.flags['F_CONTIGUOUS'] and phi.shape == (4 * 30, d)
+        assert phi.flags['F_CONTIGUOUS'] and phi.shape == (4 * (it // 2), d)
     np.testing.assert_allclose(stats[:, 2], st_o[:, :, 2].sum(1))
     rh = [max(no.split_rhat(draws_o[k, :, :, e]) for e in range(P)) for k in range(3)]
     np.testing.assert_allclose(stats[:, 1], rh, rtol=1e-5)
