@@ -115,6 +115,17 @@ __device__ inline double readlane_d(double v, int lane) {
     return x.d;
 }
 
+// value of the lane whose index differs from this lane's ONLY in bit B (B >= 2):
+// a true xor partner, needed by all-reduce stages that must not mix the low bits.
+//   B=2: row_ror:4 and B=3: row_ror:8 rotate within a row of 16 and keep the low bits
+//   (summing v + ror4(v), then + ror8, covers the 4 lanes that share (lane & 3)).
+template <int B>
+__device__ inline double plain_partner_d(double x, int lane) {
+    if constexpr (B == 2) return dpp_d<0x124>(x);
+    else if constexpr (B == 3) return dpp_d<0x128>(x);
+    else return partner_d<B>(x, lane);
+}
+
 // wave64 sums: DPP row reduction, result broadcast from lane 63 through SGPRs.
 __device__ inline double wave_sum(double v) {
     v += dpp_d<DPP_QUAD_XOR1>(v);
@@ -124,6 +135,17 @@ __device__ inline double wave_sum(double v) {
     v += dpp_d<DPP_ROW_BCAST15, 0xA>(v);
     v += dpp_d<DPP_ROW_BCAST31, 0xC>(v);
     return readlane_d(v, 63);
+}
+__device__ inline double wave_max(double v) {
+    // old = -inf keeps rows that a row_bcast does not write neutral
+    auto mx = [](double x, double y) { return fmax(x, y); };
+    v = mx(v, dpp_d<DPP_QUAD_XOR1>(v));
+    v = mx(v, dpp_d<DPP_QUAD_XOR2>(v));
+    v = mx(v, dpp_d<DPP_ROW_HALF_MIRROR>(v));
+    v = mx(v, dpp_d<DPP_ROW_MIRROR>(v));
+    // every lane of a row now holds the row maximum: combine the 4 rows through SGPRs
+    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    return mx(mx(r0, r1), mx(r2, r3));
 }
 __device__ inline void wave_sum2(double &a, double &b) {
     a += dpp_d<DPP_QUAD_XOR1>(a); b += dpp_d<DPP_QUAD_XOR1>(b);
@@ -154,6 +176,22 @@ __device__ inline double log_sum_exp2(double a, double b) {
     if (a == INFINITY && b == INFINITY) return INFINITY;
     if (a > b) return a + log1p(exp(b - a));
     return b + log1p(exp(a - b));
+}
+
+// Merging two log-weights a (left) and b (right): lse = log(e^a + e^b) and the
+// multinomial probability of the right one, e^b / (e^a + e^b), from ONE exp
+// (base_nuts.hpp computes log_sum_exp and exp(b - lse) separately).
+__device__ inline void merge_weights(double a, double b, double &lse, double &p_right) {
+    if (a == -INFINITY) { lse = b; p_right = (b == -INFINITY) ? NAN : 1.0; return; }
+    if (b >= a) {
+        const double e = exp(a - b);
+        lse = b + log1p(e);
+        p_right = 1.0 / (1.0 + e);
+    } else {
+        const double e = exp(b - a);
+        lse = a + log1p(e);
+        p_right = e / (1.0 + e);
+    }
 }
 
 // y f - log(1+e^f) and y - sigmoid(f) sharing one exp (bernoulli_logit)

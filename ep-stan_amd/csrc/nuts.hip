@@ -91,7 +91,7 @@ __device__ inline void butterfly(double *acc, int lane) {
     }
 }
 
-template <int NV, int DP, int WPC>
+template <int NV, int DP, int WPC, bool OML, bool STL>
 __global__ void __launch_bounds__(256)
 k_nuts(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -133,18 +133,21 @@ k_nuts(NutsArgs a) {
         }
         for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r];
     }
-    const double *Om = a.cav_Om + (size_t)k * d * d;
-    if (a.om_in_lds) {
-        double *Oms = reinterpret_cast<double *>(smem + a.off_Om);
-        for (int idx = tid; idx < d * d; idx += blockDim.x) Oms[idx] = Om[idx];
-        Om = Oms;
+    // Omega and the tree stack: LDS-typed pointers when resident (template flags keep
+    // the address space static, so the compiler emits ds_read/ds_write, not flat_*)
+    const double *Om_g = a.cav_Om + (size_t)k * d * d;
+    double *Oms = reinterpret_cast<double *>(smem + a.off_Om);
+    if constexpr (OML) {
+        for (int idx = tid; idx < d * d; idx += blockDim.x) Oms[idx] = Om_g[idx];
     }
     __syncthreads();
     if (chain >= a.chains) return;        // only possible when WPC == 1 (no later barriers)
+    auto om_at = [&](int idx) -> double { if constexpr (OML) return Oms[idx]; else return Om_g[idx]; };
 
-    double *stk;
-    if (a.stack_in_lds) stk = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
-    else stk = a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
+    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
+    auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
 
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
@@ -152,7 +155,7 @@ k_nuts(NutsArgs a) {
     // ------------------------------------------------------------- state
     V mu, inv_e, qs, gs, zq, zp, zg, pq, pp, pg, mq, mp, mg, rho, psp, psm;
     V n_rho, n_psl, n_pq, n_pg, psr, wmean, wm2;
-    double lps = 0, zlp = 0, plp = 0, mlp = 0, n_lw = 0, n_plp = 0;
+    double lps = 0, zlp = 0, plp = 0, mlp = 0, n_key = 0, n_plp = 0;
     FORV {
         const int e = lane + 64 * i;
         mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
@@ -164,7 +167,7 @@ k_nuts(NutsArgs a) {
     }
     // initial position (method.py:159 init / :404-406 init_prev)
     {
-        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV {
             const int e = lane + 64 * i;
             double q0 = 0.0;
@@ -199,6 +202,13 @@ k_nuts(NutsArgs a) {
     uint32_t ss_t = 0;
     double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;
     int parity = 0;
+    // Batched random numbers: lane x of u_dir holds DIR(depth x) for x < 16 and TOP(depth x-16)
+    // for 16 <= x < 32 of the current transition; lane x of gum holds the Gumbel variate
+    // -log(-log u) of leaf (leaf & ~63) + x of the current doubling.
+    double u_dir = 0.0, gum = 0.0;
+    // Leaf energy errors dH of the current doubling, lane (leaf & 63); reduced 64 at a time into
+    // the running log-sum-weight (lw_m + log lw_s) and the accept statistic.
+    double dhb = 0.0, lw_m = -INFINITY, lw_s = 0.0;
 
     FORV { zq.v[i] = qs.v[i]; }
     const bool teacher = a.eps_in != nullptr;       // fixed step size / metric (test hook)
@@ -211,6 +221,24 @@ k_nuts(NutsArgs a) {
     }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
+    // reduce the buffered leaf energy errors (lanes 0..cnt-1 of dhb)
+    auto flush_dh = [&](int cnt) {
+        const bool ok = lane < cnt;
+        const double dh = ok ? dhb : -INFINITY;
+        const double mb = wave_max(dh);
+        const double m_new = fmax(lw_m, mb);
+        double w = 0.0, me = 0.0;
+        if (ok) {
+            w = (m_new == -INFINITY) ? 0.0 : exp(dh - m_new);
+            me = dh > 0 ? 1.0 : exp(dh);
+        }
+        wave_sum2(w, me);
+        const double scale = (lw_m == -INFINITY) ? 0.0 : exp(lw_m - m_new);
+        lw_s = lw_s * scale + w;
+        lw_m = m_new;
+        sum_metro += me;
+    };
+
 #ifdef EPX_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -219,6 +247,7 @@ k_nuts(NutsArgs a) {
     for (;;) {
         STAMP(6);
         // =================================================== leapfrog (single site of the gradient)
+        double kin = 0.0;
         FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
         FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
         {
@@ -244,7 +273,6 @@ k_nuts(NutsArgs a) {
             double bs[DP];
 #pragma unroll
             for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
-            alpha = uniform_d(alpha);
 
             STAMP(0);
             // ---- fused row pass: f = alpha + x.beta, g = y - sigmoid(f), acc += g x
@@ -261,9 +289,10 @@ k_nuts(NutsArgs a) {
                     const double2 v = rowp[jp ^ sw];
                     x[2 * jp] = v.x; x[2 * jp + 1] = v.y;
                 }
-                double f = alpha;
+                double f0 = alpha, f1 = 0.0;
 #pragma unroll
-                for (int j = 0; j < DP; ++j) f = fma(x[j], bs[j], f);
+                for (int j = 0; j < DP; j += 2) { f0 = fma(x[j], bs[j], f0); f1 = fma(x[j + 1], bs[j + 1], f1); }
+                const double f = f0 + f1;
                 double l, g;
                 logistic_terms(f, (double)ys[r], l, g);
                 ll += l; da += g;
@@ -286,10 +315,15 @@ k_nuts(NutsArgs a) {
                 for (int ii = 0; ii < NV; ++ii) {
                     const int lo = jb > 64 * ii ? jb : 64 * ii;
                     const int hi = je < 64 * (ii + 1) ? je : 64 * (ii + 1);
-                    for (int j = lo; j < hi; ++j) {
-                        const double vj = readlane_d(vv.v[ii], j & 63);
-                        const double *col = Om + (size_t)j * d;
-                        FORV { const int e = lane + 64 * i; if (e < d) Ov.v[i] = fma(col[e], vj, Ov.v[i]); }
+                    for (int j = lo; j < hi; j += 2) {
+                        // two columns per step: both loads are issued before the fmas
+                        const bool ok1 = j + 1 < hi;
+                        const int j1 = ok1 ? j + 1 : j;
+                        const double v0 = readlane_d(vv.v[ii], j & 63);
+                        const double v1 = ok1 ? readlane_d(vv.v[ii], j1 & 63) : 0.0;
+                        double c0[NV], c1[NV];
+                        FORV { const int e = lane + 64 * i; c0[i] = e < d ? om_at(j * d + e) : 0.0; c1[i] = e < d ? om_at(j1 * d + e) : 0.0; }
+                        FORV { Ov.v[i] = fma(c0[i], v0, Ov.v[i]); Ov.v[i] = fma(c1[i], v1, Ov.v[i]); }
                     }
                 }
             }
@@ -364,27 +398,109 @@ k_nuts(NutsArgs a) {
                 }
                 zg.v[i] = e < P ? g : 0.0;
             }
-            zlp = uniform_d(wave_sum(lpt) + ll);
+            // second half step of the momentum, then ONE reduction for lp and the kinetic energy
+            double ks = 0.0;
+            FORV { zp.v[i] += 0.5 * eps_l * zg.v[i]; ks += inv_e.v[i] * zp.v[i] * zp.v[i]; }
+            wave_sum2(lpt, ks);
+            zlp = lpt + ll;
+            kin = 0.5 * ks;
         }
-        FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
         ngrad += 1.0;
         STAMP(5);
 
-        // =================================================== state machine
-        bool do_begin_ss = false, do_ss_setup = false, do_begin_transition = false;
-        bool do_begin_doubling = false, do_end_doubling = false, do_end_transition = false;
-        int valid = 1;
-
-        double kin = 0.0;
-        {
-            double s = 0.0;
-            FORV s += inv_e.v[i] * zp.v[i] * zp.v[i];
-            kin = 0.5 * uniform_d(wave_sum(s));
-        }
         double h = -zlp + kin;
         if (isnan(h)) h = INFINITY;
 
-        if (mode == MODE_INIT) {
+        bool do_begin_ss = false, do_ss_setup = false, do_begin_transition = false;
+        bool do_begin_doubling = false, do_end_transition = false;
+
+        if (mode == MODE_TREE) {
+            // ---------------- one new leaf of the subtree being built (base_nuts::build_tree, depth 0)
+            ++nleap;
+            if (h - H0 > 1000.0) divergent = 1;
+            const double dH = H0 - h;
+            const int slot = leaf & 63;
+            dhb = (lane == slot) ? dH : dhb;
+            int valid = divergent ? 0 : 1;
+            int l = 0;
+            if (valid) {
+                FORV {
+                    n_rho.v[i] = zp.v[i];
+                    psr.v[i] = inv_e.v[i] * zp.v[i];
+                    n_psl.v[i] = psr.v[i];
+                    n_pq.v[i] = zq.v[i]; n_pg.v[i] = zg.v[i];
+                }
+                n_plp = zlp;
+                n_key = dH + readlane_d(gum, slot);      // Gumbel key: arg-max == multinomial draw
+                int ii = leaf;
+                while (ii & 1) {
+                    const int base = l * SREC;
+                    const double st_key = ld_stk(base + 4 * NV * 64), st_plp = ld_stk(base + 4 * NV * 64 + 1);
+                    const bool take_right = n_key > st_key;
+                    double c1 = 0.0, c2 = 0.0;
+                    FORV {
+                        const double Lrho = ld_stk(base + (0 * NV + i) * 64 + lane);
+                        const double Lpsl = ld_stk(base + (1 * NV + i) * 64 + lane);
+                        const double Lpq = ld_stk(base + (2 * NV + i) * 64 + lane);
+                        const double Lpg = ld_stk(base + (3 * NV + i) * 64 + lane);
+                        if (!take_right) { n_pq.v[i] = Lpq; n_pg.v[i] = Lpg; }
+                        n_rho.v[i] += Lrho;
+                        n_psl.v[i] = Lpsl;
+                        c1 += psr.v[i] * n_rho.v[i];
+                        c2 += n_psl.v[i] * n_rho.v[i];
+                    }
+                    if (!take_right) { n_plp = st_plp; n_key = st_key; }
+                    wave_sum2(c1, c2);
+                    if (!(c1 > 0 && c2 > 0)) { valid = 0; break; }
+                    ii >>= 1; ++l;
+                }
+            }
+            if (valid && leaf != nleaf - 1) {
+                // ---- fast path: park the node as a pending left sibling and keep integrating
+                const int base = l * SREC;
+                FORV {
+                    st_stk(base + (0 * NV + i) * 64 + lane, n_rho.v[i]);
+                    st_stk(base + (1 * NV + i) * 64 + lane, n_psl.v[i]);
+                    st_stk(base + (2 * NV + i) * 64 + lane, n_pq.v[i]);
+                    st_stk(base + (3 * NV + i) * 64 + lane, n_pg.v[i]);
+                }
+                if (lane == 0) { st_stk(base + 4 * NV * 64, n_key); st_stk(base + 4 * NV * 64 + 1, n_plp); }
+                ++leaf;
+                if ((leaf & 63) == 0) {
+                    flush_dh(64);
+                    double u1, u2;
+                    const uint32_t li = (uint32_t)(leaf + lane);
+                    rng_u2(key, (uint32_t)t + toff, K_MERGE, (uint32_t)depth, li >> 1, u1, u2);
+                    gum = -log(-log((li & 1) ? u2 : u1));
+                }
+                continue;
+            }
+            // ---- the new subtree is complete or was rejected
+            flush_dh(slot + 1);
+            if (fwd) { FORV { pq.v[i] = zq.v[i]; pp.v[i] = zp.v[i]; pg.v[i] = zg.v[i]; } plp = zlp; }
+            else     { FORV { mq.v[i] = zq.v[i]; mp.v[i] = zp.v[i]; mg.v[i] = zg.v[i]; } mlp = zlp; }
+            if (!valid) do_end_transition = true;
+            else {
+                ++depth;
+                const double lw_sub = lw_m + log(lw_s);
+                bool take;
+                if (lw_sub > lsw) take = true;
+                else take = readlane_d(u_dir, 16 + depth - 1) < exp(lw_sub - lsw);
+                if (take) { FORV { qs.v[i] = n_pq.v[i]; gs.v[i] = n_pg.v[i]; } lps = n_plp; }
+                lsw = log_sum_exp2(lsw, lw_sub);
+                double c1 = 0.0, c2 = 0.0;
+                FORV {
+                    rho.v[i] += n_rho.v[i];
+                    if (fwd) psp.v[i] = psr.v[i]; else psm.v[i] = psr.v[i];
+                    c1 += psp.v[i] * rho.v[i];
+                    c2 += psm.v[i] * rho.v[i];
+                }
+                wave_sum2(c1, c2);
+                if (!(c1 > 0 && c2 > 0)) do_end_transition = true;
+                else if (depth >= a.max_depth) do_end_transition = true;
+                else do_begin_doubling = true;
+            }
+        } else if (mode == MODE_INIT) {
             FORV { gs.v[i] = zg.v[i]; }
             lps = zlp;
             int fin = isfinite(zlp) ? 1 : 0;
@@ -400,7 +516,7 @@ k_nuts(NutsArgs a) {
             if (!fin) { failed = 1; break; }
             ss_t = 0; ss_after_update = 0;
             if (teacher) do_begin_transition = true; else do_begin_ss = true;
-        } else if (mode == MODE_SS) {
+        } else {
             const double dH = H0 - h;
             bool done = false;
             if (ss_trial == 0) ss_dir = dH > LOG08 ? 1 : -1;
@@ -413,89 +529,8 @@ k_nuts(NutsArgs a) {
             }
             if (done) {
                 if (ss_after_update) { da_mu = log(10.0 * eps); da_count = 0; s_bar = 0; x_bar = 0; }
-                if (ss_after_update && t == a.warmup) { /* unreachable: update windows end before warm-up does */ }
                 do_begin_transition = true;
             } else { ++ss_trial; do_ss_setup = true; }
-        } else {
-            // ---------------- one new leaf of the subtree being built (base_nuts::build_tree, depth 0)
-            ++nleap;
-            if (h - H0 > 1000.0) divergent = 1;
-            const double dH = H0 - h;
-            sum_metro += dH > 0 ? 1.0 : exp(dH);
-            if (divergent) { valid = 0; do_end_doubling = true; }
-            else {
-                FORV {
-                    n_rho.v[i] = zp.v[i];
-                    psr.v[i] = inv_e.v[i] * zp.v[i];
-                    n_psl.v[i] = psr.v[i];
-                    n_pq.v[i] = zq.v[i]; n_pg.v[i] = zg.v[i];
-                }
-                n_plp = zlp; n_lw = dH;
-                int l = 0, ii = leaf;
-                while (ii & 1) {
-                    const double *rec = stk + (size_t)l * SREC;
-                    const double st_lw = rec[4 * NV * 64], st_plp = rec[4 * NV * 64 + 1];
-                    const double lw_new = log_sum_exp2(st_lw, n_lw);
-                    const double u = rng_uniform(key, (uint32_t)t + toff, K_MERGE,
-                                                 ((uint32_t)depth << 16) | (uint32_t)leaf, (uint32_t)l);
-                    const bool take_right = (n_lw > lw_new) || (u < exp(n_lw - lw_new));
-                    double c1 = 0.0, c2 = 0.0;
-                    FORV {
-                        const double Lrho = rec[(0 * NV + i) * 64 + lane];
-                        const double Lpsl = rec[(1 * NV + i) * 64 + lane];
-                        if (!take_right) {
-                            n_pq.v[i] = rec[(2 * NV + i) * 64 + lane];
-                            n_pg.v[i] = rec[(3 * NV + i) * 64 + lane];
-                        }
-                        n_rho.v[i] += Lrho;
-                        n_psl.v[i] = Lpsl;
-                        c1 += psr.v[i] * n_rho.v[i];
-                        c2 += n_psl.v[i] * n_rho.v[i];
-                    }
-                    if (!take_right) n_plp = st_plp;
-                    n_lw = lw_new;
-                    wave_sum2(c1, c2);
-                    if (!(c1 > 0 && c2 > 0)) { valid = 0; break; }
-                    ii >>= 1; ++l;
-                }
-                if (!valid) do_end_doubling = true;
-                else if (leaf != nleaf - 1) {
-                    double *rec = stk + (size_t)l * SREC;
-                    FORV {
-                        rec[(0 * NV + i) * 64 + lane] = n_rho.v[i];
-                        rec[(1 * NV + i) * 64 + lane] = n_psl.v[i];
-                        rec[(2 * NV + i) * 64 + lane] = n_pq.v[i];
-                        rec[(3 * NV + i) * 64 + lane] = n_pg.v[i];
-                    }
-                    if (lane == 0) { rec[4 * NV * 64] = n_lw; rec[4 * NV * 64 + 1] = n_plp; }
-                    ++leaf;               // continue integrating from z
-                } else do_end_doubling = true;
-            }
-        }
-
-        if (do_end_doubling) {
-            if (fwd) { FORV { pq.v[i] = zq.v[i]; pp.v[i] = zp.v[i]; pg.v[i] = zg.v[i]; } plp = zlp; }
-            else     { FORV { mq.v[i] = zq.v[i]; mp.v[i] = zp.v[i]; mg.v[i] = zg.v[i]; } mlp = zlp; }
-            if (!valid) do_end_transition = true;
-            else {
-                ++depth;
-                bool take;
-                if (n_lw > lsw) take = true;
-                else take = rng_uniform(key, (uint32_t)t + toff, K_TOP, (uint32_t)(depth - 1), 0) < exp(n_lw - lsw);
-                if (take) { FORV { qs.v[i] = n_pq.v[i]; gs.v[i] = n_pg.v[i]; } lps = n_plp; }
-                lsw = log_sum_exp2(lsw, n_lw);
-                double c1 = 0.0, c2 = 0.0;
-                FORV {
-                    rho.v[i] += n_rho.v[i];
-                    if (fwd) psp.v[i] = psr.v[i]; else psm.v[i] = psr.v[i];
-                    c1 += psp.v[i] * rho.v[i];
-                    c2 += psm.v[i] * rho.v[i];
-                }
-                wave_sum2(c1, c2);
-                if (!(c1 > 0 && c2 > 0)) do_end_transition = true;
-                else if (depth >= a.max_depth) do_end_transition = true;
-                else do_begin_doubling = true;
-            }
         }
 
         if (do_end_transition) {
@@ -510,7 +545,7 @@ k_nuts(NutsArgs a) {
                 const double eta_da = 1.0 / (da_count + T0);
                 s_bar = (1.0 - eta_da) * s_bar + eta_da * (DELTA - as);
                 const double x = da_mu - s_bar * sqrt(da_count) / GAMMA;
-                const double x_eta = pow(da_count, -KAPPA);
+                const double x_eta = exp(-KAPPA * log(da_count));          // da_count^(-kappa)
                 x_bar = (1.0 - x_eta) * x_bar + x_eta * x;
                 eps = exp(x);
                 // var_adaptation::learn_variance
@@ -574,7 +609,7 @@ k_nuts(NutsArgs a) {
                 zq.v[i] = qs.v[i]; zg.v[i] = gs.v[i];
                 s += inv_e.v[i] * zp.v[i] * zp.v[i];
             }
-            H0 = -lps + 0.5 * uniform_d(wave_sum(s));
+            H0 = -lps + 0.5 * wave_sum(s);
             eps_l = eps;
         }
         if (do_begin_transition) {
@@ -590,17 +625,25 @@ k_nuts(NutsArgs a) {
                 s += inv_e.v[i] * pp.v[i] * pp.v[i];
             }
             plp = lps; mlp = lps;
-            H0 = -lps + 0.5 * uniform_d(wave_sum(s));
+            H0 = -lps + 0.5 * wave_sum(s);
             lsw = 0.0; sum_metro = 0.0; depth = 0; nleap = 0; divergent = 0;
+            // direction / top-level uniforms of this transition in one Philox batch
+            u_dir = rng_uniform(key, (uint32_t)t + toff, lane < 16 ? K_DIR : K_TOP, (uint32_t)(lane & 15), 0);
             mode = MODE_TREE;
             do_begin_doubling = true;
         }
         if (do_begin_doubling) {
-            fwd = rng_uniform(key, (uint32_t)t + toff, K_DIR, (uint32_t)depth, 0) > 0.5 ? 1 : 0;
+            fwd = readlane_d(u_dir, depth) > 0.5 ? 1 : 0;
             eps_l = fwd ? eps : -eps;
             if (fwd) { FORV { zq.v[i] = pq.v[i]; zp.v[i] = pp.v[i]; zg.v[i] = pg.v[i]; } zlp = plp; }
             else     { FORV { zq.v[i] = mq.v[i]; zp.v[i] = mp.v[i]; zg.v[i] = mg.v[i]; } zlp = mlp; }
             leaf = 0; nleaf = 1 << depth;
+            lw_m = -INFINITY; lw_s = 0.0;
+            {
+                double u1, u2;
+                rng_u2(key, (uint32_t)t + toff, K_MERGE, (uint32_t)depth, (uint32_t)(lane >> 1), u1, u2);
+                gum = -log(-log((lane & 1) ? u2 : u1));
+            }
         }
     }
 
@@ -650,14 +693,18 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     if (off + om <= cap) { a.om_in_lds = 1; off += om; off = (off + 15) & ~(size_t)15; }
     const size_t stack = (size_t)a.cpb * a.max_depth * (4 * nv * 64 + 2) * 8;
     a.stack_in_lds = 0; a.off_stack = (int)off;
-    if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
+    if (a.om_in_lds && off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
+    if (wpc > 1 && !a.stack_in_lds && a.om_in_lds) {      // layout 2 is built for "both" or "neither"
+        a.om_in_lds = 0;
+        off = (size_t)a.off_Om;
+    }
     a.lds_bytes = (int)off;
     return off;
 }
 
-template <int NV, int DP, int WPC>
+template <int NV, int DP, int WPC, bool OML, bool STL>
 static int launch_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
-    auto kern = k_nuts<NV, DP, WPC>;
+    auto kern = k_nuts<NV, DP, WPC, OML, STL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return (int)e;
@@ -668,8 +715,16 @@ static int launch_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 
 template <int NV, int DP>
 static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t stream) {
-    if (wpc == 1) return launch_one<NV, DP, 1>(a, nblocks, stream);
-    if (wpc == 4) return launch_one<NV, DP, 4>(a, nblocks, stream);
+    // (Omega in LDS, stack in LDS): layout 2 has both or neither; layout 1 may have Omega only
+    if (wpc == 4) {
+        if (a.om_in_lds && a.stack_in_lds) return launch_one<NV, DP, 4, true, true>(a, nblocks, stream);
+        return launch_one<NV, DP, 4, false, false>(a, nblocks, stream);
+    }
+    if (wpc == 1) {
+        if (a.om_in_lds && a.stack_in_lds) return launch_one<NV, DP, 1, true, true>(a, nblocks, stream);
+        if (a.om_in_lds) return launch_one<NV, DP, 1, true, false>(a, nblocks, stream);
+        return launch_one<NV, DP, 1, false, false>(a, nblocks, stream);
+    }
     return -1;
 }
 
