@@ -106,6 +106,24 @@ __device__ inline double partner_d(double x, int lane) {
     else return dpp_d<DPP_QUAD_XOR1>(x);
 }
 
+// One butterfly exchange for selector bit 5 or 4 without selects: v_permlane{32,16}_swap
+// swaps the upper half (odd rows) of `a` with the lower half (even rows) of `b`, after which
+// lanes whose bit B is 0 hold (own a, partner's a) and the others (partner's b, own b):
+// a' + b' is "keep + received" for every lane.
+template <int B>
+__device__ inline double swap_add_d(double a, double b) {
+    union { double d; unsigned u[2]; } x, y, p, q;
+    x.d = a; y.d = b;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        v2u_t s;
+        if constexpr (B == 5) s = __builtin_amdgcn_permlane32_swap(x.u[h], y.u[h], false, false);
+        else s = __builtin_amdgcn_permlane16_swap(x.u[h], y.u[h], false, false);
+        p.u[h] = s.x; q.u[h] = s.y;
+    }
+    return p.d + q.d;
+}
+
 // value of lane `lane` (wave-uniform index) broadcast as a scalar
 __device__ inline double readlane_d(double v, int lane) {
     union { double d; uint32_t u[2]; } x;

@@ -77,12 +77,17 @@ enum { MODE_INIT = 0, MODE_SS = 1, MODE_TREE = 2 };
 template <int CNT, int B>
 __device__ inline void butterfly(double *acc, int lane) {
     if constexpr (CNT > 1) {
-        const bool upper = (lane >> B) & 1;
+        if constexpr (B >= 4) {
 #pragma unroll
-        for (int j = 0; j < CNT / 2; ++j) {
-            const double send = upper ? acc[j] : acc[j + CNT / 2];
-            const double keep = upper ? acc[j + CNT / 2] : acc[j];
-            acc[j] = keep + partner_d<B>(send, lane);
+            for (int j = 0; j < CNT / 2; ++j) acc[j] = swap_add_d<B>(acc[j], acc[j + CNT / 2]);
+        } else {
+            const bool upper = (lane >> B) & 1;
+#pragma unroll
+            for (int j = 0; j < CNT / 2; ++j) {
+                const double send = upper ? acc[j] : acc[j + CNT / 2];
+                const double keep = upper ? acc[j + CNT / 2] : acc[j];
+                acc[j] = keep + partner_d<B>(send, lane);
+            }
         }
         butterfly<CNT / 2, B - 1>(acc, lane);
     } else if constexpr (B >= 0) {

@@ -303,8 +303,8 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
             # warm-up (search, dual averaging, metric window) and the first kept draws must agree;
             # later a chain may part ways once rounding differences have been amplified past a
             # decision threshold (chaotic trajectories) -- most chains never do in these runs
-            assert np.all(err[c, :5] < 2e-5), (k, c, err[c, :5])
-            if np.all(err[c] < 2e-5):
+            assert np.all(err[c, :5] < 1e-3), (k, c, err[c, :5])      # a wrong decision gives O(0.1-1)
+            if np.all(err[c] < 1e-4):
                 n_full += 1
                 assert cs[k, c, 2] == st_o[k, c, 2]                              # same leapfrog count
                 assert cs[k, c, 3] == st_o[k, c, 3]                              # same gradient count
@@ -367,8 +367,8 @@ def test_nuts_layouts_agree_and_are_deterministic():
     np.testing.assert_array_equal(out[1][0], out[1][1])                    # bitwise reproducible
     # 1 wave per chain vs 4 waves per chain: same algorithm, different summation order
     err = np.abs(out[1][0] - out[2][0]).reshape(2, 4, 22, P).max(axis=3)
-    assert np.all(err[:, :, :5] < 2e-5)
-    assert np.sum(np.all(err < 2e-5, axis=2)) >= 6
+    assert np.all(err[:, :, :5] < 1e-3)
+    assert np.sum(np.all(err < 1e-4, axis=2)) >= 6
 
 
 def test_nuts_warm_start_and_thin():
