@@ -82,10 +82,13 @@ def main():
     from epstan_amd import dist as edist, models
     from epstan_amd.method import Master
     comm = None
-    if world > 1:
+    under_torchrun = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    if world > 1 or under_torchrun:
+        # one rank per GPU over RCCL; also taken at world_size 1 under torchrun so that the
+        # collective path (device-resident packed sums, all-reduce) is the one exercised
         import torch.distributed as tdist
         torch.cuda.set_device(local_rank)
-        tdist.init_process_group('nccl')
+        tdist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         comm = edist.TorchComm(device=torch.device('cuda', local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
@@ -99,7 +102,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if comm is not None:
             tdist.barrier()
 
     if args.warmup > 0:
@@ -112,11 +115,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     info = res[0]
-    if world > 1:
+    if comm is not None:
         tmax = comm.allreduce_max(np.array([dt]))[0]
+        tdist.barrier()
     else:
         tmax = dt
     if rank != 0:
+        tdist.destroy_process_group()
         return
     assert info == 0, 'EP failed with info %d' % info
 
@@ -125,13 +130,22 @@ def main():
     ngrad = np.array(M.ngrad_log[n_launch0:])
     n_rows = float(args.n)
     F_g = 4.0 * n_rows * args.D + 12.0 * n_rows             # SURVEY.md §8d flops per gradient
-    B_g = n_rows * args.D * 8 + n_rows * 4                   # bytes per gradient sweep (LDS resident)
     flops_per_launch = float(ngrad.mean()) * F_g
     t_kernel = float(ms.mean()) * 1e-3
     achieved_tf = flops_per_launch / t_kernel / 1e12
     sites_local = args.sites
-    hbm_alg = sites_local * (B_g + 2 * (M.dphi**2 + M.dphi) * 8) \
-        + sites_local * args.chains * ((args.siter - args.siter // 2) * M.engine.P * 8)
+    # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup: one
+    # workgroup per (site, chain) in layout 2, per site in layout 1), draws and last states out
+    wg_per_site = 1 if sites_local >= 192 or args.layout == 1 else args.chains
+    P = M.engine.P
+    hbm_alg = sites_local * wg_per_site * (n_rows * args.D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
+        + sites_local * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_c2_pmc_hbm.json')
+    if (os.path.exists(pmc) and (args.sites, args.D, args.n, args.model, args.chains, args.siter)
+            == (64, 16, 200, 'm4b', 4, 200)):
+        # measured separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
+        traffic = json.load(open(pmc))['hbm_bytes_per_launch_corrected']
     out = {
         'metric': 'site-updates/sec', 'value': J * args.steps / tmax, 'unit': 'site-updates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -145,7 +159,7 @@ def main():
                    'parallelism': 'sites sharded over %d GPU(s), 1 all-reduce/iter' % world},
         'roofline': {'kernel': 'k_nuts (sampler)', 'bound': 'mfma', 'achieved': achieved_tf,
                      'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / FP64_PEAK_TFLOPS,
-                     'traffic': None,
+                     'traffic': traffic,
                      'note': 'FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
                              'duration of the sampler launch; X is LDS resident, so HBM is not the bound: '
                              'hbm_frac below',
@@ -156,6 +170,8 @@ def main():
         'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
                                                / (sites_local * args.chains * args.siter)),
     }
+    if comm is not None:
+        tdist.destroy_process_group()
     if args.cpu_sites > 0:
         try:
             out['cpu_baseline'] = cpu_baseline(mod, data, Q0, r0, min(args.cpu_sites, J), args.chains,
