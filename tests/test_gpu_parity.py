@@ -441,3 +441,82 @@ def test_ep_iterations_at_c2_properties(name, J, D, n):
     np.testing.assert_allclose(vec, mt, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(Mat, scatter, rtol=1e-9, atol=1e-9)
     assert nsamp == 400
+
+
+# ------------------------------------------------------------------ shapes and edge cases
+@pytest.mark.parametrize('chains,it,thin,init', [(1, 30, 1, 'random'), (2, 40, 3, '0'), (8, 24, 1, 'random'),
+                                                 (3, 30, 2, 'random')])
+def test_nuts_chain_counts_thin_init(chains, it, thin, init):
+    """chains != 4 (find_damp.py uses 8), thinning, init='0' (method.py:154-160, 579-583)."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 4, 40, 77, K=3, tight=100.0)
+    eng, Om_dev, mu_dev = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    seeds = np.array([3, 4, 5], dtype=np.int64)
+    for layout in (1, 2):
+        opts = HipEngine.sampler_opts(chains=chains, iter=it, thin=thin, init=init, layout=layout)
+        stats, ms = eng.sample_batch(seeds, opts)
+        ini = None if init == 'random' else np.zeros((3, chains, P))
+        draws_o, _, st_o = no.nuts_sites('m4b_sg', X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it,
+                                         thin=thin, init=ini)
+        nk = draws_o.shape[2]
+        assert eng.num_draws() == chains * nk
+        for k in range(3):
+            dev = eng.get_draws(k, True).reshape(chains, nk, P)
+            err = np.abs(dev - draws_o[k]).max(axis=(1, 2))
+            assert np.sum(err < 1e-4) >= chains - 1, err
+
+
+def test_ragged_sites_and_extreme_shapes():
+    """Sites of very different sizes (n_j = 1 ... 1500), D = 1, and rows that need several passes
+    per lane: the gradient at every site equals the oracle's."""
+    rng = np.random.RandomState(5)
+    for model, D, sizes in [('m1b_sg', 1, [1, 2, 63, 64, 65, 700]), ('m4b_sg', 5, [1, 257, 1500, 3]),
+                            ('m3b_sg', 32, [300, 1, 129]), ('m2b_sg', 7, [10, 512])]:
+        N = int(np.sum(sizes))
+        X = rng.randn(N, D)
+        y = (rng.rand(N) < 0.4).astype(int)
+        k_lim = np.concatenate(([0], np.cumsum(sizes)))
+        d, P = no.dims(model, D)
+        K = len(sizes)
+        Oms = np.stack([np.eye(d) * (1.0 + k) for k in range(K)])
+        mus = rng.randn(K, d) * 0.3
+        eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+        for k in range(K):
+            th = rng.randn(P) * 0.5
+            lp, g = eng.logdensity_grad(k, th)
+            lp_o, g_o = no.logdensity_grad(model, X[k_lim[k]:k_lim[k + 1]], y[k_lim[k]:k_lim[k + 1]],
+                                           mu_dev[k], Om_dev[k], th)
+            assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o))
+            np.testing.assert_allclose(g, g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+        # and a short sampling run over the ragged batch in both layouts terminates with finite draws
+        for layout in (1, 2):
+            stats, ms = eng.sample_batch(np.arange(K) + 1, HipEngine.sampler_opts(chains=2, iter=20, layout=layout))
+            assert np.all(np.isfinite(stats)) and np.all(stats[:, 7] == 0)
+
+
+def test_many_sites_batch_and_errors():
+    """K = 600 small sites in one launch (more sites than CUs, layout 1 by default), reproducible
+    and equal to sampling the same sites one at a time; unsupported shapes fail loudly."""
+    rng = np.random.RandomState(8)
+    K, n, D = 600, 12, 3
+    X = rng.randn(K * n, D); y = (rng.rand(K * n) < 0.5).astype(int)
+    eng = HipEngine('m1b_sg', X, y, np.arange(K + 1) * n)
+    eng.set_prior(np.eye(4), np.zeros(4))
+    eng.set_global(np.eye(4) * 2.0, np.zeros(4))
+    assert np.all(eng.cavity_batch(QI))
+    seeds = np.arange(K) + 100
+    opts = HipEngine.sampler_opts(chains=4, iter=20)
+    eng.sample_batch(seeds, opts)
+    all_draws = np.stack([eng.get_draws(k, True) for k in (0, 299, 599)])
+    for j, k in enumerate((0, 299, 599)):
+        eng.sample_batch(seeds[k:k + 1], HipEngine.sampler_opts(chains=4, iter=20, layout=1), k0=k, count=1)
+        np.testing.assert_array_equal(eng.get_draws(k, True), all_draws[j])
+    with pytest.raises(_lib.EpxError):                      # D > 32: streaming variant not built yet
+        HipEngine('m4b_sg', rng.randn(40, 40), np.zeros(40, dtype=int), np.array([0, 20, 40])).sample_batch(
+            np.array([1, 2]), opts)
+    with pytest.raises(_lib.EpxError):                      # rows of one site exceed LDS
+        HipEngine('m1b_sg', rng.randn(3000, 16), np.zeros(3000, dtype=int), np.array([0, 2999, 3000])
+                  ).sample_batch(np.array([1, 2]), opts)
+    with pytest.raises(_lib.EpxError):
+        HipEngine('m1b_sg', X, np.full(K * n, 2), np.arange(K + 1) * n)      # y must be 0/1
+    with pytest.raises(_lib.EpxError):
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=20, warmup=20))
