@@ -257,7 +257,7 @@ k_nuts(NutsArgs a) {
         FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
         {
             V eq;
-            FORV eq.v[i] = exp(zq.v[i]);
+            FORV eq.v[i] = exp_d(zq.v[i]);
             double alpha, sa, eta, sb2 = 0.0;
             double beta_l;
             if (model == 0) {
