@@ -71,7 +71,7 @@ def main():
     ap.add_argument('--siter', type=int, default=200)
     ap.add_argument('--prec-estim', default='sample')
     ap.add_argument('--layout', type=int, default=0)
-    ap.add_argument('--cpu-sites', type=int, default=16, help='0 disables the cpu_baseline leg')
+    ap.add_argument('--cpu-sites', type=int, default=32, help='0 disables the cpu_baseline leg')
     ap.add_argument('--cpu-threads', type=int, default=0)
     args = ap.parse_args()
 

@@ -320,15 +320,19 @@ k_nuts(NutsArgs a) {
                 for (int ii = 0; ii < NV; ++ii) {
                     const int lo = jb > 64 * ii ? jb : 64 * ii;
                     const int hi = je < 64 * (ii + 1) ? je : 64 * (ii + 1);
-                    for (int j = lo; j < hi; j += 2) {
-                        // two columns per step: both loads are issued before the fmas
-                        const bool ok1 = j + 1 < hi;
-                        const int j1 = ok1 ? j + 1 : j;
-                        const double v0 = readlane_d(vv.v[ii], j & 63);
-                        const double v1 = ok1 ? readlane_d(vv.v[ii], j1 & 63) : 0.0;
-                        double c0[NV], c1[NV];
-                        FORV { const int e = lane + 64 * i; c0[i] = e < d ? om_at(j * d + e) : 0.0; c1[i] = e < d ? om_at(j1 * d + e) : 0.0; }
-                        FORV { Ov.v[i] = fma(c0[i], v0, Ov.v[i]); Ov.v[i] = fma(c1[i], v1, Ov.v[i]); }
+                    constexpr int CU = OML ? 2 : 4;     // columns in flight: more when Omega streams from L2
+                    for (int j = lo; j < hi; j += CU) {
+                        double vj[CU], cc[CU][NV];
+#pragma unroll
+                        for (int u = 0; u < CU; ++u) {
+                            const bool ok = j + u < hi;
+                            const int ju = ok ? j + u : j;
+                            const double t2 = readlane_d(vv.v[ii], ju & 63);
+                            vj[u] = ok ? t2 : 0.0;
+                            FORV { const int e = lane + 64 * i; cc[u][i] = e < d ? om_at(ju * d + e) : 0.0; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < CU; ++u) { FORV Ov.v[i] = fma(cc[u][i], vj[u], Ov.v[i]); }
                     }
                 }
             }
