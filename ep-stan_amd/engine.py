@@ -225,6 +225,12 @@ class HipEngine(object):
         check(self.lib.epx_logdensity_grad(self.ctx, int(k), dptr(theta), ctypes.byref(lp), dptr(g)))
         return lp.value, g
 
+    def invert_normal_params(self, A, b):
+        """util.invert_normal_params on this engine's device (new arrays)."""
+        from . import util
+        return util.invert_normal_params(np.asfortranarray(A, dtype=np.float64),
+                                         np.asarray(b, dtype=np.float64))
+
     # ---- global update
     def site_sums(self, out_tensor=None):
         """Packed [sum Qi, sum ri, sum dQi, sum dri] of the local sites.

@@ -566,7 +566,7 @@ class Master(object):
 
     def cur_approx(self):
         """Current posterior approximation moments (S, m) (method.py:884-896)."""
-        return invert_normal_params(self.Q, self.r)
+        return self.engine.invert_normal_params(self.Q, self.r)
 
     def _ret(self, info, calc_moments, return_analytics, moments, analytics, as_tuple=False):
         out = [info]

@@ -179,6 +179,9 @@ class OracleEngine(object):
         return no.logdensity_grad(self.model, self.X[lo:hi], self.y[lo:hi], self.cav_mu[k],
                                   self.cav_Om[k], theta)
 
+    def invert_normal_params(self, A, b):
+        return eo.invert_normal_params(A, b)
+
     # ---- global update
     def site_sums(self, out_tensor=None):
         out = np.concatenate([self.Qi.sum(2).ravel(order='F'), self.ri.sum(1),

@@ -520,3 +520,19 @@ def test_many_sites_batch_and_errors():
         HipEngine('m1b_sg', X, np.full(K * n, 2), np.arange(K + 1) * n)      # y must be 0/1
     with pytest.raises(_lib.EpxError):
         eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=20, warmup=20))
+
+
+def test_fit_main_and_kl_on_gpu(tmp_path, monkeypatch):
+    """fit.py's EP branch end to end on the device, scored with kl_mvn (plot_res.py:41-60)."""
+    from epstan_amd import fit
+    monkeypatch.setattr(fit, 'RES_PATH', str(tmp_path))
+    conf = fit.configurations(J=4, D=4, K=4, npg=50, iter=3, siter=100, run_ep=True, save_res=False)
+    res = fit.main('m4b', conf, verbose=False)
+    assert res['m_s_ep'].shape == (4, 10)
+    S, m = res['S_s_ep'][-1], res['m_s_ep'][-1]
+    assert abs(fit.kl_mvn(m, S, m, S)) < 1e-9
+    S1 = S * 1.3
+    ref = 0.5 * (np.trace(np.linalg.solve(S1, S)) - 10 + np.linalg.slogdet(S1)[1] - np.linalg.slogdet(S)[1])
+    assert abs(fit.kl_mvn(m, S, m, S1) - ref) < 1e-9
+    # three EP iterations move the approximation away from the prior towards the data
+    assert fit.kl_mvn(res['m_s_ep'][-1], res['S_s_ep'][-1], res['m_s_ep'][0], res['S_s_ep'][0]) > 1.0

@@ -246,3 +246,31 @@ def test_force_pd_branch(runs):
 def test_site_range():
     assert [dist.site_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
     assert dist.site_range(4096, 7, 8) == (3584, 4096)
+
+
+# ---------------------------------------------------------------- fit.py plumbing
+def test_fit_configurations_and_ep_branch_schema(tmp_path, monkeypatch):
+    from epstan_amd import fit
+    conf = fit.configurations()
+    assert (conf.J, conf.D, conf.K, conf.npg, conf.siter, conf.chains) == (64, 16, 32, 20, 200, 4)   # fit.py:134-151
+    assert (conf.seed_data, conf.seed_ep, conf.prec_estim) == (100, 1, 'sample')
+    assert fit.EP_DEFAULT_ITERS_TO_RUN(64) == 256 and fit.EP_DEFAULT_ITERS_TO_RUN(3) == 20
+    with pytest.raises(ValueError):
+        fit.configurations(bogus=1)
+    assert 'J = 64' in str(conf)
+    monkeypatch.setattr(fit, 'RES_PATH', str(tmp_path))
+    conf = fit.configurations(J=4, D=3, K=4, npg=15, iter=2, siter=40, run_ep=True, id='t')
+    res = fit.main('m1b', conf, verbose=False, _engine_factory=factory)
+    d = 4
+    assert res['m_s_ep'].shape == (3, d) and res['S_s_ep'].shape == (3, d, d)      # initial approx prepended
+    assert res['time_s_ep'][0] == 0.0 and np.all(np.diff(res['time_s_ep']) >= 0)
+    assert np.isnan(res['mstepsize_s_ep'][0]) and np.isnan(res['mrhat_s_ep'][0]) and res['othertimes'].shape == (2,)
+    saved = np.load(os.path.join(str(tmp_path), 'res_d_m1b_t.npz'), allow_pickle=True)
+    assert set(saved.files) == {'conf', 'm_s_ep', 'S_s_ep', 'time_s_ep', 'mstepsize_s_ep', 'mrhat_s_ep', 'othertimes'}
+    np.testing.assert_allclose(res['S_s_ep'][0], np.eye(d) * 1.5**2, rtol=1e-12)        # the prior (m1b.py:46-50)
+    with pytest.raises(NotImplementedError):
+        fit.main('m1b', fit.configurations(J=8, K=4, run_ep=True), _engine_factory=factory)
+    with pytest.raises(NotImplementedError):
+        fit.main('m1b', fit.configurations(run_full=True), _engine_factory=factory)
+    M = fit.main('m4b', fit.configurations(J=4, D=2, K=4, npg=10), ret_master=True, _engine_factory=factory)
+    assert isinstance(M, Master) and M.dphi == 6 and abs(M.df0(1) - 0.5) < 1e-15
