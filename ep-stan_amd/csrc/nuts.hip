@@ -417,243 +417,11 @@ k_nuts(NutsArgs a) {
         ngrad += 1.0;
         STAMP(5);
 
-        double h = -zlp + kin;
-        if (isnan(h)) h = INFINITY;
-
-        bool do_begin_ss = false, do_ss_setup = false, do_begin_transition = false;
-        bool do_begin_doubling = false, do_end_transition = false;
-
-        if (mode == MODE_TREE) {
-            // ---------------- one new leaf of the subtree being built (base_nuts::build_tree, depth 0)
-            ++nleap;
-            if (h - H0 > 1000.0) divergent = 1;
-            const double dH = H0 - h;
-            const int slot = leaf & 63;
-            dhb = (lane == slot) ? dH : dhb;
-            int valid = divergent ? 0 : 1;
-            int l = 0;
-            if (valid) {
-                FORV {
-                    n_rho.v[i] = zp.v[i];
-                    psr.v[i] = inv_e.v[i] * zp.v[i];
-                    n_psl.v[i] = psr.v[i];
-                    n_pq.v[i] = zq.v[i]; n_pg.v[i] = zg.v[i];
-                }
-                n_plp = zlp;
-                n_key = dH + readlane_d(gum, slot);      // Gumbel key: arg-max == multinomial draw
-                int ii = leaf;
-                while (ii & 1) {
-                    const int base = l * SREC;
-                    const double st_key = ld_stk(base + 4 * NV * 64), st_plp = ld_stk(base + 4 * NV * 64 + 1);
-                    const bool take_right = n_key > st_key;
-                    double c1 = 0.0, c2 = 0.0;
-                    FORV {
-                        const double Lrho = ld_stk(base + (0 * NV + i) * 64 + lane);
-                        const double Lpsl = ld_stk(base + (1 * NV + i) * 64 + lane);
-                        const double Lpq = ld_stk(base + (2 * NV + i) * 64 + lane);
-                        const double Lpg = ld_stk(base + (3 * NV + i) * 64 + lane);
-                        if (!take_right) { n_pq.v[i] = Lpq; n_pg.v[i] = Lpg; }
-                        n_rho.v[i] += Lrho;
-                        n_psl.v[i] = Lpsl;
-                        c1 += psr.v[i] * n_rho.v[i];
-                        c2 += n_psl.v[i] * n_rho.v[i];
-                    }
-                    if (!take_right) { n_plp = st_plp; n_key = st_key; }
-                    wave_sum2(c1, c2);
-                    if (!(c1 > 0 && c2 > 0)) { valid = 0; break; }
-                    ii >>= 1; ++l;
-                }
-            }
-            if (valid && leaf != nleaf - 1) {
-                // ---- fast path: park the node as a pending left sibling and keep integrating
-                const int base = l * SREC;
-                FORV {
-                    st_stk(base + (0 * NV + i) * 64 + lane, n_rho.v[i]);
-                    st_stk(base + (1 * NV + i) * 64 + lane, n_psl.v[i]);
-                    st_stk(base + (2 * NV + i) * 64 + lane, n_pq.v[i]);
-                    st_stk(base + (3 * NV + i) * 64 + lane, n_pg.v[i]);
-                }
-                if (lane == 0) { st_stk(base + 4 * NV * 64, n_key); st_stk(base + 4 * NV * 64 + 1, n_plp); }
-                ++leaf;
-                if ((leaf & 63) == 0) {
-                    flush_dh(64);
-                    double u1, u2;
-                    const uint32_t li = (uint32_t)(leaf + lane);
-                    rng_u2(key, (uint32_t)t + toff, K_MERGE, (uint32_t)depth, li >> 1, u1, u2);
-                    gum = -log(-log((li & 1) ? u2 : u1));
-                }
-                continue;
-            }
-            // ---- the new subtree is complete or was rejected
-            flush_dh(slot + 1);
-            if (fwd) { FORV { pq.v[i] = zq.v[i]; pp.v[i] = zp.v[i]; pg.v[i] = zg.v[i]; } plp = zlp; }
-            else     { FORV { mq.v[i] = zq.v[i]; mp.v[i] = zp.v[i]; mg.v[i] = zg.v[i]; } mlp = zlp; }
-            if (!valid) do_end_transition = true;
-            else {
-                ++depth;
-                const double lw_sub = lw_m + log(lw_s);
-                bool take;
-                if (lw_sub > lsw) take = true;
-                else take = readlane_d(u_dir, 16 + depth - 1) < exp(lw_sub - lsw);
-                if (take) { FORV { qs.v[i] = n_pq.v[i]; gs.v[i] = n_pg.v[i]; } lps = n_plp; }
-                lsw = log_sum_exp2(lsw, lw_sub);
-                double c1 = 0.0, c2 = 0.0;
-                FORV {
-                    rho.v[i] += n_rho.v[i];
-                    if (fwd) psp.v[i] = psr.v[i]; else psm.v[i] = psr.v[i];
-                    c1 += psp.v[i] * rho.v[i];
-                    c2 += psm.v[i] * rho.v[i];
-                }
-                wave_sum2(c1, c2);
-                if (!(c1 > 0 && c2 > 0)) do_end_transition = true;
-                else if (depth >= a.max_depth) do_end_transition = true;
-                else do_begin_doubling = true;
-            }
-        } else if (mode == MODE_INIT) {
-            FORV { gs.v[i] = zg.v[i]; }
-            lps = zlp;
-            int fin = isfinite(zlp) ? 1 : 0;
-            FORV { if (!isfinite(zg.v[i])) fin = 0; }
-            fin = __all(fin);
-            if (a.dbg) {
-                if (wt == 0) {
-                    if (lane == 0) a.dbg[0] = zlp;
-                    FORV { const int e = lane + 64 * i; if (e < P) a.dbg[1 + e] = zg.v[i]; }
-                }
-                return;
-            }
-            if (!fin) { failed = 1; break; }
-            ss_t = 0; ss_after_update = 0;
-            if (teacher) do_begin_transition = true; else do_begin_ss = true;
-        } else {
-            const double dH = H0 - h;
-            bool done = false;
-            if (ss_trial == 0) ss_dir = dH > LOG08 ? 1 : -1;
-            else {
-                if (ss_dir == 1 && !(dH > LOG08)) done = true;
-                else if (ss_dir == -1 && !(dH < LOG08)) done = true;
-                else eps = ss_dir == 1 ? 2.0 * eps : 0.5 * eps;
-                if (!done && (eps > 1e7 || eps == 0.0)) done = true;
-                if (!done && ss_trial > 200) done = true;
-            }
-            if (done) {
-                if (ss_after_update) { da_mu = log(10.0 * eps); da_count = 0; s_bar = 0; x_bar = 0; }
-                do_begin_transition = true;
-            } else { ++ss_trial; do_ss_setup = true; }
-        }
-
-        if (do_end_transition) {
-            const double accept = sum_metro / (double)nleap;
-            eps_sum += eps;
-            nleap_tot += nleap;
-            bool metric_updated = false;
-            if (t < a.warmup) {
-                // stepsize_adaptation::learn_stepsize
-                da_count += 1.0;
-                const double as = accept > 1.0 ? 1.0 : accept;
-                const double eta_da = 1.0 / (da_count + T0);
-                s_bar = (1.0 - eta_da) * s_bar + eta_da * (DELTA - as);
-                const double x = da_mu - s_bar * sqrt(da_count) / GAMMA;
-                const double x_eta = exp(-KAPPA * log(da_count));          // da_count^(-kappa)
-                x_bar = (1.0 - x_eta) * x_bar + x_eta * x;
-                eps = exp(x);
-                // var_adaptation::learn_variance
-                const bool in_win = (va_counter >= va_init_buf) && (va_counter < a.warmup - va_term) &&
-                                    (va_counter != a.warmup);
-                if (in_win) {
-                    va_n += 1.0;
-                    FORV {
-                        const double delta = qs.v[i] - wmean.v[i];
-                        wmean.v[i] += delta / va_n;
-                        wm2.v[i] += (qs.v[i] - wmean.v[i]) * delta;
-                    }
-                }
-                const bool end_win = (va_counter == va_next) && (va_counter != a.warmup);
-                if (end_win) {
-                    if (va_next != a.warmup - va_term - 1) {
-                        va_wsize *= 2;
-                        va_next = va_counter + va_wsize;
-                        if (va_next != a.warmup - va_term - 1) {
-                            const int boundary = va_next + 2 * va_wsize;
-                            if (boundary >= a.warmup - va_term) va_next = a.warmup - va_term - 1;
-                        }
-                    }
-                    FORV {
-                        const double s2 = va_n > 1.0 ? wm2.v[i] / (va_n - 1.0) : 0.0;
-                        inv_e.v[i] = (va_n / (va_n + 5.0)) * s2 + 1e-3 * (5.0 / (va_n + 5.0));
-                        wmean.v[i] = 0.0; wm2.v[i] = 0.0;
-                    }
-                    va_n = 0;
-                    metric_updated = true;
-                }
-                ++va_counter;
-                if (t == a.warmup - 1 && !metric_updated) eps = exp(x_bar);     // complete_adaptation
-            } else {
-                acc_sum += accept; depth_sum += depth; ndiv += divergent; ++npost;
-                if ((t - a.warmup) % a.thin == 0) {
-                    if (wt == 0) {
-                        double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kept) * P;
-                        FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
-                    }
-                    ++kept;
-                }
-            }
-            ++t;
-            if (metric_updated) { ss_t = (uint32_t)t; ss_after_update = 1; do_begin_ss = true; }
-            else do_begin_transition = true;
-        }
-
-        if (do_begin_ss) {
-            if (eps == 0.0 || eps > 1e7 || isnan(eps)) {
-                if (ss_after_update) { da_mu = log(10.0 * eps); da_count = 0; s_bar = 0; x_bar = 0; }
-                do_begin_ss = false; do_begin_transition = true;
-            }
-            else { ss_trial = 0; ss_dir = 0; do_ss_setup = true; mode = MODE_SS; }
-        }
-        if (do_ss_setup) {
-            double s = 0.0;
-            FORV {
-                const int e = lane + 64 * i;
-                zp.v[i] = e < P ? rng_normal(key, ss_t, K_SSMOM, e, (uint32_t)ss_trial) / sqrt(inv_e.v[i]) : 0.0;
-                zq.v[i] = qs.v[i]; zg.v[i] = gs.v[i];
-                s += inv_e.v[i] * zp.v[i] * zp.v[i];
-            }
-            H0 = -lps + 0.5 * wave_sum(s);
-            eps_l = eps;
-        }
-        if (do_begin_transition) {
-            if (t >= a.iter) break;
-            double s = 0.0;
-            FORV {
-                const int e = lane + 64 * i;
-                pp.v[i] = e < P ? rng_normal(key, (uint32_t)t + toff, K_MOM, e, 0) / sqrt(inv_e.v[i]) : 0.0;
-                pq.v[i] = qs.v[i]; pg.v[i] = gs.v[i];
-                mq.v[i] = qs.v[i]; mg.v[i] = gs.v[i]; mp.v[i] = pp.v[i];
-                psp.v[i] = inv_e.v[i] * pp.v[i]; psm.v[i] = psp.v[i];
-                rho.v[i] = pp.v[i];
-                s += inv_e.v[i] * pp.v[i] * pp.v[i];
-            }
-            plp = lps; mlp = lps;
-            H0 = -lps + 0.5 * wave_sum(s);
-            lsw = 0.0; sum_metro = 0.0; depth = 0; nleap = 0; divergent = 0;
-            // direction / top-level uniforms of this transition in one Philox batch
-            u_dir = rng_uniform(key, (uint32_t)t + toff, lane < 16 ? K_DIR : K_TOP, (uint32_t)(lane & 15), 0);
-            mode = MODE_TREE;
-            do_begin_doubling = true;
-        }
-        if (do_begin_doubling) {
-            fwd = readlane_d(u_dir, depth) > 0.5 ? 1 : 0;
-            eps_l = fwd ? eps : -eps;
-            if (fwd) { FORV { zq.v[i] = pq.v[i]; zp.v[i] = pp.v[i]; zg.v[i] = pg.v[i]; } zlp = plp; }
-            else     { FORV { zq.v[i] = mq.v[i]; zp.v[i] = mp.v[i]; zg.v[i] = mg.v[i]; } zlp = mlp; }
-            leaf = 0; nleaf = 1 << depth;
-            lw_m = -INFINITY; lw_s = 0.0;
-            {
-                double u1, u2;
-                rng_u2(key, (uint32_t)t + toff, K_MERGE, (uint32_t)depth, (uint32_t)(lane >> 1), u1, u2);
-                gum = -log(-log((lane & 1) ? u2 : u1));
-            }
-        }
+#define EPX_CHAIN_EXIT break
+#define EPX_DBG_EXIT return
+#include "nuts_state_machine.inc"
+#undef EPX_CHAIN_EXIT
+#undef EPX_DBG_EXIT
     }
 
     // ------------------------------------------------------------- epilogue
