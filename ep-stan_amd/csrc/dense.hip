@@ -178,8 +178,8 @@ k_moments(MomentArgs a) {
         int nsl = T / d;                          // slices of the draw index
         if (nsl > d) nsl = d;
         if (nsl < 1) nsl = 1;
-        if (tid < d * nsl) {
-            const int i = tid % d, sl = tid / d;
+        for (int idx = tid; idx < d * nsl; idx += T) {       // d may exceed the block size
+            const int i = idx % d, sl = idx / d;
             double s = 0.0;
             for (int t = sl; t < S; t += nsl) s += X[(long)t * ss + (long)i * si];
             V[i + (size_t)sl * ld] = s;          // slices are combined in a fixed order below

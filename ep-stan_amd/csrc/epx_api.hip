@@ -395,29 +395,41 @@ static int ensure_sampler_buffers(epx_ctx *c, int chains, int nkeep) {
 
 static int pad_dp(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : -1; }
 
+// layout (out): 1 = one block per site (wave = chain, X resident in LDS), 2 = one block per
+// (site, chain) with 4 cooperating waves, 3 = streaming (chains in lock step, X through an LDS tile)
 static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts &o, NutsArgs &a,
-                           int *wpc_out, int *dp_out, int *nv_out) {
+                           int *wpc_out, int *dp_out, int *nv_out, int *layout_out) {
     const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
-    const int dp = pad_dp(c->D);
-    if (dp < 0) return fail("D = %d > 32: the streaming-X sampler variant is not built yet", c->D);
-    const int nv = (c->P + 63) / 64;
-    if (nv > 2) return fail("P = %d > 128 sampled coordinates not supported yet", c->P);
     memset(&a, 0, sizeof a);
     a.model = c->model; a.D = c->D; a.d = c->d; a.P = c->P; a.k0 = k0;
     a.chains = o.chains; a.iter = o.iter; a.warmup = o.warmup; a.thin = o.thin; a.nkeep = nkeep;
     a.max_depth = o.max_depth; a.init_mode = o.init;
     a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
-    // layout: one block per site when there are enough sites to fill the 256 CUs,
-    // else one block per (site, chain) with 4 cooperating waves
+    int nv = (c->P + 63) / 64;
+    int dp = pad_dp(c->D);
+    // resident layouts: enough sites to fill the 256 CUs -> one block per site, else one block
+    // per (site, chain) with 4 cooperating waves
     int layout = o.layout;
     if (layout == 0) layout = count >= 192 ? 1 : 2;
-    int wpc;
-    if (layout == 1) { wpc = 1; a.cpb = o.chains < 4 ? o.chains : 4; }
-    else { wpc = 4; a.cpb = 1; }
-    const size_t lds = nuts_lds_layout(a, wpc, dp, c->n_max);
-    if (lds > LDS_CAP)
-        return fail("site rows do not fit LDS (%zu B > %zu B): n_max=%d, D=%d; streaming variant not built yet",
-                    lds, LDS_CAP, c->n_max, c->D);
+    int wpc = 1;
+    bool resident = dp > 0 && nv <= 2 && layout != 3;
+    if (resident) {
+        if (layout == 1) { wpc = 1; a.cpb = o.chains < 4 ? o.chains : 4; }
+        else { wpc = 4; a.cpb = 1; }
+        const size_t lds = nuts_lds_layout(a, wpc, dp, c->n_max);
+        if (lds > LDS_CAP) resident = false;
+    }
+    if (!resident) {
+        // rows (or parameters) do not fit the resident kernel: stream X through an LDS tile
+        layout = 3;
+        if (c->D > 128) return fail("D = %d > 128 is not supported by the streaming sampler", c->D);
+        if (nv > 7) return fail("P = %d > 448 sampled coordinates not supported", c->P);
+        dp = c->D <= 64 ? 64 : 128;
+        a.cpb = 4; wpc = 1;
+        a.stack_in_lds = 0; a.om_in_lds = 0;
+        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp);
+        if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
+    }
     if (!a.stack_in_lds) {
         const size_t need = (size_t)count * o.chains * o.max_depth * (4 * nv * 64 + 2);
         if (c->stack_elems < need) {
@@ -427,8 +439,13 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         }
         a.stack = c->stack;
     }
-    *wpc_out = wpc; *dp_out = dp; *nv_out = nv;
+    *wpc_out = wpc; *dp_out = dp; *nv_out = nv; *layout_out = layout;
     return 0;
+}
+
+static int launch_sampler(const NutsArgs &a, int count, int wpc, int dp, int nv, int layout, hipStream_t stream) {
+    if (layout == 3) return launch_nuts_stream(a, count, dp, nv, stream);
+    return launch_nuts(a, count, wpc, dp, nv, stream);
 }
 
 static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, const epx_sampler_opts &o,
@@ -438,8 +455,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     if (ensure_sampler_buffers(c, o.chains, nkeep)) return -1;
     if (o.init == EPX_INIT_PREV && !c->has_last) return fail("init=PREV before any sampling call");
     NutsArgs a;
-    int wpc, dp, nv;
-    if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv)) return -1;
+    int wpc, dp, nv, layout;
+    if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv, &layout)) return -1;
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
     a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
 #ifdef EPX_STAMPS
@@ -457,7 +474,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
 #endif
     HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    int rc = launch_nuts(a, count, wpc, dp, nv, c->stream);
+    int rc = launch_sampler(a, count, wpc, dp, nv, layout, c->stream);
     if (rc != 0) return fail("NUTS kernel launch failed (%d: %s)", rc, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     RhatArgs ra;
@@ -625,15 +642,15 @@ int epx_logdensity_grad(epx_ctx *c, int k, const double *theta, double *lp, doub
     memset(&o, 0, sizeof o);
     o.chains = 1; o.iter = 2; o.warmup = 1; o.thin = 1; o.init = EPX_INIT_PREV; o.max_depth = 10; o.layout = 2;
     NutsArgs a;
-    int wpc, dp, nv;
-    if (build_nuts_args(c, k, 1, o, a, &wpc, &dp, &nv)) return -1;
+    int wpc, dp, nv, layout;
+    if (build_nuts_args(c, k, 1, o, a, &wpc, &dp, &nv, &layout)) return -1;
     const size_t P = c->P;
     HIPCHK(hipMemcpy(c->dbg + P + 1, theta, P * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(c->dbg_seed, 0, sizeof(int64_t)));
     a.seeds = c->dbg_seed;
     a.last = c->dbg + P + 1 - (size_t)k * P;      // kernel reads last[(k*chains + chain)*P], chains = 1
     a.dbg = c->dbg;
-    int rc = launch_nuts(a, 1, wpc, dp, nv, c->stream);
+    int rc = launch_sampler(a, 1, wpc, dp, nv, layout, c->stream);
     if (rc != 0) return fail("NUTS kernel launch failed (%d)", rc);
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<double> outv(P + 1);

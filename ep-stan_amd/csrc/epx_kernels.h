@@ -126,6 +126,11 @@ struct NutsArgs {
 int launch_nuts(const NutsArgs &a, int count, int wpc, int dp, int nv, hipStream_t stream);
 size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
 
+// streaming variant (nuts_stream.hip): one workgroup per site, chains in lock step, X through
+// a 64-row LDS tile; dpb in {64, 128}, nv = ceil(P/64) <= 7
+int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream);
+size_t nuts_stream_lds_bytes(int nv, int dpb);
+
 struct RhatArgs {
     int k0, chains, nkeep, P;
     const double *draws;          // K x chains x nkeep x P

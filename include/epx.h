@@ -54,7 +54,9 @@ typedef struct epx_sampler_opts {
     int32_t thin;        /* default 1 */
     int32_t init;        /* enum epx_init */
     int32_t max_depth;   /* Stan max_treedepth, default 10 */
-    int32_t layout;      /* 0 auto, 1 one block per site, 2 one block per (site,chain) */
+    int32_t layout;      /* 0 auto, 1 one block per site (rows resident in LDS), 2 one block per
+                            (site, chain), 3 streaming (rows through an LDS tile, chains in lock step;
+                            chosen automatically when the rows do not fit LDS or D > 32) */
     int32_t reserved;
 } epx_sampler_opts;
 

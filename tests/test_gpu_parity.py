@@ -510,12 +510,10 @@ def test_many_sites_batch_and_errors():
     for j, k in enumerate((0, 299, 599)):
         eng.sample_batch(seeds[k:k + 1], HipEngine.sampler_opts(chains=4, iter=20, layout=1), k0=k, count=1)
         np.testing.assert_array_equal(eng.get_draws(k, True), all_draws[j])
-    with pytest.raises(_lib.EpxError):                      # D > 32: streaming variant not built yet
-        HipEngine('m4b_sg', rng.randn(40, 40), np.zeros(40, dtype=int), np.array([0, 20, 40])).sample_batch(
-            np.array([1, 2]), opts)
-    with pytest.raises(_lib.EpxError):                      # rows of one site exceed LDS
-        HipEngine('m1b_sg', rng.randn(3000, 16), np.zeros(3000, dtype=int), np.array([0, 2999, 3000])
-                  ).sample_batch(np.array([1, 2]), opts)
+    with pytest.raises(_lib.EpxError):                      # D > 128: beyond the streaming variant
+        e2 = HipEngine('m1b_sg', rng.randn(40, 200), np.zeros(40, dtype=int), np.array([0, 20, 40]))
+        e2.set_global(np.eye(201), np.zeros(201)); e2.cavity_batch(QI)
+        e2.sample_batch(np.array([1, 2]), opts)
     with pytest.raises(_lib.EpxError):
         HipEngine('m1b_sg', X, np.full(K * n, 2), np.arange(K + 1) * n)      # y must be 0/1
     with pytest.raises(_lib.EpxError):
@@ -569,3 +567,79 @@ def test_ep_posterior_matches_cpu_path_within_monte_carlo_error():
     assert np.all(np.abs(np.diag(S_g) / np.diag(S_c1) - 1) < tol_v), tol_v
     # and EP actually learned something: the posterior is much tighter than the prior
     assert np.all(np.diag(S_g) < 0.8 * np.diag(np.linalg.inv(Q0)))
+
+
+# ------------------------------------------------------------------ streaming sampler (layout 3)
+@pytest.mark.parametrize('model,D,n', [('m4b_sg', 40, 150), ('m1b_sg', 64, 100), ('m3b_sg', 100, 257),
+                                       ('m2b_sg', 128, 64), ('m5b_sg', 33, 70), ('m4b_sg', 128, 2000)])
+def test_streaming_gradient_matches_oracle(model, D, n):
+    """Sites beyond the LDS-resident kernel (D > 32, up to config C5's D = 128, n_j = 2000):
+    the streaming kernel's log density and gradient equal the oracle's."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 300 + D, K=2)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    rng = np.random.RandomState(6)
+    for k in range(2):
+        theta = rng.randn(P) * 0.3
+        lp, g = eng.logdensity_grad(k, theta)
+        lo, hi = k_lim[k], k_lim[k + 1]
+        lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta)
+        assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o))
+        np.testing.assert_allclose(g, g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+
+
+@pytest.mark.parametrize('model,D,n,chains', [('m4b_sg', 8, 90, 4), ('m1b_sg', 16, 120, 3), ('m4b_sg', 40, 100, 4),
+                                              ('m3b_sg', 64, 80, 2), ('m4b_sg', 20, 300, 6)])
+def test_streaming_sampler_equals_resident_and_oracle(model, D, n, chains):
+    """Layout 3 (lock-step chains, tiled X) on shapes the resident layouts also handle, and on
+    D > 32: whole short site updates against the C oracle, chain by chain."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 40 + D, K=2, tight=300.0)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([21, 22], dtype=np.int64)
+    it = 44
+    opts = HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=3)
+    stats, ms = eng.sample_batch(seeds, opts)
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it)
+    cs = eng.get_chain_stats(chains)
+    nk = it // 2
+    n_full = 0
+    for k in range(2):
+        dev = eng.get_draws(k, True).reshape(chains, nk, P)
+        err = np.abs(dev - draws_o[k]).max(axis=2) / max(1.0, np.abs(draws_o[k]).max())
+        for c in range(chains):
+            assert np.all(err[c, :3] < 1e-3), (k, c, err[c, :3])
+            if np.all(err[c] < 1e-4):
+                n_full += 1
+                assert cs[k, c, 2] == st_o[k, c, 2] and cs[k, c, 3] == st_o[k, c, 3]
+    assert n_full >= (3 * 2 * chains) // 4, n_full
+
+
+def test_streaming_transitions_at_c5_site_size():
+    """One site of BASELINE config C5 (D = 128, n_j = 2000, m4b: d = 258, P = 387): single
+    transitions from typical-set points against the oracle (teacher forced), plus the moment and
+    cavity kernels at d = 258 (global-workspace path)."""
+    model, D, n = 'm4b_sg', 128, 2000
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 5, K=1, tight=20.0)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    assert (d, P) == (258, 387)
+    seeds = np.array([9], dtype=np.int64)
+    stats, ms = eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=30, init='random'))
+    cs = eng.get_chain_stats(4)
+    draws = eng.get_draws(0, True).reshape(1, 4, 15, P)
+    q0 = draws[:, :, -1, :]
+    eps = cs[:, :, 1]
+    inv_e = np.repeat(draws.reshape(1, -1, P).var(axis=1)[:, None, :], 4, axis=1) + 1e-3
+    out, st = eng.nuts_transitions(seeds, q0, eps, inv_e, nt=1, t_offset=3)
+    ref, st_o = no.nuts_transitions(model, X, y, k_lim, mu_dev, Om_dev, seeds, q0, eps, inv_e, nt=1, t_offset=3)
+    err = np.abs(out - ref).max(axis=(2, 3)) / np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+    same = st[:, :, 2] == st_o[:, :, 2]
+    assert np.sum(~same | (err > 1e-6)) <= 1, (err, st[:, :, 2], st_o[:, :, 2])
+    # moment stage + cavity at d = 258 against the NumPy oracle
+    eng.set_global(np.eye(d) * 3.0, np.zeros(d))
+    rng = np.random.RandomState(2)
+    samp = rng.randn(600, d, 1) * 0.5 + 0.1
+    flags = eng.moments_batch(np.asfortranarray(samp), 'sample')
+    dQ, dr = eng.get_site(DQI, 0)
+    dQ_o, dr_o, mt, scatter, ok = eo.tilted_moments(samp[:, :, 0], np.eye(d) * 3.0, np.zeros(d), 'sample')
+    assert flags[0] and ok
+    np.testing.assert_allclose(dQ, dQ_o, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(dr, dr_o, rtol=1e-8, atol=1e-8)
