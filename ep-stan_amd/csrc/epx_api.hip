@@ -44,6 +44,7 @@ struct epx_ctx {
     int64_t *k_lim_d;
     double *X;
     uint8_t *y;
+    int *y32;
     double *Q0, *r0, *Q, *r, *S, *m;
     double *Qi, *ri, *Qi2, *ri2, *dQi, *dri;
     double *cav_Om, *cav_mu;
@@ -163,8 +164,12 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
     HIPCHK(hipEventCreate(&c->ev1));
     const size_t K = K_local, d2 = (size_t)d * d;
     HIPCHK(dalloc(&c->k_lim_d, K + 1));
-    HIPCHK(dalloc(&c->X, (size_t)c->N * D));
+    // X carries a zeroed KiB behind the last row: the streaming sampler's row DMA reads full
+    // 128-column images
+    HIPCHK(dalloc(&c->X, (size_t)c->N * D + 128));
+    HIPCHK(hipMemset(c->X + (size_t)c->N * D, 0, 128 * sizeof(double)));
     HIPCHK(dalloc(&c->y, (size_t)c->N));
+    HIPCHK(dalloc(&c->y32, (size_t)c->N));
     HIPCHK(dalloc(&c->Q0, d2)); HIPCHK(dalloc(&c->r0, d));
     HIPCHK(dalloc(&c->Q, d2)); HIPCHK(dalloc(&c->r, d));
     HIPCHK(dalloc(&c->S, d2)); HIPCHK(dalloc(&c->m, d));
@@ -190,6 +195,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
             yb[i] = (uint8_t)y[i];
         }
         HIPCHK(hipMemcpy(c->y, yb.data(), yb.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->y32, y, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemset(c->Qi, 0, K * d2 * 8)); HIPCHK(hipMemset(c->ri, 0, K * d * 8));
     HIPCHK(hipMemset(c->Qi2, 0, K * d2 * 8)); HIPCHK(hipMemset(c->ri2, 0, K * d * 8));
@@ -204,7 +210,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->k_lim_d, c->X, c->y, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -404,7 +410,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     a.model = c->model; a.D = c->D; a.d = c->d; a.P = c->P; a.k0 = k0;
     a.chains = o.chains; a.iter = o.iter; a.warmup = o.warmup; a.thin = o.thin; a.nkeep = nkeep;
     a.max_depth = o.max_depth; a.init_mode = o.init;
-    a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
+    a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.y32 = c->y32; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
     int nv = (c->P + 63) / 64;
     int dp = pad_dp(c->D);
     // resident layouts: enough sites to fill the 256 CUs -> one block per site, else one block
@@ -427,11 +433,12 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         dp = c->D <= 64 ? 64 : 128;
         a.cpb = 4; wpc = 1;
         a.stack_in_lds = 0; a.om_in_lds = 0;
-        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp);
+        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d);
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {
-        const size_t need = (size_t)count * o.chains * o.max_depth * (4 * nv * 64 + 2);
+        const size_t need = layout == 3 ? (size_t)count * o.chains * nuts_stream_chain_doubles(nv, o.max_depth)
+                                        : (size_t)count * o.chains * o.max_depth * (4 * nv * 64 + 2);
         if (c->stack_elems < need) {
             if (c->stack) (void)hipFree(c->stack);
             HIPCHK(dalloc(&c->stack, need));

@@ -103,6 +103,7 @@ struct NutsArgs {
     const int64_t *k_lim;         // K+1 row limits
     const double *X;              // N x D row-major
     const uint8_t *y;             // N
+    const int *y32;               // N, the same responses as int32 (DMA granule of the streaming sampler)
     const double *cav_Om;         // K x d x d
     const double *cav_mu;         // K x d
     const int64_t *seeds;         // per site of the batch (index k - k0)
@@ -127,9 +128,11 @@ int launch_nuts(const NutsArgs &a, int count, int wpc, int dp, int nv, hipStream
 size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
 
 // streaming variant (nuts_stream.hip): one workgroup per site, chains in lock step, X through
-// a 64-row LDS tile; dpb in {64, 128}, nv = ceil(P/64) <= 7
+// an LDS-DMA ring; dpb in {64, 128}, nv = ceil(P/64) <= 7.  a.stack holds, per (site of the
+// batch, chain), nuts_stream_chain_doubles() doubles (tree stack + cold store).
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream);
-size_t nuts_stream_lds_bytes(int nv, int dpb);
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d);
+size_t nuts_stream_chain_doubles(int nv, int max_depth);
 
 struct RhatArgs {
     int k0, chains, nkeep, P;

@@ -1,0 +1,352 @@
+// Row streaming engine of the streaming sampler (nuts_stream.hip): one pass over a site's
+// rows per leapfrog, shared by the (up to 4) chains of the workgroup.  HBM-bound by design:
+// algorithmic traffic per pass = n*D*8 (X) + n*4 (y) bytes for 4 gradients.
+//
+//   * X travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into a ring
+//     of NSL slots of 16 rows; three tiles stay in flight across the raw s_barriers (counted
+//     s_waitcnt vmcnt, never 0 inside a pass), and the ring does not stop at leapfrog
+//     boundaries: the first three tiles of the next pass are in flight while the tree
+//     bookkeeping runs.
+//   * One DMA instruction writes 1 KiB of LDS linearly (wave-uniform base + lane*16), so the
+//     image of a row is unpadded; bank conflicts are avoided by permuting the 16-byte chunks
+//     of row r on the SOURCE side (slot s holds chunk s ^ r).
+//   * The two skinny products of the gradient, F = X B (n x D by D x 4 chains) and
+//     G = X' g (D x n by n x 4), run on v_mfma_f64_4x4x4f64 (4 blocks of 4x4x4: 16 rows or
+//     columns x 4 chains per instruction, every lane useful), with B in registers: per 16-row
+//     tile a wave issues DPB/8 + 4 ds_read_b64 and DPB/8 MFMA instead of several hundred
+//     LDS-fed FMAs.  The matrix pipe is nowhere near saturated; the point is issue slots.
+//   * Six waves with fixed roles and a software pipeline over tiles with ONE barrier per tile:
+//     in phase p the four chain waves do the forward product of tile p (wave = column
+//     quarter) and the backward product of tile p-2, wave 4 (loader) waits for tile p and
+//     issues the DMA of tile p+3, wave 5 evaluates the logistic terms of tile p-1 for all 4
+//     chains (lane = (row, chain)).
+//   * stream_pass is a real function call (noinline): inlined into the sampler kernel its
+//     loops inherit that kernel's register pressure and the compiler parks loop invariants in
+//     scratch -- a scratch reload is a VMEM operation, and one inside the loader's loop drains
+//     the whole DMA ring.  As a callee it is allocated on its own (about 100 VGPRs, no
+//     scratch).  All LDS accesses go through address_space(3) pointers built from byte
+//     offsets (generic pointers would turn into flat loads across the call boundary).
+// Rows beyond the site (last tile) are clamped to the last row and masked in the logistic
+// step; columns beyond D read whatever follows in memory (finite: the engine pads X with a
+// zeroed KiB) and meet zero coefficients.
+//
+// v_mfma_f64_4x4x4f64 operand layout (measured, scripts/probe/mfma_layout.hip):
+//   A[b][i][k] in lane 16k + 4b + i,  B[b][k][j] in lane 16k + 4b + j,  D[b][i][j] in lane 16i + 4b + j.
+#pragma once
+#include "epx_device.h"
+
+namespace epx {
+
+constexpr int TR = 16;          // rows per ring slot
+constexpr int NSL = 6;          // ring slots: 3 resident (backward, logistic, forward) + 3 in flight
+constexpr int NCH = 4;          // chain slots (waves 0..3) per workgroup
+constexpr int STREAM_WAVES = 6; // + loader (wave 4) + logistic (wave 5)
+constexpr int STREAM_THREADS = 64 * STREAM_WAVES;
+
+template <int DPB> struct StreamGeom {
+    static constexpr int CPR = DPB / 2;            // 16-byte chunks per row image
+    static constexpr int ROWB = DPB * 8;           // bytes per row image
+    static constexpr int RPI = 64 / CPR;           // rows per DMA instruction (1 KiB)
+    static constexpr int NI = TR / RPI;            // DMA instructions per tile
+    static constexpr int SLOTB = TR * ROWB;        // bytes per ring slot
+    static constexpr int G = NI + 1;               // VMEM operations of the loader wave per tile (+ the y piece)
+    static constexpr int DW = DPB / 4;             // columns per wave
+    static constexpr int KS = DW / 4;              // forward k-steps per wave
+    static constexpr int MB = DW / 16;             // backward 16-column groups per wave
+};
+
+// LDS-DMA pieces as inline asm: hipcc does not count them, so it inserts no vmcnt(0) before the
+// LDS reads of the ring (it does for the builtin); completion is counted by hand (wait_vm).
+// M0 = wave-uniform LDS destination, written in the statement that uses it.
+__device__ inline void glds16(const void *src, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+__device__ inline void glds4(const void *src, unsigned lds_off) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_off);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that leaves VMEM (the LDS-DMA ring) in flight
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------- LDS map
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+__device__ inline lds_f64 *lds_d(unsigned byte_off) { return reinterpret_cast<lds_f64 *>(byte_off); }
+__device__ inline lds_i32 *lds_i(unsigned byte_off) { return reinterpret_cast<lds_i32 *>(byte_off); }
+
+// byte offsets from the start of the engine's LDS block (the start of the dynamic segment)
+template <int DPB> struct StreamOffs {
+    using Gm = StreamGeom<DPB>;
+    static constexpr unsigned RING = 0;                                 // NSL slots of TR row images
+    static constexpr unsigned YRING = NSL * Gm::SLOTB;                  // NSL x TR responses (int32)
+    static constexpr unsigned BETA = YRING + NSL * TR * 4;              // DPB x 4 coefficients, [column][chain]
+    static constexpr unsigned PART = BETA + DPB * NCH * 8;              // 2 buffers x 4 waves x [chain][row] forward partials
+    static constexpr unsigned GS = PART + 2 * 4 * 64 * 8;               // 2 buffers x [chain][row] residuals
+    static constexpr unsigned GSUM = GS + 2 * 64 * 8;                   // DPB x 4 gradient wrt the coefficients, [column][chain]
+    static constexpr unsigned RED = GSUM + DPB * NCH * 8;               // 4 chains x {da, ll}
+    static constexpr unsigned ALPHA = RED + NCH * 2 * 8;                // 4 intercepts
+    static constexpr unsigned END = ALPHA + NCH * 8;
+};
+template <int DPB> constexpr int stream_lds_bytes() { return (int)StreamOffs<DPB>::END; }
+
+// what the sampler kernel touches directly (generic pointers into the same block)
+struct StreamLds {
+    double *beta_s, *Gs, *alpha_s;
+    template <int DPB> __device__ void carve(unsigned char *base) {
+        beta_s = reinterpret_cast<double *>(base + StreamOffs<DPB>::BETA);
+        Gs = reinterpret_cast<double *>(base + StreamOffs<DPB>::GSUM);
+        alpha_s = reinterpret_cast<double *>(base + StreamOffs<DPB>::ALPHA);
+    }
+};
+
+// ---------------------------------------------------------------------------------- loader
+// state of one pass (the sampler kernel keeps one per thread and hands its scalars to
+// stream_pass in registers -- a struct argument would travel through scratch memory, and the
+// callee's lazy loads of it put vmcnt(0) waits inside the loader's loop)
+template <int DPB> struct PassArgs {
+    const double *Xg;           // first row of the site
+    const int *yg;              // its responses (int32)
+    int n, D, ntile;
+    unsigned lds0;              // LDS byte address of the engine's block
+    int slot_f;                 // ring: slot of the next tile to consume
+    int slot_i;                 // ring: slot the next DMA goes to       (loader)
+    int t_i;                    // ring: site tile the next DMA fetches  (loader)
+    int wave, lane;
+    unsigned off[StreamGeom<DPB>::NI];   // loader: per-lane byte offsets of the pieces of a full tile
+};
+struct PassOut { double da, ll; int slot_f, slot_i, t_i; };
+
+template <int DPB>
+__device__ inline void loader_init(PassArgs<DPB> &pa, int lane) {
+    using Gm = StreamGeom<DPB>;
+    const int rl = lane / Gm::CPR, sl = lane % Gm::CPR;
+#pragma unroll
+    for (int q = 0; q < Gm::NI; ++q) {
+        const int r = q * Gm::RPI + rl;
+        pa.off[q] = (unsigned)(r * pa.D * 8 + (sl ^ (r & (Gm::CPR - 1))) * 16);
+    }
+}
+
+// DMA of tile `tt` of the site into ring slot `slot` (executed by the loader wave only)
+template <int DPB>
+__device__ inline void ring_issue(const PassArgs<DPB> &s, int tt, int slot, int lane) {
+    using Gm = StreamGeom<DPB>;
+    using Of = StreamOffs<DPB>;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(s.lds0 + Of::RING + slot * Gm::SLOTB);
+    if ((tt + 1) * TR <= s.n) {
+        // full tile: one scalar base + the precomputed lane offsets
+        const unsigned long long base = (unsigned long long)(s.Xg + (size_t)tt * TR * s.D);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const unsigned long long sbase = ((unsigned long long)bhi << 32) | blo;
+        unsigned keep;
+        if constexpr (Gm::NI == 16) {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %11, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %12, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %13, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %14, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %15, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %16, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %17, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %18, %2\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst), "s"(sbase), "v"(s.off[0]), "v"(s.off[1]), "v"(s.off[2]), "v"(s.off[3]), "v"(s.off[4]),
+                  "v"(s.off[5]), "v"(s.off[6]), "v"(s.off[7]), "v"(s.off[8]), "v"(s.off[9]), "v"(s.off[10]),
+                  "v"(s.off[11]), "v"(s.off[12]), "v"(s.off[13]), "v"(s.off[14]), "v"(s.off[15])
+                : "memory", "scc");
+        } else {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %2\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %2\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst), "s"(sbase), "v"(s.off[0]), "v"(s.off[1]), "v"(s.off[2]), "v"(s.off[3]), "v"(s.off[4]),
+                  "v"(s.off[5]), "v"(s.off[6]), "v"(s.off[7])
+                : "memory", "scc");
+        }
+    } else {
+        // ragged last tile: rows beyond the site are clamped to its last row
+        const int rl = lane / Gm::CPR, sl = lane % Gm::CPR;
+#pragma unroll
+        for (int q = 0; q < Gm::NI; ++q) {
+            const int r = q * Gm::RPI + rl;
+            const int c = sl ^ (r & (Gm::CPR - 1));
+            int row = tt * TR + r;
+            row = row < s.n ? row : s.n - 1;
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(s.Xg) + ((size_t)row * s.D + 2 * c) * 8;
+            glds16(src, dst + q * 1024);
+        }
+    }
+    {
+        int row = tt * TR + (lane & (TR - 1));
+        row = row < s.n ? row : s.n - 1;
+        if (lane < TR) glds4(s.yg + row, s.lds0 + Of::YRING + slot * TR * 4);
+    }
+}
+
+// Prime the ring: the first three tiles (loader wave; the site must have at least one row).
+template <int DPB>
+__device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
+    for (int i = 0; i < 3; ++i) {
+        ring_issue<DPB>(s, s.t_i, s.slot_i, lane);
+        s.t_i = s.t_i + 1 == s.ntile ? 0 : s.t_i + 1;
+        s.slot_i = s.slot_i + 1 == NSL ? 0 : s.slot_i + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------- one pass
+// All six waves call stream_pass once per leapfrog (same number of barriers on every path).
+// In: beta, alpha (LDS, published by a barrier before the call).  Out: GSUM (LDS; valid on
+// return, the pass ends with a barrier), and on chain wave c: da = sum of the residuals of
+// chain c, ll = its log likelihood; the new ring position.
+template <int DPB>
+__device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, const int *yg, int n, int D, int ntile,
+                                                             unsigned lds0, int slot_f0, int slot_i0, int t_i0,
+                                                             int wave_, int lane) {
+    using Gm = StreamGeom<DPB>;
+    using Of = StreamOffs<DPB>;
+    PassArgs<DPB> s;
+    s.Xg = Xg; s.yg = yg; s.n = n; s.D = D; s.ntile = ntile; s.lds0 = lds0;
+    s.slot_f = slot_f0; s.slot_i = slot_i0; s.t_i = t_i0; s.wave = wave_; s.lane = lane;
+    const int wave = __builtin_amdgcn_readfirstlane(s.wave);
+    if (wave == NCH) loader_init<DPB>(s, lane);
+    const int nt = __builtin_amdgcn_readfirstlane(s.ntile);
+    const int nrow = __builtin_amdgcn_readfirstlane(s.n);
+    const unsigned B0 = __builtin_amdgcn_readfirstlane(s.lds0);
+    const int l15 = lane & 15, lg = lane >> 4, l3 = lane & 3;
+    int slot_f = __builtin_amdgcn_readfirstlane(s.slot_f);      // slot of tile p
+    int slot_l = slot_f, slot_b = slot_f;                       // slots of tiles p-1 and p-2 (set as the pipe fills)
+    PassOut out;
+    out.da = 0.0; out.ll = 0.0; out.slot_i = s.slot_i; out.t_i = s.t_i;
+    if (wave < NCH) {
+        // ------------------------------------------------ chain waves: the two products
+        double bq[Gm::KS];                      // forward B operand: beta[k0 + lg][chain l3]
+#pragma unroll
+        for (int ks = 0; ks < Gm::KS; ++ks) bq[ks] = *lds_d(B0 + Of::BETA + ((wave * Gm::DW + 4 * ks + lg) * NCH + l3) * 8);
+        double acc[Gm::MB];
+#pragma unroll
+        for (int mb = 0; mb < Gm::MB; ++mb) acc[mb] = 0.0;
+        const int frow = 4 * (l15 >> 2) + lg;   // D lane of the forward product -> (row frow, chain l3)
+        for (int p = 0; p < nt + 2; ++p) {
+            lds_barrier();
+            const bool do_f = p < nt, do_b = p >= 2;
+            double a[Gm::KS], bb[4], aa[4 * Gm::MB];
+            if (do_f) {
+                const unsigned tile = B0 + Of::RING + slot_f * Gm::SLOTB + l15 * Gm::ROWB;
+#pragma unroll
+                for (int ks = 0; ks < Gm::KS; ++ks) {
+                    const int col = wave * Gm::DW + 4 * ks + lg;
+                    a[ks] = *lds_d(tile + (((col >> 1) ^ l15) & (Gm::CPR - 1)) * 16 + (col & 1) * 8);
+                }
+            }
+            if (do_b) {
+                const unsigned tile = B0 + Of::RING + slot_b * Gm::SLOTB;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int rk = 2 * ks + (lg >> 1) + 8 * (lg & 1);
+                    bb[ks] = *lds_d(B0 + Of::GS + ((p & 1) * 64 + l3 * 16 + rk) * 8);
+#pragma unroll
+                    for (int mb = 0; mb < Gm::MB; ++mb) {
+                        const int col = wave * Gm::DW + 16 * mb + l15;
+                        aa[ks * Gm::MB + mb] =
+                            *lds_d(tile + rk * Gm::ROWB + (((col >> 1) ^ rk) & (Gm::CPR - 1)) * 16 + (col & 1) * 8);
+                    }
+                }
+            }
+            if (do_f) {
+                double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+                for (int ks = 0; ks < Gm::KS; ks += 2) {
+                    f0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks], bq[ks], f0, 0, 0, 0);
+                    f1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks + 1], bq[ks + 1], f1, 0, 0, 0);
+                }
+                *lds_d(B0 + Of::PART + (((p & 1) * 4 + wave) * 64 + l3 * 16 + frow) * 8) = f0 + f1;
+            }
+            if (do_b) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int mb = 0; mb < Gm::MB; ++mb)
+                        acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[ks * Gm::MB + mb], bb[ks], acc[mb], 0, 0, 0);
+            }
+            slot_b = slot_l; slot_l = slot_f;
+            if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
+        }
+        // publish G[column][chain]
+#pragma unroll
+        for (int mb = 0; mb < Gm::MB; ++mb)
+            *lds_d(B0 + Of::GSUM + ((wave * Gm::DW + 16 * mb + 4 * (l15 >> 2) + lg) * NCH + l3) * 8) = acc[mb];
+    } else if (wave == NCH) {
+        // ------------------------------------------------ loader
+        int slot_i = __builtin_amdgcn_readfirstlane(s.slot_i), t_i = __builtin_amdgcn_readfirstlane(s.t_i);
+        for (int p = 0; p < nt + 2; ++p) {
+            if (p < nt) wait_vm<2 * Gm::G>();   // tile p has landed; tiles p+1, p+2 stay in flight
+            lds_barrier();
+            if (p < nt) {
+                ring_issue<DPB>(s, t_i, slot_i, lane);          // tile p+3 -> the slot of tile p-3
+                t_i = t_i + 1 == nt ? 0 : t_i + 1;
+                slot_i = slot_i + 1 == NSL ? 0 : slot_i + 1;
+                slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
+            }
+        }
+        out.slot_i = slot_i; out.t_i = t_i;
+    } else {
+        // ------------------------------------------------ logistic terms: lane = (row l15, chain lg)
+        double ll = 0.0, da = 0.0;
+        const double alpha_l = *lds_d(B0 + Of::ALPHA + lg * 8);
+        for (int p = 0; p < nt + 2; ++p) {
+            lds_barrier();
+            if (p >= 1 && p - 1 < nt) {
+                const int pb = (p - 1) & 1;
+                const int row = (p - 1) * TR + l15;
+                double f = alpha_l;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) f += *lds_d(B0 + Of::PART + ((pb * 4 + w) * 64 + lane) * 8);
+                double l = 0.0, g = 0.0;
+                if (row < nrow) logistic_terms(f, (double)*lds_i(B0 + Of::YRING + (slot_l * TR + l15) * 4), l, g);
+                ll += l; da += g;
+                *lds_d(B0 + Of::GS + (pb * 64 + lane) * 8) = g;
+            }
+            slot_b = slot_l; slot_l = slot_f;
+            if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
+        }
+        // da, ll: sum over the 16 rows of each lane group -> red[chain]
+        da += dpp_d<DPP_QUAD_XOR1>(da); ll += dpp_d<DPP_QUAD_XOR1>(ll);
+        da += dpp_d<DPP_QUAD_XOR2>(da); ll += dpp_d<DPP_QUAD_XOR2>(ll);
+        da += dpp_d<DPP_ROW_HALF_MIRROR>(da); ll += dpp_d<DPP_ROW_HALF_MIRROR>(ll);
+        da += dpp_d<DPP_ROW_MIRROR>(da); ll += dpp_d<DPP_ROW_MIRROR>(ll);
+        if (l15 == 0) { *lds_d(B0 + Of::RED + lg * 16) = da; *lds_d(B0 + Of::RED + lg * 16 + 8) = ll; }
+    }
+    out.slot_f = slot_f;
+    lds_barrier();
+    if (wave < NCH) { out.da = *lds_d(B0 + Of::RED + wave * 16); out.ll = *lds_d(B0 + Of::RED + wave * 16 + 8); }
+    return out;
+}
+template <int DPB>
+__device__ inline PassOut stream_pass(const PassArgs<DPB> &s) {
+    return stream_pass_impl<DPB>(s.Xg, s.yg, s.n, s.D, s.ntile, s.lds0, s.slot_f, s.slot_i, s.t_i, s.wave, s.lane);
+}
+
+}  // namespace epx

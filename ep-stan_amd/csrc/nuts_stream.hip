@@ -3,104 +3,144 @@
 //
 // Same algorithm as k_nuts (the tree bookkeeping / adaptation code is the shared include
 // nuts_state_machine.inc); what changes is the gradient, which is HBM-bound here
-// (0.5 flop per byte of X):
-//   * one workgroup = one site, wave c = chain c, and the (up to 4) chains advance in
-//     LOCK STEP: every loop iteration is one leapfrog of every chain, so the site's rows
-//     are streamed from HBM ONCE per leapfrog for all chains (n_j*D*8 bytes) instead of
-//     once per chain;
-//   * X goes through a 64-row LDS tile (register-staged prefetch of the next tile while the
-//     current one is consumed); per tile the 4 waves split the COLUMNS for the forward
-//     product F = X B (lane = row, 4 chains per lane) and for the backward product
-//     G += X' (y - sigmoid F) (lane = column, rows split over lane groups), and split the
-//     CHAINS for the logistic terms;
+// (0.5 flop per byte of X per chain):
+//   * one workgroup = one site; waves 0..3 = chains, advancing in LOCK STEP: every loop
+//     iteration is one leapfrog of every chain, so the site's rows are streamed from HBM ONCE
+//     per leapfrog for all chains (n_j*D*8 bytes) instead of once per chain; waves 4 and 5 are
+//     the loader and the logistic wave of the row streaming engine (epx_stream_tile.h: LDS-DMA
+//     ring, MFMA f64 skinny products, one barrier per 16-row tile);
 //   * the cavity term Omega (phi - mu) is one pass over Omega (d*d*8 bytes from HBM/L2) for
 //     all chains (thread = row of Omega);
-//   * per-chain vectors (P up to 448) stay in registers, element e in lane e%64, register e/64;
-//     the parameter transforms gather through LDS copies of q and exp(q).
-// Algorithmic HBM bytes per leapfrog of one site: n_j*D*8 + n_j + d*d*8 (X, y, Omega), for
+//   * per-chain vectors have up to 448 coordinates (element e in lane e%64, register e/64).
+//     Only the nine vectors touched on every leaf stay in registers; the thirteen that change
+//     once per subtree / transition (current sample, tree ends, rho, p-sharp of the ends,
+//     adaptation sums) live in a per-chain "cold store" in global memory (L2-resident,
+//     512-byte coalesced rows) -- 23 x 14 VGPRs would otherwise spill into scratch and pay a
+//     memory round trip in the middle of every bookkeeping step;
+//   * the parameter transforms gather through LDS copies of q and exp(q).
+// Algorithmic HBM bytes per leapfrog of one site: n_j*D*8 + n_j*4 + d*d*8 (X, y, Omega), for
 // min(chains, 4) gradients.
 #include "epx_device.h"
 #include "epx_kernels.h"
+#include "epx_stream_tile.h"
 
 namespace epx {
 
 template <int NV> struct VecS { double v[NV]; };
 #define FORV _Pragma("unroll") for (int i = 0; i < NV; ++i)
+// In-kernel cycle stamps exist only in the diagnostic build (-DEPX_STAMPS); its run time is
+// never quoted, only the shares of the segments (scripts/stamps_stream.py).
+#ifdef EPX_STAMPS
+#define STAMP(i)                                                                   \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+        tacc[i] += t_ - tprev; tprev = t_;                                         \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+#else
 #define STAMP(i) do { } while (0)
+#endif
+
+// cold-store vector: same `.v[i]` syntax as VecS, backed by global memory
+struct ColdRef {
+    double *p;
+    __device__ operator double() const { return *p; }
+    __device__ const ColdRef &operator=(double x) const { *p = x; return *this; }
+    __device__ const ColdRef &operator=(const ColdRef &o) const { const double x = *o.p; *p = x; return *this; }
+    __device__ const ColdRef &operator+=(double x) const { *p = *p + x; return *this; }
+};
+// b is wave-uniform (scalar registers), so every access is `saddr + lane*8 + immediate`
+struct ColdIdx { double *b; int lane; __device__ ColdRef operator[](int i) const { return ColdRef{b + (lane + 64 * i)}; } };
+struct ColdV { ColdIdx v; };
+enum { CV_QS, CV_GS, CV_PQ, CV_PP, CV_PG, CV_MQ, CV_MP, CV_MG, CV_RHO, CV_PSP, CV_PSM, CV_WMEAN, CV_WM2, CV_COUNT };
 
 enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 #define MODE_INIT SMODE_INIT
 #define MODE_SS SMODE_SS
 #define MODE_TREE SMODE_TREE
 
-constexpr int TR = 64;          // rows per LDS tile
-constexpr int NCH = 4;          // chain slots (waves) per workgroup
+constexpr int OM_UNROLL = 16;   // columns of Omega in flight per thread
 
 template <int NV, int DPB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(STREAM_THREADS)
 k_nuts_stream(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     using V = VecS<NV>;
-    constexpr int DW = DPB / 4;                 // columns per wave
-    constexpr int NH = 64 / DW;                 // lane groups over the rows in the backward pass
-    constexpr int XS = DPB + 1;                 // padded row stride of the tile (odd: conflict free)
     constexpr int SREC = 4 * NV * 64 + 2;       // per-level stack record (doubles)
     constexpr int PMAX = 64 * NV;
-    constexpr int NPRE = TR * DPB / 256;        // doubles of the next tile staged per thread
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
     const int wt = 0;                           // one wave per chain
+    const bool is_chain = wave < NCH;
     const int bps = (a.chains + NCH - 1) / NCH;
     const int sb = blockIdx.x / bps, cb = blockIdx.x % bps;
     const int k = a.k0 + sb;
-    const int chain = cb * NCH + wave;
-    const bool active = chain < a.chains;
+    const int chain = cb * NCH + (is_chain ? wave : 0);
+    const bool active = is_chain && chain < a.chains;
     const int D = a.D, d = a.d, P = a.P, model = a.model;
     const int64_t row0 = a.k_lim[k];
-    const int n = (int)(a.k_lim[k + 1] - row0);
-    const int ntile = (n + TR - 1) / TR;
 
-    // ---- LDS carve-up (doubles)
-    double *Xt = reinterpret_cast<double *>(smem);                 // TR x XS
-    double *beta_s = Xt + TR * XS;                                 // DPB x 4
-    double *part = beta_s + DPB * NCH;                             // 4 waves x 4 chains x TR
-    double *gs4 = part + 4 * NCH * TR;                             // TR x 4
-    double *Gs = gs4 + TR * NCH;                                   // DPB x 4
-    double *vs4 = Gs + DPB * NCH;                                  // d x 4 (padded to PMAX)
-    double *Ovs = vs4 + PMAX * NCH;                                // d x 4
-    double *q_s = Ovs + PMAX * NCH;                                // 4 x PMAX
+    // ---- LDS carve-up
+    StreamLds L;
+    L.template carve<DPB>(smem);
+    double *mu_s = reinterpret_cast<double *>(smem + stream_lds_bytes<DPB>());     // d (padded to even)
+    double *vs4 = mu_s + ((d + 1) & ~1);                           // d x 4: phi - mu, [e][chain]
+    double *Ovs = vs4 + d * NCH;                                   // d x 4: Omega (phi - mu)
+    double *q_s = Ovs + d * NCH;                                   // 4 x PMAX
     double *eq_s = q_s + NCH * PMAX;                               // 4 x PMAX
-    double *alpha_s = eq_s + NCH * PMAX;                           // 4 (+ pad)
-    int *sh_done = reinterpret_cast<int *>(alpha_s + 8);
+    int *sh_done = reinterpret_cast<int *>(eq_s + NCH * PMAX);
     if (tid == 0) *sh_done = 0;
+    for (int e = tid; e < d; e += STREAM_THREADS) mu_s[e] = a.cav_mu[(size_t)k * d + e];
 
-    const double *Xg = a.X + (size_t)row0 * D;
-    const uint8_t *yg = a.y + row0;
+    PassArgs<DPB> site;
+    site.Xg = a.X + (size_t)row0 * D; site.yg = a.y32 + row0;
+    site.n = (int)(a.k_lim[k + 1] - row0); site.D = D; site.ntile = (site.n + TR - 1) / TR;
+    site.lds0 = (unsigned)(size_t)smem; site.slot_f = 0; site.slot_i = 0; site.t_i = 0;
+    site.wave = wave; site.lane = lane0;
+    if (wave == NCH) { loader_init<DPB>(site, lane0); ring_prime<DPB>(site, lane0); }
+
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
-    double *stk_g = a.stack + ((size_t)sb * a.chains + (active ? chain : 0)) * a.max_depth * SREC;
+    const size_t chain_slot = (size_t)sb * a.chains + (active ? chain : 0);
+    // wave-uniform base pointers (held in scalar registers; lanes add lane*8)
+    auto uniform_ptr = [](double *p) -> double * {
+        const unsigned long long u = (unsigned long long)p;
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (double *)(((unsigned long long)hi32 << 32) | lo32);
+    };
+    double *stk_g = uniform_ptr(a.stack + chain_slot * ((size_t)a.max_depth * SREC + (size_t)CV_COUNT * PMAX));
+    double *cold = stk_g + (size_t)a.max_depth * SREC;
+#ifdef EPX_EXP_NOSTK
+    auto ld_stk = [&](int off) -> double { return 1e-3 * off; };
+    auto st_stk = [&](int off, double v) { };
+#else
     auto ld_stk = [&](int off) -> double { return stk_g[off]; };
     auto st_stk = [&](int off, double v) { stk_g[off] = v; };
+#endif
 
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
 
     // ------------------------------------------------------------- state (as in k_nuts)
-    V mu, inv_e, qs, gs, zq, zp, zg, pq, pp, pg, mq, mp, mg, rho, psp, psm;
-    V n_rho, n_psl, n_pq, n_pg, psr, wmean, wm2;
-    double lps = 0, zlp = 0, plp = 0, mlp = 0, n_key = 0, n_plp = 0;
+    V inv_e, zq, zp, zg;                                                // registers, live across leapfrogs
+    ColdV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;    // cold store
+    auto bind = [&](ColdV &x, int which, int ln) { x.v.b = cold + which * PMAX; x.v.lane = ln; };
+#define EPX_BIND_COLD(ln)                                                                              \
+    bind(qs, CV_QS, ln); bind(gs, CV_GS, ln); bind(pq, CV_PQ, ln); bind(pp, CV_PP, ln); bind(pg, CV_PG, ln); \
+    bind(mq, CV_MQ, ln); bind(mp, CV_MP, ln); bind(mg, CV_MG, ln); bind(rho, CV_RHO, ln);                 \
+    bind(psp, CV_PSP, ln); bind(psm, CV_PSM, ln); bind(wmean, CV_WMEAN, ln); bind(wm2, CV_WM2, ln)
+    EPX_BIND_COLD(lane0);
+    double lps = 0, zlp = 0, plp = 0, mlp = 0;
     FORV {
-        const int e = lane + 64 * i;
-        mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
         inv_e.v[i] = 1.0;
-        wmean.v[i] = 0.0; wm2.v[i] = 0.0;
-        gs.v[i] = 0; zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
-        mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
-        n_rho.v[i] = 0; n_psl.v[i] = 0; n_pq.v[i] = 0; n_pg.v[i] = 0; psr.v[i] = 0;
+        zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0;
     }
     if (active) {
         const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV {
-            const int e = lane + 64 * i;
+            const int e = lane0 + 64 * i;
             double q0 = 0.0;
             if (e < P) {
                 if (a.init_mode == 2) q0 = lastp[e];
@@ -110,9 +150,10 @@ k_nuts_stream(NutsArgs a) {
                     q0 = -2.0 + 4.0 * ((e & 1) ? u2 : u1);
                 }
             }
-            qs.v[i] = q0;
+            zq.v[i] = q0;
+            qs.v[i] = q0; wmean.v[i] = 0.0; wm2.v[i] = 0.0;
         }
-    } else { FORV qs.v[i] = 0.0; }
+    }
     const double DELTA = 0.8, GAMMA = 0.05, T0 = 10.0, KAPPA = 0.75, LOG08 = -0.2231435513142097558;
     double eps = 1.0, da_mu = log(10.0), s_bar = 0, x_bar = 0, da_count = 0;
     int va_init_buf = 75, va_term = 50, va_base = 25;
@@ -132,19 +173,18 @@ k_nuts_stream(NutsArgs a) {
     double u_dir = 0.0, gum = 0.0;
     double dhb = 0.0, lw_m = -INFINITY, lw_s = 0.0;
 
-    FORV { zq.v[i] = qs.v[i]; }
     const bool teacher = a.eps_in != nullptr;
     if (teacher && active) {
         eps = a.eps_in[(size_t)sb * a.chains + chain];
         if (a.inv_e_in) {
             const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * P;
-            FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
+            FORV { const int e = lane0 + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
     auto flush_dh = [&](int cnt) {
-        const bool ok = lane < cnt;
+        const bool ok = lane0 < cnt;
         const double dh = ok ? dhb : -INFINITY;
         const double mb = wave_max(dh);
         const double m_new = fmax(lw_m, mb);
@@ -160,43 +200,35 @@ k_nuts_stream(NutsArgs a) {
         sum_metro += me;
     };
 
-    // stage tile `tt` of X from HBM into registers (zero padded rows / columns)
-    auto load_tile = [&](int tt, double *pre) {
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * 256 + tid;                  // element of the TR x DPB tile
-            const int r = idx / DPB, c = idx - r * DPB;
-            const int row = tt * TR + r;
-            pre[u] = (row < n && c < D) ? Xg[(size_t)row * D + c] : 0.0;
-        }
-    };
-    auto store_tile = [&](const double *pre) {
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int idx = u * 256 + tid;
-            const int r = idx / DPB, c = idx - r * DPB;
-            Xt[r * XS + c] = pre[u];
-        }
-    };
-
-    int finished = active ? 0 : 1, counted = 0;
+    int finished = active ? 0 : 1, counted = is_chain ? 0 : 1;
+#ifdef EPX_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        STAMP(4);
+        // `lane` is re-derived through an opaque move every iteration: otherwise the compiler
+        // hoists all per-element index arithmetic of the loop body (7 elements x dozens of
+        // indices and predicates) out of the loop and spills it
+        // (and again after the row pass, so that nothing index-like stays live across it)
+        double kin = 0.0, sa = 0, eta = 0, sb2 = 0, lpt = 0.0, ll = 0.0, da = 0.0;
+        {
+        int lane_v = lane0;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
         // ---- lock step: leave only when every chain of the workgroup is done
         if (finished && !counted) { if (lane == 0) atomicAdd(sh_done, 1); counted = 1; }
-        __syncthreads();
+        lds_barrier();
         if (*sh_done >= NCH) break;
+        STAMP(5);
 
         // =================================================== leapfrog, all chains together
-        double kin = 0.0;
-        FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
-        FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
-        V eq;
-        FORV eq.v[i] = exp_d(zq.v[i]);
-        double sa = 0, eta = 0, sb2 = 0;
-        {
+        if (is_chain) {
+            FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
+            FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
             // ---- step A (wave = chain): publish q, exp(q); alpha, beta, phi - mu
             double *qc = q_s + wave * PMAX, *eqc = eq_s + wave * PMAX;
-            FORV { qc[lane + 64 * i] = zq.v[i]; eqc[lane + 64 * i] = eq.v[i]; }
+            FORV { qc[lane + 64 * i] = zq.v[i]; eqc[lane + 64 * i] = exp_d(zq.v[i]); }
             double alpha;
             if (model == 0) { sa = eqc[0]; eta = qc[d]; alpha = eta * sa; }
             else if (model == 1) { sa = eqc[0]; sb2 = eqc[1]; eta = qc[2]; alpha = eta * sa; }
@@ -212,114 +244,70 @@ k_nuts_stream(NutsArgs a) {
                     else if (model == 2) bj = qc[d + 1 + j] * eqc[1 + j];
                     else bj = qc[2 + j] + qc[d + 1 + j] * eqc[2 + D + j];
                 }
-                beta_s[j * NCH + wave] = bj;
+                L.beta_s[j * NCH + wave] = bj;
             }
-            FORV { const int e = lane + 64 * i; if (e < d) vs4[e * NCH + wave] = zq.v[i] - mu.v[i]; }
-            if (lane == 0) alpha_s[wave] = alpha;
+            FORV { const int e = lane + 64 * i; if (e < d) vs4[e * NCH + wave] = zq.v[i] - mu_s[e]; }
+            if (lane == 0) L.alpha_s[wave] = alpha;
         }
-        double ll = 0.0, da = 0.0;
+        STAMP(0);
+        lds_barrier();
         {
-            // ---- step B: stream the rows once for all chains
-            double acc[NCH] = {0.0, 0.0, 0.0, 0.0};
-            double pre[NPRE];
-            load_tile(0, pre);
-            store_tile(pre);
-            __syncthreads();
-            const double alpha_c = alpha_s[wave];
-            for (int tt = 0; tt < ntile; ++tt) {
-                if (tt + 1 < ntile) load_tile(tt + 1, pre);            // HBM loads in flight during the tile
-                // forward partials: this wave's columns, lane = row, 4 chains per lane
-                {
-                    double pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
-                    const double *xr = Xt + lane * XS + wave * DW;
-                    const double *bp = beta_s + (wave * DW) * NCH;
-#pragma unroll 8
-                    for (int dd = 0; dd < DW; ++dd) {
-                        const double x = xr[dd];
-                        const double2 b01 = *reinterpret_cast<const double2 *>(bp + dd * NCH);
-                        const double2 b23 = *reinterpret_cast<const double2 *>(bp + dd * NCH + 2);
-                        pf0 = fma(x, b01.x, pf0); pf1 = fma(x, b01.y, pf1);
-                        pf2 = fma(x, b23.x, pf2); pf3 = fma(x, b23.y, pf3);
-                    }
-                    double *pw = part + (wave * NCH) * TR + lane;
-                    pw[0 * TR] = pf0; pw[1 * TR] = pf1; pw[2 * TR] = pf2; pw[3 * TR] = pf3;
-                }
-                __syncthreads();
-                // logistic terms: this wave's chain, lane = row
-                {
-                    const int row = tt * TR + lane;
-                    double f = alpha_c;
+            // ---- Omega (phi - mu) for all chains in one pass over Omega (thread = row)
+            if (tid < d) {
+                double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+                const double *omp = Om_g + tid;
+                int j = 0;
+                for (; j + OM_UNROLL <= d; j += OM_UNROLL) {
+                    double om[OM_UNROLL];
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) f += part[(w * NCH + wave) * TR + lane];
-                    double l = 0.0, g = 0.0;
-                    if (row < n) logistic_terms(f, (double)yg[row], l, g);
-                    ll += l; da += g;
-                    gs4[lane * NCH + wave] = g;
-                }
-                __syncthreads();
-                // backward: this wave's columns, lane = (column, row group), 4 chains per lane
-                {
-                    const int dl = lane % DW, h = lane / DW;
-                    const double *xc = Xt + wave * DW + dl;
-#pragma unroll 4
-                    for (int r = h; r < TR; r += NH) {
-                        const double x = xc[r * XS];
-                        const double2 g01 = *reinterpret_cast<const double2 *>(gs4 + r * NCH);
-                        const double2 g23 = *reinterpret_cast<const double2 *>(gs4 + r * NCH + 2);
-                        acc[0] = fma(x, g01.x, acc[0]); acc[1] = fma(x, g01.y, acc[1]);
-                        acc[2] = fma(x, g23.x, acc[2]); acc[3] = fma(x, g23.y, acc[3]);
+                    for (int u = 0; u < OM_UNROLL; ++u) om[u] = omp[(size_t)(j + u) * d];
+#pragma unroll
+                    for (int u = 0; u < OM_UNROLL; ++u) {
+                        const double2 v01 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH);
+                        const double2 v23 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH + 2);
+                        o0 = fma(om[u], v01.x, o0); o1 = fma(om[u], v01.y, o1);
+                        o2 = fma(om[u], v23.x, o2); o3 = fma(om[u], v23.y, o3);
                     }
                 }
-                __syncthreads();
-                if (tt + 1 < ntile) { store_tile(pre); __syncthreads(); }
+                for (; j < d; ++j) {
+                    const double om = omp[(size_t)j * d];
+                    o0 = fma(om, vs4[j * NCH], o0); o1 = fma(om, vs4[j * NCH + 1], o1);
+                    o2 = fma(om, vs4[j * NCH + 2], o2); o3 = fma(om, vs4[j * NCH + 3], o3);
+                }
+                *reinterpret_cast<double2 *>(Ovs + tid * NCH) = make_double2(o0, o1);
+                *reinterpret_cast<double2 *>(Ovs + tid * NCH + 2) = make_double2(o2, o3);
             }
-            // fold the row groups, publish G[column][chain]
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if constexpr (DW <= 16) acc[c] += partner_d<4>(acc[c], lane);
-                acc[c] += partner_d<5>(acc[c], lane);
+        }
+        lds_barrier();
+        STAMP(1);
+        if (is_chain) {
+            // cavity part of the gradient and of lp
+            FORV {
+                const int e = lane + 64 * i;
+                double g = 0.0;
+                if (e < d) {
+                    const double ov = Ovs[e * NCH + wave];
+                    g = -ov; lpt += -0.5 * vs4[e * NCH + wave] * ov;
+                }
+                zg.v[i] = g;
             }
-            if (lane < DW) {
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) Gs[(wave * DW + lane) * NCH + c] = acc[c];
-            }
-            wave_sum2(da, ll);
         }
         {
-            // ---- step C: Omega (phi - mu) for all chains in one pass over Omega (thread = row)
-#pragma unroll
-            for (int rr = 0; rr < (PMAX + 255) / 256; ++rr) {
-                const int irow = tid + 256 * rr;
-                if (irow < d) {
-                    double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-                    int j = 0;
-                    for (; j + 4 <= d; j += 4) {
-                        double om[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) om[u] = Om_g[(size_t)(j + u) * d + irow];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const double2 v01 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH);
-                            const double2 v23 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH + 2);
-                            o0 = fma(om[u], v01.x, o0); o1 = fma(om[u], v01.y, o1);
-                            o2 = fma(om[u], v23.x, o2); o3 = fma(om[u], v23.y, o3);
-                        }
-                    }
-                    for (; j < d; ++j) {
-                        const double om = Om_g[(size_t)j * d + irow];
-                        o0 = fma(om, vs4[j * NCH], o0); o1 = fma(om, vs4[j * NCH + 1], o1);
-                        o2 = fma(om, vs4[j * NCH + 2], o2); o3 = fma(om, vs4[j * NCH + 3], o3);
-                    }
-                    Ovs[irow * NCH + 0] = o0; Ovs[irow * NCH + 1] = o1;
-                    Ovs[irow * NCH + 2] = o2; Ovs[irow * NCH + 3] = o3;
-                }
-            }
+            const PassOut po = stream_pass<DPB>(site);
+            site.slot_f = po.slot_f; site.slot_i = po.slot_i; site.t_i = po.t_i;
+            da = po.da; ll = po.ll;
         }
-        __syncthreads();
+        }
+        STAMP(2);
+        if (!is_chain) continue;
+        int lane_w = lane0;
+        asm volatile("" : "+v"(lane_w));
+        const int lane = lane_w;
+        EPX_BIND_COLD(lane);
         {
             // ---- step D (wave = chain): lp and the chain rule back to (phi, eta, etb)
             const double *qc = q_s + wave * PMAX, *eqc = eq_s + wave * PMAX;
-            auto dbat = [&](int j) { return (j >= 0 && j < D) ? Gs[j * NCH + wave] : 0.0; };
+            auto dbat = [&](int j) { return (j >= 0 && j < D) ? L.Gs[j * NCH + wave] : 0.0; };
             auto gq = [&](int e) { return (e >= 0 && e < P) ? qc[e] : 0.0; };
             auto geq = [&](int e) { return (e >= 0 && e < P) ? eqc[e] : 0.0; };
             double dot = 0.0;
@@ -328,15 +316,11 @@ k_nuts_stream(NutsArgs a) {
                 FORV { const int e = lane + 64 * i; if (e >= 3 && e < P) tsum += dbat(e - 3) * zq.v[i]; }
                 dot = wave_sum(tsum);
             }
-            double lpt = 0.0;
             FORV {
                 const int e = lane + 64 * i;
                 const double q = zq.v[i];
-                double g = 0.0;
-                if (e < d) {
-                    const double ov = Ovs[e * NCH + wave];
-                    g = -ov; lpt += -0.5 * (q - mu.v[i]) * ov;
-                } else if (e < P) lpt -= laplace ? fabs(q) : 0.5 * q * q;
+                double g = zg.v[i];                 // cavity part (elements < d), 0 beyond
+                if (e >= d && e < P) lpt -= laplace ? fabs(q) : 0.5 * q * q;
                 const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;
                 if (model == 0) {
                     if (e == 0) g += da * eta * sa;
@@ -351,7 +335,7 @@ k_nuts_stream(NutsArgs a) {
                     const int j = e <= D ? e - 1 : e - d - 1;
                     const double db = dbat(j);
                     if (e == 0) g += da * eta * sa;
-                    else if (e <= D) g += db * gq(d + 1 + j) * eq.v[i];
+                    else if (e <= D) g += db * gq(d + 1 + j) * eqc[e];
                     else if (e == d) g = da * sa - pr;
                     else if (e < P) g = db * geq(1 + j) - pr;
                 } else {
@@ -360,7 +344,7 @@ k_nuts_stream(NutsArgs a) {
                     if (e == 0) g += da;
                     else if (e == 1) g += da * eta * sa;
                     else if (e < 2 + D) g += db;
-                    else if (e < d) g += db * gq(d + 1 + j) * eq.v[i];
+                    else if (e < d) g += db * gq(d + 1 + j) * eqc[e];
                     else if (e == d) g = da * sa - pr;
                     else if (e < P) g = db * geq(2 + D + j) - pr;
                 }
@@ -372,27 +356,39 @@ k_nuts_stream(NutsArgs a) {
             zlp = lpt + ll;
             kin = 0.5 * ks;
         }
+        STAMP(3);
         if (finished) continue;          // idle chain slots only take part in the shared work
         ngrad += 1.0;
 
+        // the new-subtree vectors never outlive one iteration (a leaf is merged, then parked on
+        // the stack or consumed), so they are iteration-local: nothing to keep across the row pass
+        V n_rho, n_psl, n_pq, n_pg, psr;
+        double n_key = 0, n_plp = 0;
 #define EPX_CHAIN_EXIT { finished = 1; eps_l = 0.0; continue; }
 #define EPX_DBG_EXIT { finished = 1; eps_l = 0.0; continue; }
 #include "nuts_state_machine.inc"
 #undef EPX_CHAIN_EXIT
 #undef EPX_DBG_EXIT
     }
+    if (wave == NCH) wait_vm<0>();       // drain the prefetched tiles before the LDS goes away
 
+#ifdef EPX_STAMPS
+    if (a.stamps && wave == 0 && lane0 == 0) {
+        for (int i = 0; i < 7; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
+        a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)ngrad;
+    }
+#endif
     // ------------------------------------------------------------- epilogue
     if (active && !a.dbg) {
         double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
-        FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
+        FORV { const int e = lane0 + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
         if (failed) {
             for (int kk = 0; kk < a.nkeep; ++kk) {
                 double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * P;
-                FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
+                FORV { const int e = lane0 + 64 * i; if (e < P) dst[e] = qs.v[i]; }
             }
         }
-        if (lane == 0) {
+        if (lane0 == 0) {
             double *st = a.chain_stats + ((size_t)k * a.chains + chain) * ST_COUNT;
             st[ST_STEPSIZE_MEAN] = a.iter > 0 && !failed ? eps_sum / a.iter : 0.0;
             st[ST_STEPSIZE_FINAL] = eps;
@@ -407,11 +403,15 @@ k_nuts_stream(NutsArgs a) {
 }
 
 // LDS bytes of the streaming kernel
-size_t nuts_stream_lds_bytes(int nv, int dpb) {
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d) {
     const size_t pmax = 64 * (size_t)nv;
-    size_t dbl = (size_t)TR * (dpb + 1) + (size_t)dpb * NCH + 4 * NCH * TR + (size_t)TR * NCH + (size_t)dpb * NCH
-                 + 2 * pmax * NCH + 2 * NCH * pmax + 8 + 2;
-    return dbl * 8;
+    const size_t eng = dpb == 64 ? stream_lds_bytes<64>() : stream_lds_bytes<128>();
+    const size_t dbl = (size_t)((d + 1) & ~1) + 2 * (size_t)d * NCH + 2 * NCH * pmax + 2;
+    return eng + dbl * 8;
+}
+// doubles of global memory per chain: tree stack + cold store
+size_t nuts_stream_chain_doubles(int nv, int max_depth) {
+    return (size_t)max_depth * (4 * (size_t)nv * 64 + 2) + (size_t)CV_COUNT * 64 * nv;
 }
 
 template <int NV, int DPB>
@@ -420,7 +420,7 @@ static int launch_stream_one(const NutsArgs &a, int nblocks, size_t lds, hipStre
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(STREAM_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -438,11 +438,11 @@ static int launch_stream_nv(const NutsArgs &a, int nblocks, int nv, size_t lds, 
     return -1;
 }
 
-// count sites; dpb in {64, 128}; nv = ceil(P / 64) <= 7; the tree stack lives in a.stack
+// count sites; dpb in {64, 128}; nv = ceil(P / 64) <= 7; tree stack and cold store live in a.stack
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream) {
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
-    const size_t lds = nuts_stream_lds_bytes(nv, dpb);
+    const size_t lds = nuts_stream_lds_bytes(nv, dpb, a.d);
     if (dpb == 64) return launch_stream_nv<64>(a, nblocks, nv, lds, stream);
     if (dpb == 128) return launch_stream_nv<128>(a, nblocks, nv, lds, stream);
     return -1;

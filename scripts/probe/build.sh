@@ -1,0 +1,8 @@
+#!/bin/bash
+# Builds the stand-alone probes of the row streaming engine into variants/ (git-ignored).
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p variants
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iep-stan_amd/csrc scripts/probe/stream_probe.hip -o variants/stream_probe
+hipcc --offload-arch=gfx950 -O2 scripts/probe/mfma_layout.hip -o variants/mfma_layout
+echo "built variants/stream_probe variants/mfma_layout"
