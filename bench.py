@@ -27,10 +27,15 @@ FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (AMD spec; D
 HBM_PEAK_GBS = 8000.0
 
 
-def workload(J, D, n, model):
+def workload(J, D, n, model, cor_input=True):
     from epstan_amd import models
     mod = models.MODELS[model](J, D, n)
-    data = mod.simulate_data(Sigma_x='rand', rng=100)          # seed_data=100 (fit.py:157)
+    if cor_input:
+        data = mod.simulate_data(Sigma_x='rand', rng=100)      # seed_data=100, cor_input=True (fit.py:157, 235-238)
+    else:
+        # fit.py's cor_input=False branch; the random vine correlation matrix of the reference
+        # (common.py:33-78) is numerically not positive definite from D ~ 120 on
+        data = mod.simulate_data(rng=100)
     _, _, Q0, r0 = mod.get_prior()
     return mod, data, Q0, r0
 
@@ -71,6 +76,7 @@ def main():
     ap.add_argument('--siter', type=int, default=200)
     ap.add_argument('--prec-estim', default='sample')
     ap.add_argument('--layout', type=int, default=0)
+    ap.add_argument('--cor-input', type=int, default=1, help='0: uncorrelated covariates (fit.py cor_input=False)')
     ap.add_argument('--cpu-sites', type=int, default=32, help='0 disables the cpu_baseline leg')
     ap.add_argument('--cpu-threads', type=int, default=0)
     args = ap.parse_args()
@@ -94,7 +100,7 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
     J = args.sites * world
-    mod, data, Q0, r0 = workload(J, args.D, args.n, args.model)
+    mod, data, Q0, r0 = workload(J, args.D, args.n, args.model, bool(args.cor_input))
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
                chains=args.chains, iter=args.siter, prec_estim=args.prec_estim,
                df0=models.default_df0(J), comm=comm, device=local_rank, layout=args.layout,
@@ -146,6 +152,36 @@ def main():
             == (64, 16, 200, 'm4b', 4, 200)):
         # measured separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
         traffic = json.load(open(pmc))['hbm_bytes_per_launch_corrected']
+    roof = {'kernel': 'k_nuts (sampler)', 'bound': 'mfma', 'achieved': achieved_tf,
+            'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / FP64_PEAK_TFLOPS,
+            'traffic': traffic,
+            'note': 'FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
+                    'duration of the sampler launch; X is LDS resident, so HBM is not the bound: '
+                    'hbm_frac below',
+            'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
+            'hbm_algorithmic_bytes': hbm_alg,
+            'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}
+    if M.engine.last_layout() == 3:
+        # streaming sampler: the site rows (and the cavity precision) come from HBM once per
+        # leapfrog of a workgroup's chains in lock step -> the HBM roofline is the one that binds
+        passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
+        B_pass = n_rows * args.D * 8 + n_rows * 4 + M.dphi**2 * 8     # X, y (int32), Omega
+        hbm_alg = float(passes.mean()) * B_pass
+        gbs = hbm_alg / t_kernel / 1e9
+        tr = None
+        pmc3 = os.path.join(ROOT, 'profiles', 'r01_stream_pmc_hbm.json')
+        if os.path.exists(pmc3):
+            pj = json.load(open(pmc3))
+            if pj.get('workload') == [args.sites, args.D, args.n, args.model, args.chains, args.siter]:
+                tr = pj['hbm_bytes_per_launch_corrected']
+        roof = {'kernel': 'k_nuts_stream (sampler)', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr,
+                'note': 'algorithmic bytes = row passes x (n D 8 + n 4 + d^2 8) over the HIP-event duration '
+                        'of the sampler launch; includes the tail where few sites are still sampling',
+                'launch_ms': float(ms.mean()), 'row_passes_per_launch': float(passes.mean()),
+                'gradients_per_launch': float(ngrad.mean()),
+                'passes_max_over_mean_site': float(np.mean([p.max() / p.mean() for p in M.pass_log[n_launch0:]])),
+                'fp64_tflops': achieved_tf}
     out = {
         'metric': 'site-updates/sec', 'value': J * args.steps / tmax, 'unit': 'site-updates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -153,19 +189,12 @@ def main():
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'ep_iters_per_sec': args.steps / tmax,
         'config': {'workload': 'hierarchical logistic regression %s, J=%d sites (=%d/GPU), D=%d, n_j=%d, '
-                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)'
+                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s'
                                % (args.model, J, args.sites, args.D, args.n, args.chains, args.siter,
-                                  args.chains * (args.siter - args.siter // 2), args.prec_estim),
+                                  args.chains * (args.siter - args.siter // 2), args.prec_estim,
+                                  '' if args.cor_input else ', uncorrelated covariates'),
                    'parallelism': 'sites sharded over %d GPU(s), 1 all-reduce/iter' % world},
-        'roofline': {'kernel': 'k_nuts (sampler)', 'bound': 'mfma', 'achieved': achieved_tf,
-                     'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / FP64_PEAK_TFLOPS,
-                     'traffic': traffic,
-                     'note': 'FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
-                             'duration of the sampler launch; X is LDS resident, so HBM is not the bound: '
-                             'hbm_frac below',
-                     'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
-                     'hbm_algorithmic_bytes': hbm_alg,
-                     'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS},
+        'roofline': roof,
         'sampler_share_of_step': float(ms.sum() * 1e-3 / dt),
         'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
                                                / (sites_local * args.chains * args.siter)),

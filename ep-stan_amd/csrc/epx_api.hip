@@ -70,6 +70,7 @@ struct epx_ctx {
     hipEvent_t ev0, ev1;
     unsigned long long *stamps;
     size_t stamps_n, stamps_last;
+    int last_layout;
 };
 
 const char *epx_last_error(void) { return g_err.c_str(); }
@@ -490,6 +491,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     hipLaunchKernelGGL(k_site_stats, dim3(count), dim3(128), 0, c->stream, ra);
     HIPCHK(hipGetLastError());
     c->has_last = 1;
+    c->last_layout = layout;
     c->nsamp = o.chains * nkeep;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (elapsed_ms) {
@@ -631,6 +633,11 @@ extern "C" int epx_dbg_get_stamps(epx_ctx *c, unsigned long long *out, int max_b
     return (int)nb;
 }
 #endif
+
+int epx_last_layout(epx_ctx *c) {
+    if (!c) return fail("null context");
+    return c->last_layout;
+}
 
 int epx_get_chain_stats(epx_ctx *c, int k0, int count, double *out) {
     CTX(c);

@@ -212,6 +212,20 @@ class HipEngine(object):
                                             dptr(inv_e), dptr(out), dptr(cs)))
         return out, cs
 
+    def last_layout(self):
+        return int(self.lib.epx_last_layout(self.ctx))
+
+    def row_passes(self, chains, k0=0, count=None):
+        """Passes over the site rows made by the last sampling call: in the streaming layout the
+        (up to 4) chains of a workgroup advance in lock step and share one pass per leapfrog;
+        otherwise every gradient is its own pass (over LDS-resident rows)."""
+        cs = self.get_chain_stats(chains, k0, count)[:, :, 3]
+        if self.last_layout() != 3:
+            return cs.sum(axis=1)
+        nb = (chains + 3) // 4
+        pad = np.zeros((cs.shape[0], nb * 4)); pad[:, :chains] = cs
+        return pad.reshape(cs.shape[0], nb, 4).max(axis=2).sum(axis=1)
+
     def get_chain_stats(self, chains, k0=0, count=None):
         count = self.K - k0 if count is None else count
         out = np.zeros((count, chains, N_STAT))

@@ -338,6 +338,7 @@ class Master(object):
         self.last_site_stats = None         # sampler statistics of the last iteration (local sites)
         self.sampling_ms = []               # device time of every sampling launch (this rank)
         self.ngrad_log = []                 # gradient evaluations of every sampling launch (this rank)
+        self.pass_log = []                  # passes over the site rows of every sampling launch (per site)
 
         # ---- validate X, y (method.py:674-689)
         self.N = X.shape[0]
@@ -631,6 +632,7 @@ class Master(object):
                 self.last_site_stats = stats        # (K_local, 8): see epx_site_stat in include/epx.h
                 self.sampling_ms.append(ms)
                 self.ngrad_log.append(float(stats[:, 3].sum()))
+                self.pass_log.append(eng.row_passes(w0.stan_params['chains']))
                 tl = np.full(self.K_local, ms * 1e-3)
                 ml, rl = stats[:, 0], stats[:, 1]
             for j, w in enumerate(local_workers):

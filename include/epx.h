@@ -194,6 +194,10 @@ int epx_nuts_transitions(epx_ctx *ctx, int k0, int count, const int64_t *seeds, 
                          int t_offset, int layout, const double *q0, const double *eps,
                          const double *inv_e, double *q_out, double *chain_stats);
 /* chain stats of the last sampling call: (count, chains, EPX_ST_COUNT) */
+/* Thread layout the last sampling call ran with (1, 2 or 3, see epx_sampler_opts.layout; 0 before
+ * the first call).  Measurement aid: layout 3 streams the rows from HBM once per leapfrog, so its
+ * roofline is the HBM one (bench.py).  No reference counterpart. */
+int epx_last_layout(epx_ctx *ctx);
 int epx_get_chain_stats(epx_ctx *ctx, int k0, int count, double *out);
 /* TEST HOOK: uniforms/normals of the device random stream */
 int epx_rng_probe(int device, uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a,

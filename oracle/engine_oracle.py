@@ -170,6 +170,12 @@ class OracleEngine(object):
         dr = self.draws[k].reshape(-1, self.P)
         return np.asfortranarray(dr if all_params else dr[:, :self.d])
 
+    def last_layout(self):
+        return 0
+
+    def row_passes(self, chains, k0=0, count=None):
+        return self.get_chain_stats(chains, k0, count)[:, :, 3].sum(axis=1)
+
     def get_chain_stats(self, chains, k0=0, count=None):
         count = self.K - k0 if count is None else count
         return self.chain_stats[k0:k0 + count].copy()
