@@ -71,6 +71,8 @@ struct epx_ctx {
     unsigned long long *stamps;
     size_t stamps_n, stamps_last;
     int last_layout;
+    int *order_d;
+    int order_n;
 };
 
 const char *epx_last_error(void) { return g_err.c_str(); }
@@ -211,7 +213,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -467,6 +469,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv, &layout)) return -1;
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
     a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
+    a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
 #ifdef EPX_STAMPS
     {
         const int nblk = count * ((o.chains + a.cpb - 1) / a.cpb);
@@ -633,6 +636,21 @@ extern "C" int epx_dbg_get_stamps(epx_ctx *c, unsigned long long *out, int max_b
     return (int)nb;
 }
 #endif
+
+int epx_set_site_order(epx_ctx *c, const int32_t *order, int count) {
+    CTX(c);
+    if (!order || count <= 0) { c->order_n = 0; return 0; }
+    if (count > c->K) return fail("site order has %d entries for %d sites", count, c->K);
+    std::vector<char> seen((size_t)count, 0);
+    for (int i = 0; i < count; ++i) {
+        if (order[i] < 0 || order[i] >= count || seen[order[i]]) return fail("site order is not a permutation of 0..%d", count - 1);
+        seen[order[i]] = 1;
+    }
+    if (!c->order_d) HIPCHK(dalloc(&c->order_d, (size_t)c->K));
+    HIPCHK(hipMemcpy(c->order_d, order, (size_t)count * sizeof(int), hipMemcpyHostToDevice));
+    c->order_n = count;
+    return 0;
+}
 
 int epx_last_layout(epx_ctx *c) {
     if (!c) return fail("null context");

@@ -107,6 +107,7 @@ struct NutsArgs {
     const double *cav_Om;         // K x d x d
     const double *cav_mu;         // K x d
     const int64_t *seeds;         // per site of the batch (index k - k0)
+    const int *order;             // optional: workgroup i works on site order[i] of the batch (longest first), or NULL
     double *draws;                // K x chains x nkeep x P
     double *last;                 // K x chains x P (read when init_mode == PREV, always written)
     double *chain_stats;          // K x chains x ST_COUNT

@@ -110,7 +110,7 @@ k_nuts(NutsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int team = wave / WPC, wt = wave % WPC;
     const int bps = (a.chains + a.cpb - 1) / a.cpb;
-    const int sb = blockIdx.x / bps, cb = blockIdx.x % bps;
+    const int sb = a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps), cb = blockIdx.x % bps;
     const int k = a.k0 + sb;
     const int chain = cb * a.cpb + team;
     const int D = a.D, d = a.d, P = a.P, model = a.model;
@@ -419,7 +419,9 @@ k_nuts(NutsArgs a) {
 
 #define EPX_CHAIN_EXIT break
 #define EPX_DBG_EXIT return
+#define STAMP_LEAF do { } while (0)
 #include "nuts_state_machine.inc"
+#undef STAMP_LEAF
 #undef EPX_CHAIN_EXIT
 #undef EPX_DBG_EXIT
     }

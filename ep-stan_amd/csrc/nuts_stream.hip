@@ -75,7 +75,7 @@ k_nuts_stream(NutsArgs a) {
     const int wt = 0;                           // one wave per chain
     const bool is_chain = wave < NCH;
     const int bps = (a.chains + NCH - 1) / NCH;
-    const int sb = blockIdx.x / bps, cb = blockIdx.x % bps;
+    const int sb = a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps), cb = blockIdx.x % bps;
     const int k = a.k0 + sb;
     const int chain = cb * NCH + (is_chain ? wave : 0);
     const bool active = is_chain && chain < a.chains;
@@ -366,7 +366,9 @@ k_nuts_stream(NutsArgs a) {
         double n_key = 0, n_plp = 0;
 #define EPX_CHAIN_EXIT { finished = 1; eps_l = 0.0; continue; }
 #define EPX_DBG_EXIT { finished = 1; eps_l = 0.0; continue; }
+#define STAMP_LEAF STAMP(6)
 #include "nuts_state_machine.inc"
+#undef STAMP_LEAF
 #undef EPX_CHAIN_EXIT
 #undef EPX_DBG_EXIT
     }

@@ -215,6 +215,14 @@ class HipEngine(object):
     def last_layout(self):
         return int(self.lib.epx_last_layout(self.ctx))
 
+    def set_site_order(self, order=None):
+        """Scheduling hint: workgroup i of the next full-batch sampling calls takes site order[i]."""
+        if order is None:
+            check(self.lib.epx_set_site_order(self.ctx, None, 0))
+            return
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        check(self.lib.epx_set_site_order(self.ctx, order.ctypes.data, int(order.shape[0])))
+
     def row_passes(self, chains, k0=0, count=None):
         """Passes over the site rows made by the last sampling call: in the streaming layout the
         (up to 4) chains of a workgroup advance in lock step and share one pass per leapfrog;

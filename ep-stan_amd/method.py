@@ -271,8 +271,10 @@ class Master(object):
     GPU-only keyword arguments: `device` (HIP device index, default: rank's
     LOCAL_RANK or 0), `comm` (a `dist.TorchComm` to shard the sites over several
     GPUs), `max_treedepth` (default 10), `layout` (0 auto, 1 block per site,
-    2 block per (site, chain)), `sync_sites` (gather the site arrays of all
-    ranks into the host mirrors when `run` returns, default True).
+    2 block per (site, chain), 3 streaming), `sync_sites` (gather the site arrays
+    of all ranks into the host mirrors when `run` returns, default True),
+    `balance_sites` (dispatch the sites of an iteration in decreasing order of the
+    leapfrogs they took in the previous one; results do not depend on it, default True).
     """
 
     INFO_OK = 0
@@ -306,6 +308,7 @@ class Master(object):
         max_treedepth     = 10,
         layout            = 0,
         sync_sites        = True,
+        balance_sites     = True,
         _engine_factory   = None,
     )
 
@@ -333,6 +336,7 @@ class Master(object):
         self.max_treedepth = gpu['max_treedepth']
         self.layout = gpu['layout']
         self.sync_sites = gpu['sync_sites']
+        self.balance_sites = gpu['balance_sites']
         self.comm = gpu['comm'] if gpu['comm'] is not None else _dist.LocalComm()
         self._sample_injector = None        # test hook: f(data, stan_params) -> (S, d) draws
         self.last_site_stats = None         # sampler statistics of the last iteration (local sites)
@@ -633,6 +637,9 @@ class Master(object):
                 self.sampling_ms.append(ms)
                 self.ngrad_log.append(float(stats[:, 3].sum()))
                 self.pass_log.append(eng.row_passes(w0.stan_params['chains']))
+                if self.balance_sites and self.K_local > 1:
+                    # longest-first dispatch of the next iteration's workgroups (results unaffected)
+                    eng.set_site_order(np.argsort(-self.pass_log[-1], kind='stable'))
                 tl = np.full(self.K_local, ms * 1e-3)
                 ml, rl = stats[:, 0], stats[:, 1]
             for j, w in enumerate(local_workers):

@@ -194,6 +194,13 @@ int epx_nuts_transitions(epx_ctx *ctx, int k0, int count, const int64_t *seeds, 
                          int t_offset, int layout, const double *q0, const double *eps,
                          const double *inv_e, double *q_out, double *chain_stats);
 /* chain stats of the last sampling call: (count, chains, EPX_ST_COUNT) */
+/* Scheduling hint for the next sampling calls that cover sites 0..count-1: workgroup i takes site
+ * order[i] (a permutation of 0..count-1).  Workgroups are dispatched in index order, so listing the
+ * sites by decreasing expected work (e.g. the leapfrogs of the previous EP iteration) shortens the
+ * tail of the launch.  Results do not depend on it.  NULL / count 0 clears the hint.
+ * No reference counterpart (the reference runs its sites one after the other, method.py:1005-1023). */
+int epx_set_site_order(epx_ctx *ctx, const int32_t *order, int count);
+
 /* Thread layout the last sampling call ran with (1, 2 or 3, see epx_sampler_opts.layout; 0 before
  * the first call).  Measurement aid: layout 3 streams the rows from HBM once per leapfrog, so its
  * roofline is the HBM one (bench.py).  No reference counterpart. */

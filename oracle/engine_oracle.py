@@ -173,6 +173,9 @@ class OracleEngine(object):
     def last_layout(self):
         return 0
 
+    def set_site_order(self, order=None):
+        pass
+
     def row_passes(self, chains, k0=0, count=None):
         return self.get_chain_stats(chains, k0, count)[:, :, 3].sum(axis=1)
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from epstan_amd import _lib
 from epstan_amd.engine import HipEngine, QI
-NAMES = ['A: transforms', 'Omega pass', 'row stream', 'D: chain rule', 'bookkeeping', 'top barrier']
+NAMES = ['A: transforms', 'Omega pass', 'row stream', 'D: chain rule', 'bookkeeping (other)', 'top barrier', 'bookkeeping (plain leaf)']
 K, D, n = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 128, 2000
 rng = np.random.RandomState(0)
 X = rng.randn(K * n, D) * 0.3
@@ -20,7 +20,7 @@ buf = np.zeros((4096, 8), dtype=np.uint64)
 lib.epx_dbg_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 nb = lib.epx_dbg_get_stamps(eng.ctx, buf.ctypes.data, 4096)
 st = buf[:nb].astype(np.float64)
-per = st[:, :6] / st[:, 7:8]
+per = st[:, :7] / st[:, 7:8]
 med = np.median(per, axis=0)
 tot_ticks = st[:, 7].max()
 print('K=%d: %.1f ms, slowest block %d leapfrogs -> %.1f us each; s_memtime units per leapfrog (median over %d blocks): %.0f'

@@ -371,6 +371,31 @@ def test_nuts_layouts_agree_and_are_deterministic():
     assert np.sum(np.all(err < 1e-4, axis=2)) >= 6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('model,D,n,layout', [('m4b_sg', 8, 90, 1), ('m4b_sg', 8, 90, 2), ('m4b_sg', 40, 70, 3)])
+def test_site_order_hint_does_not_change_results(model, D, n, layout):
+    """epx_set_site_order only permutes which workgroup takes which site."""
+    K = 5
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 11, K=K, tight=30.0)
+    eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.arange(K, dtype=np.int64) + 3
+    opts = HipEngine.sampler_opts(chains=4, iter=30, init='random', layout=layout)
+    eng.sample_batch(seeds, opts)
+    ref = np.stack([eng.get_draws(k, True) for k in range(K)])
+    ref_stats = eng.get_chain_stats(4)
+    eng.set_site_order([3, 0, 4, 2, 1])
+    eng.sample_batch(seeds, opts)
+    np.testing.assert_array_equal(np.stack([eng.get_draws(k, True) for k in range(K)]), ref)
+    np.testing.assert_array_equal(eng.get_chain_stats(4), ref_stats)
+    with pytest.raises(Exception):
+        eng.set_site_order([0, 0, 1, 2, 3])
+    eng.set_site_order(None)
+    eng.sample_batch(seeds, opts)
+    np.testing.assert_array_equal(np.stack([eng.get_draws(k, True) for k in range(K)]), ref)
+    assert eng.last_layout() == layout
+
+
+@pytest.mark.gpu
 def test_nuts_warm_start_and_thin():
     """init_prev (method.py:404-406): the next call starts at the last draws."""
     X, y, k_lim, Oms, mus, d, P = _site_problem('m1b_sg', 4, 60, 9, K=2, tight=40.0)
