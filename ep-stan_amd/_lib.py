@@ -66,6 +66,9 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     'epx_last_layout': (ctypes.c_int, [ctypes.c_void_p]),
+    'epx_damp_sweep': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, ctypes.c_void_p,
+                                      c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p, ctypes.c_int,
+                                      c_double_p]),
     'epx_set_site_order': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     'epx_get_chain_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p]),
     'epx_rng_probe': (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32,

@@ -327,6 +327,7 @@ k_site_sums_final(SumArgs a) {
 __global__ void __launch_bounds__(256)
 k_global(GlobalArgs a) {
     extern __shared__ __align__(16) double lds[];
+    __shared__ double red[16];
     const int d = a.d, ld = a.ld, tid = threadIdx.x, T = blockDim.x;
     double *W, *V, *vec;
     ws_pointers(a.ws, 0, d, ld, lds, W, V, vec);
@@ -343,11 +344,51 @@ k_global(GlobalArgs a) {
     __syncthreads();
     const bool ok = block_potrf(W, d, ld);
     if (tid == 0) *a.flag = ok ? 1 : 0;
+    double half_logdet_Q = 0.0;
+    if (ok && a.crit) {
+        double t = 0.0;
+        for (int j = tid; j < d; j += T) t += log(W[j + (size_t)j * ld]);
+        half_logdet_Q = block_sum(t, red);
+    }
     if (ok && a.want_moments) {
         block_potrs(W, d, ld, vec);
         block_potri(W, V, d, ld);
         for (int idx = tid; idx < d2; idx += T) a.S[idx] = W[(idx % d) + (size_t)(idx / d) * ld];
         for (int i = tid; i < d; i += T) a.m[i] = vec[i];
+    }
+    if (a.crit) {
+        // selection criteria of find_damp.py:155-163 with S^-1 = Q:
+        //   mse = mean((m - m_t)^2)
+        //   KL(N(m_t,S_t) || N(m,S)) = (tr(Q S_t) + dm'Q dm - d)/2 - logdet(S_t)/2 - logdet(Q)/2      (kl_mvn, :38-56)
+        //   ll  = sum_s log N(x_s | m, S) = -n/2 (d log 2pi - logdet Q) - (tr(Q Sc) + n (xbar-m)'Q(xbar-m))/2
+        double mse = NAN, kl = NAN, ll = NAN;
+        if (ok && a.want_moments) {
+            const double *mt = a.tgt, *St = a.tgt + d, *xb = St + d2, *Sc = xb + d;
+            const double hl_St = Sc[d2], ns = Sc[d2 + 1];
+            double e2 = 0.0, trt = 0.0, trc = 0.0, qt = 0.0, qc = 0.0;
+            for (int i = tid; i < d; i += T) { const double e = vec[i] - mt[i]; e2 += e * e; }
+            for (int idx = tid; idx < d2; idx += T) {
+                const int i = idx % d, j = idx / d;
+                const double q = a.Q[idx];
+                trt += q * St[idx];
+                qt += q * (vec[i] - mt[i]) * (vec[j] - mt[j]);
+                if (ns > 0.0) { trc += q * Sc[idx]; qc += q * (xb[i] - vec[i]) * (xb[j] - vec[j]); }
+            }
+            e2 = block_sum(e2, red); trt = block_sum(trt, red); qt = block_sum(qt, red);
+            trc = block_sum(trc, red); qc = block_sum(qc, red);
+            mse = e2 / d;
+            kl = 0.5 * (trt + qt - d) - hl_St - half_logdet_Q;
+            if (ns > 0.0) ll = -0.5 * ns * (d * 1.8378770664093454836 - 2.0 * half_logdet_Q) - 0.5 * (trc + ns * qc);
+        }
+        if (tid == 0) { a.crit[0] = ok ? 1.0 : 0.0; a.crit[1] = 0.0; a.crit[2] = mse; a.crit[3] = kl; a.crit[4] = ll; }
+    }
+}
+
+// second half of a sweep entry: all-cavities flag of the trial (find_damp.py:150-153)
+__global__ void k_sweep_flag(const int *all_flag, double *crit) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        crit[1] = (crit[0] != 0.0 && *all_flag) ? 1.0 : 0.0;
+        if (crit[1] == 0.0) { crit[2] = NAN; crit[3] = NAN; crit[4] = NAN; }
     }
 }
 

@@ -73,6 +73,8 @@ struct epx_ctx {
     int last_layout;
     int *order_d;
     int order_n;
+    double *sweep_buf;        // damping sweep: target block + ndf x 5 criteria
+    size_t sweep_elems;
 };
 
 const char *epx_last_error(void) { return g_err.c_str(); }
@@ -213,7 +215,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -714,8 +716,10 @@ int epx_site_sums(epx_ctx *c, double *packed_host, double *packed_dev) {
     return 0;
 }
 
-static int launch_global(epx_ctx *c, const double *packed_dev, double df, int want_moments) {
+static int launch_global(epx_ctx *c, const double *packed_dev, double df, int want_moments,
+                         const double *tgt = nullptr, double *crit = nullptr) {
     GlobalArgs a;
+    a.tgt = tgt; a.crit = crit;
     a.d = c->d; a.ld = ld_of(c->d); a.want_moments = want_moments;
     size_t lds;
     if (dense_ws(c, c->d, c->K, &a.ws, &lds)) return -1;
@@ -753,6 +757,48 @@ int epx_damped_trial(epx_ctx *c, double df, const double *packed_host, const dou
     HIPCHK(hipStreamSynchronize(c->stream));
     *cav_pd = h[1];
     if (first_bad) *first_bad = h[2];
+    return 0;
+}
+
+int epx_damp_sweep(epx_ctx *c, int ndf, const double *dfs, const double *packed_host, const double *packed_dev,
+                   const double *m_target, const double *S_target, double half_logdet_S_target,
+                   const double *samp_mean, const double *samp_scatter, int n_samp, double *out) {
+    CTX(c);
+    if (ndf < 1 || !dfs || !m_target || !S_target || !out) return fail("damp sweep: missing argument");
+    const size_t d = c->d, d2 = d * d, ntgt = 2 * (d + d2) + 2;
+    const size_t need = ntgt + (size_t)ndf * 5;
+    if (c->sweep_elems < need) {
+        if (c->sweep_buf) (void)hipFree(c->sweep_buf);
+        c->sweep_buf = nullptr; c->sweep_elems = 0;
+        HIPCHK(dalloc(&c->sweep_buf, need));
+        c->sweep_elems = need;
+    }
+    std::vector<double> h(ntgt, 0.0);
+    memcpy(h.data(), m_target, d * 8);
+    memcpy(h.data() + d, S_target, d2 * 8);
+    const bool have_samp = samp_mean && samp_scatter && n_samp > 0;
+    if (have_samp) { memcpy(h.data() + d + d2, samp_mean, d * 8); memcpy(h.data() + 2 * d + d2, samp_scatter, d2 * 8); }
+    h[2 * (d + d2)] = half_logdet_S_target;
+    h[2 * (d + d2) + 1] = have_samp ? (double)n_samp : 0.0;
+    HIPCHK(hipMemcpyAsync(c->sweep_buf, h.data(), ntgt * 8, hipMemcpyHostToDevice, c->stream));
+    const double *pk = packed_dev;
+    if (packed_host) {
+        HIPCHK(hipMemcpyAsync(c->packed, packed_host, (size_t)2 * (d2 + d) * 8, hipMemcpyHostToDevice, c->stream));
+        pk = c->packed;
+    }
+    if (!pk) pk = c->packed;
+    double *crit = c->sweep_buf + ntgt;
+    // every trial back to back on the stream, one synchronisation at the end
+    for (int i = 0; i < ndf; ++i) {
+        if (launch_global(c, pk, dfs[i], 1, c->sweep_buf, crit + (size_t)i * 5)) return -1;
+        if (launch_cavity(c, c->Qi, c->ri, c->dQi, c->dri, dfs[i], 0, c->K)) return -1;
+        hipLaunchKernelGGL(k_all_flags, dim3(1), dim3(256), 0, c->stream, c->flags, 0, c->K, c->iflags + 1);
+        hipLaunchKernelGGL(k_sweep_flag, dim3(1), dim3(64), 0, c->stream, c->iflags + 1, crit + (size_t)i * 5);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(out, crit, (size_t)ndf * 5 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->last_df = dfs[ndf - 1];
     return 0;
 }
 

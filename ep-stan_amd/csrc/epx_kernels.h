@@ -51,6 +51,10 @@ struct GlobalArgs {
     double df;
     double *Q, *r, *S, *m;
     int *flag;
+    // damping sweep (find_damp.py:146-173): selection criteria of the trial against a target
+    // tgt = [m_t (d), S_t (d*d), xbar (d), Sc (d*d), half_logdet_St, n_samp] ; crit = [global_pd, cav_pd, mse, kl, ll]
+    const double *tgt;
+    double *crit;
 };
 
 struct InvertArgs {
@@ -84,6 +88,7 @@ __global__ void k_site_sums_partial(SumArgs a);
 __global__ void k_site_sums_final(SumArgs a);
 __global__ void k_global(GlobalArgs a);
 __global__ void k_axpy(double *out, const double *x, const double *dx, double df, size_t n);
+__global__ void k_sweep_flag(const int *all_flag, double *crit);
 __global__ void k_all_flags(const uint8_t *flags, int k0, int count, int *out);
 __global__ void k_invert(InvertArgs a);
 __global__ void k_olse(OlseArgs a);

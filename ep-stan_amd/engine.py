@@ -280,6 +280,32 @@ class HipEngine(object):
                                             ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb)))
         return bool(g.value), bool(c.value), fb.value
 
+    def damp_sweep(self, damps, packed, m_target, S_target, samp_target=None):
+        """Score every damping factor of `damps` (find_damp.py:146-173) -> (ndf, 5) array
+        [global_pd, cav_pd (this rank's sites), mse, kl, ll]; criteria NaN unless both flags hold."""
+        damps = np.ascontiguousarray(damps, dtype=np.float64)
+        m_t = np.ascontiguousarray(m_target, dtype=np.float64)
+        S_t = np.asfortranarray(S_target, dtype=np.float64)
+        half_logdet = float(np.sum(np.log(np.diag(np.linalg.cholesky(S_t)))))
+        xm = xs = None
+        ns = 0
+        if samp_target is not None:
+            samp = np.asarray(samp_target, dtype=np.float64)
+            ns = samp.shape[0]
+            xm = np.ascontiguousarray(samp.mean(axis=0))
+            c = samp - xm
+            xs = np.asfortranarray(c.T.dot(c))
+        out = np.zeros((damps.shape[0], 5))
+        host = dev = None
+        if isinstance(packed, np.ndarray):
+            host = dptr(np.ascontiguousarray(packed, dtype=np.float64))
+        elif packed is not None:
+            dev = ctypes.c_void_p(packed.data_ptr())
+        check(self.lib.epx_damp_sweep(self.ctx, int(damps.shape[0]), dptr(damps), host, dev, dptr(m_t), dptr(S_t),
+                                      half_logdet, dptr(xm) if xm is not None else None,
+                                      dptr(xs) if xs is not None else None, int(ns), dptr(out)))
+        return out
+
     def accept(self, df):
         check(self.lib.epx_accept(self.ctx, float(df)))
 

@@ -343,6 +343,8 @@ class Master(object):
         self.sampling_ms = []               # device time of every sampling launch (this rank)
         self.ngrad_log = []                 # gradient evaluations of every sampling launch (this rank)
         self.pass_log = []                  # passes over the site rows of every sampling launch (per site)
+        self.sweep_log = []                 # results of `run(..., sweep=...)`, one dict per iteration
+        self.df_log = []                    # damping factor accepted in every iteration
 
         # ---- validate X, y (method.py:674-689)
         self.N = X.shape[0]
@@ -569,6 +571,24 @@ class Master(object):
                 ra[:, lo:hi] = rl
         self.Q[...], self.r[...] = self.engine.get_global()
 
+    def damp_sweep(self, damps, m_target, S_target, samp_target=None, packed=None):
+        """Score damping factors for the pending site updates `dQi, dri` against a target
+        posterior N(m_target, S_target): the loop `for di, df in enumerate(damps)` of
+        experiment/find_damp.py:146-173 as ONE batched device call (the proposal is affine in
+        `df`, so the site sums are reduced once).  Returns a dict with `mses`, `lls`, `kls`
+        (NaN where the proposal or a cavity is not positive definite, as in the reference) and
+        the flags `global_pd`, `cav_pd`.  Does not change the site parameters."""
+        eng, comm = self.engine, self.comm
+        if packed is None:
+            packed = comm.allreduce_sum(eng.site_sums(self._packed))
+        res = eng.damp_sweep(damps, packed, m_target, S_target, samp_target)
+        if comm.world > 1:
+            res[:, 1] = -comm.allreduce_max(-res[:, 1])
+        bad = res[:, 1] == 0.0
+        res[bad, 2:] = np.nan
+        return dict(damps=np.asarray(damps, dtype=np.float64), global_pd=res[:, 0] > 0, cav_pd=res[:, 1] > 0,
+                    mses=res[:, 2], kls=res[:, 3], lls=res[:, 4])
+
     def cur_approx(self):
         """Current posterior approximation moments (S, m) (method.py:884-896)."""
         return self.engine.invert_normal_params(self.Q, self.r)
@@ -584,12 +604,16 @@ class Master(object):
         return tuple(out) if as_tuple else out
 
     def run(self, niter, calc_moments=True, save_last_param=None, verbose=True,
-            return_analytics=False, seed=None):
+            return_analytics=False, seed=None, sweep=None):
         """Run the distributed EP algorithm (method.py:899-1247).
 
         Returns `info`, optionally followed by `(m_phi_s, cov_phi_s)` and
         `(stimes, msteps, mrhats, othertimes)` exactly like the reference
-        (a list on the early-exit paths, a tuple on the normal path)."""
+        (a list on the early-exit paths, a tuple on the normal path).
+
+        `sweep` (not in the reference's `run`; it is the body of experiment/find_damp.py): a dict
+        `damps, m_target, S_target[, samp_target]`; every iteration scores these damping factors
+        with `damp_sweep` before its own damped update and appends the result to `self.sweep_log`."""
         if niter < 1:
             if verbose:
                 print("Nothing to do here as provided arg. `niter` is {}".format(niter))
@@ -679,6 +703,10 @@ class Master(object):
             # ---- the one reduction per iteration (:1073-1074, affine in df)
             packed = comm.allreduce_sum(eng.site_sums(self._packed))
 
+            if sweep is not None:                                   # find_damp.py:146-173
+                self.sweep_log.append(self.damp_sweep(sweep['damps'], sweep['m_target'], sweep['S_target'],
+                                                      sweep.get('samp_target'), packed=packed))
+
             df = self.df0(self.iter)                                # :1060
             if verbose:
                 print("Iter {}, starting df {:.3g}".format(self.iter, df))
@@ -691,6 +719,7 @@ class Master(object):
                         c_pd = bool(comm.allreduce_min_int(1 if c_pd else 0))
                     if c_pd:                                        # :1145-1158 accept
                         eng.accept(df)
+                        self.df_log.append(df)
                         for w in local_workers:
                             w.Q, w.r = self.Q, self.r
                             w.phase = 1

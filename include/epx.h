@@ -194,6 +194,20 @@ int epx_nuts_transitions(epx_ctx *ctx, int k0, int count, const int64_t *seeds, 
                          int t_offset, int layout, const double *q0, const double *eps,
                          const double *inv_e, double *q_out, double *chain_stats);
 /* chain stats of the last sampling call: (count, chains, EPX_ST_COUNT) */
+/* Damping sweep (experiment/find_damp.py:146-173, the loop `for di, df in enumerate(damps)`): for every
+ * dfs[i] form the proposal Q = Q0 + sum(Qi + df dQi), r likewise, factorise, S = Q^-1, m = S r, all cavities,
+ * and score the proposal against a target posterior: out[i*5 + {0..4}] =
+ *   global_pd (0/1), all local cavities pd (0/1), mse = mean((m - m_target)^2)      (:157),
+ *   KL(N(m_target,S_target) || N(m,S))   (kl_mvn, :38-56; half_logdet_S_target = sum(log(diag(cho(S_target))))),
+ *   ll = sum_s log N(x_s | m, S) over the target samples (:159-160), given by their sufficient statistics
+ *        samp_mean (d), samp_scatter = sum (x_s - mean)(x_s - mean)' (d x d), n_samp  (NULL / 0: ll = NaN).
+ * The criteria are NaN unless both flags are 1 (the reference leaves its pre-filled NaN there).  All trials
+ * run back to back on the context's stream with one synchronisation at the end.  packed_*: as in
+ * epx_damped_trial.  With several ranks the caller min-reduces column 1 (and voids rows accordingly). */
+int epx_damp_sweep(epx_ctx *ctx, int ndf, const double *dfs, const double *packed_host, const double *packed_dev,
+                   const double *m_target, const double *S_target, double half_logdet_S_target,
+                   const double *samp_mean, const double *samp_scatter, int n_samp, double *out);
+
 /* Scheduling hint for the next sampling calls that cover sites 0..count-1: workgroup i takes site
  * order[i] (a permutation of 0..count-1).  Workgroups are dispatched in index order, so listing the
  * sites by decreasing expected work (e.g. the leapfrogs of the previous EP iteration) shortens the

@@ -218,6 +218,29 @@ class OracleEngine(object):
         bad = np.nonzero(~flags)[0]
         return True, bad.size == 0, (int(bad[0]) if bad.size else -1)
 
+    def damp_sweep(self, damps, packed, m_target, S_target, samp_target=None):
+        d = self.d
+        if not isinstance(packed, np.ndarray):
+            packed = packed.cpu().numpy()
+        sQ = packed[:d * d].reshape(d, d, order='F'); sr = packed[d * d:d * d + d]
+        sdQ = packed[d * d + d:2 * d * d + d].reshape(d, d, order='F'); sdr = packed[2 * d * d + d:]
+        out = np.full((len(damps), 5), np.nan)
+        out[:, :2] = 0.0
+        for di, df in enumerate(damps):
+            Q = self.Q0 + sQ + df * sdQ
+            r = self.r0 + sr + df * sdr
+            try:
+                np.linalg.cholesky(Q)
+            except np.linalg.LinAlgError:
+                continue
+            out[di, 0] = 1.0
+            ok = all(eo.cavity(Q, r, self.Qi[:, :, k] + df * self.dQi[:, :, k],
+                               self.ri[:, k] + df * self.dri[:, k])[2] for k in range(self.K))
+            if ok:
+                out[di, 1] = 1.0
+                out[di, 2:] = eo.damp_criteria(Q, r, m_target, S_target, samp_target)
+        return out
+
     def accept(self, df):
         self.Qi += df * self.dQi
         self.ri += df * self.dri

@@ -140,6 +140,54 @@ def tilted_moments(samp, Q, r, prec_estim='sample'):
 
 
 # method.py:342-346 and :956-960
+def kl_mvn(m0, S0, m1, S1, sum_log_diag_cho_S0=None):
+    """KL(N(m0,S0) || N(m1,S1)) (experiment/find_damp.py:38-56)."""
+    choS1 = np.linalg.cholesky(S1)
+    if sum_log_diag_cho_S0 is None:
+        sum_log_diag_cho_S0 = np.sum(np.log(np.diag(np.linalg.cholesky(S0))))
+    dm = m1 - m0
+    Q1 = np.linalg.inv(S1)
+    return (0.5 * (np.trace(Q1.dot(S0)) + dm.dot(Q1.dot(dm)) - len(m0))
+            - sum_log_diag_cho_S0 + np.sum(np.log(np.diag(choS1))))
+
+
+def damp_criteria(Q, r, m_target, S_target, samp_target=None):
+    """Selection criteria of one damping trial (find_damp.py:155-163): mse, kl, ll of the
+    proposal N(m, S), S = Q^-1, m = S r, against the target."""
+    S, m = invert_normal_params(Q, r)
+    mse = np.mean((m - m_target)**2)
+    kl = kl_mvn(m_target, S_target, m, S)
+    ll = np.nan
+    if samp_target is not None:
+        d = m.shape[0]
+        dx = samp_target - m
+        ll = -0.5 * (samp_target.shape[0] * (d * np.log(2 * np.pi) + np.linalg.slogdet(S)[1])
+                     + np.einsum('si,ij,sj->', dx, Q, dx))
+    return mse, kl, ll
+
+
+def damp_sweep(Q0, r0, Qi, ri, dQi, dri, damps, m_target, S_target, samp_target=None):
+    """The loop `for di, df in enumerate(damps)` of find_damp.py:146-173 -> (ndf, 5) array
+    [global_pd, cav_pd, mse, kl, ll], criteria NaN unless both flags hold."""
+    out = np.full((len(damps), 5), np.nan)
+    out[:, :2] = 0.0
+    K = Qi.shape[2]
+    for di, df in enumerate(damps):
+        Qi2 = Qi + df * dQi
+        ri2 = ri + df * dri
+        Q = Qi2.sum(2) + Q0
+        r = ri2.sum(1) + r0
+        try:
+            np.linalg.cholesky(Q)
+        except np.linalg.LinAlgError:
+            continue
+        out[di, 0] = 1.0
+        if all(cavity(Q, r, Qi2[:, :, k], ri2[:, k])[2] for k in range(K)):
+            out[di, 1] = 1.0
+            out[di, 2:] = damp_criteria(Q, r, m_target, S_target, samp_target)
+    return out
+
+
 def run_seeds(seed, niter, K):
     if isinstance(seed, np.random.RandomState):
         rng = seed

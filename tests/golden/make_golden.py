@@ -314,6 +314,66 @@ def g8_seeds(out):
     out['g8_stan_seeds'] = stan
 
 
+def g9_damp_sweep(method, util, out, models):
+    """The damping sweep of experiment/find_damp.py:137-173 at C1 size, driven through the
+    reference's own Master / Worker.cavity / invert_normal_params / find_damp.kl_mvn."""
+    import find_damp
+    from scipy import linalg, stats
+    from scipy.linalg import cho_factor
+    mod = models['m1b'].model(4, 4, 50)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    K = 4
+    patch_sampler(method, injectors.GaussianTilted('smooth'))
+    master = method.Master('none/m1b_sg', data.X, data.y, site_sizes=data.Nj,
+                           A_k={'site_id': np.arange(K)}, prior={'Q': Q0, 'r': r0},
+                           chains=4, iter=200, df0=0.5)
+    master.run(2, verbose=False, seed=3)
+    d = master.dphi
+    rng = np.random.RandomState(7)
+    S_target = rand_spd(rng, d, 0.3)
+    m_target = master.m + 0.3 * rng.randn(d)
+    samp_target = rng.multivariate_normal(m_target, S_target, size=500)
+    sum_log_diag_cho_S0 = np.sum(np.log(np.diag(cho_factor(S_target)[0])))
+    S, m, Q, r = master.S, master.m, master.Q, master.r
+    Qi, ri, Qi2, ri2, dQi, dri = master.Qi, master.ri, master.Qi2, master.ri2, master.dQi, master.dri
+    posdefs = np.zeros(K, dtype=bool)
+    for k, worker in enumerate(master.workers):
+        posdefs[k] = worker.tilted(dQi[:, :, k], dri[:, k], seed=100 + k)    # find_damp.py:139 draws a random seed
+    assert np.all(posdefs)
+    out['g9_Q0'], out['g9_r0'] = master.Q0.copy(), master.r0.copy()
+    out['g9_Qi'], out['g9_ri'] = Qi.copy(), ri.copy()
+    out['g9_dQi'], out['g9_dri'] = dQi.copy(), dri.copy()
+    out['g9_m_target'], out['g9_S_target'], out['g9_samp_target'] = m_target, S_target, samp_target
+    # damps beyond 1 make the proposal leave the positive definite cone for this scenario
+    damps = np.concatenate((np.linspace(0, 1, find_damp.N_DAMP + 2)[1:-1], [1.5, 2.5, 4.0, 5.5, 8.0, -1.0, -40.0]))
+    n = damps.shape[0]
+    mses, lls, kls = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+    gpd, cpd = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool)
+    for di, df in enumerate(damps):                                    # find_damp.py:146-173
+        np.add(Qi, np.multiply(df, dQi, out=Qi2), out=Qi2)
+        np.add(ri, np.multiply(df, dri, out=ri2), out=ri2)
+        np.add(Qi2.sum(2, out=Q), master.Q0, out=Q)
+        np.add(ri2.sum(1, out=r), master.r0, out=r)
+        try:
+            cho_Q = S
+            np.copyto(cho_Q, Q)
+            linalg.cho_factor(cho_Q, overwrite_a=True)
+            util.invert_normal_params(cho_Q, r, out_A='in-place', out_b=m, cho_form=True)
+            gpd[di] = True
+            for k, worker in enumerate(master.workers):
+                posdefs[k] = worker.cavity(Q, r, Qi2[:, :, k], ri2[:, k])
+            if np.all(posdefs):
+                cpd[di] = True
+                mses[di] = np.mean((m - m_target)**2)
+                lls[di] = np.sum(stats.multivariate_normal.logpdf(samp_target, mean=m, cov=S.T))
+                kls[di] = find_damp.kl_mvn(m_target, S_target, m, S.T, sum_log_diag_cho_S0)
+        except linalg.LinAlgError:
+            pass
+    out['g9_damps'], out['g9_mses'], out['g9_lls'], out['g9_kls'] = damps, mses, lls, kls
+    out['g9_global_pd'], out['g9_cav_pd'] = gpd, cpd
+
+
 def main():
     util, method, tmp = import_reference()
     from models import m1b, m4b
@@ -330,12 +390,15 @@ def main():
         run = {}
         g6_run(method, run, models)
         np.savez_compressed(os.path.join(HERE, 'master_run.npz'), **run)
+        swp = {}
+        g9_damp_sweep(method, util, swp, models)
+        np.savez_compressed(os.path.join(HERE, 'damp_sweep.npz'), **swp)
         sim = {}
         g7_simulators(sim, models)
         np.savez_compressed(os.path.join(HERE, 'simulators.npz'), **sim)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for f in ('algebra.npz', 'master_run.npz', 'simulators.npz'):
+    for f in ('algebra.npz', 'master_run.npz', 'simulators.npz', 'damp_sweep.npz'):
         print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')
 
 

@@ -668,3 +668,73 @@ def test_streaming_transitions_at_c5_site_size():
     assert flags[0] and ok
     np.testing.assert_allclose(dQ, dQ_o, rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(dr, dr_o, rtol=1e-8, atol=1e-8)
+
+
+# ---------------------------------------------------------------- damping sweep (find_damp.py:146-173)
+def test_damp_sweep_golden_on_gpu(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'damp_sweep.npz'))
+    runs = np.load(os.path.join(golden_dir, 'master_run.npz'))
+    M = _master(runs, 'smooth', 0.5)
+    M.run(1, verbose=False, seed=3)
+    M.Qi[...] = z['g9_Qi']; M.ri[...] = z['g9_ri']
+    M._upload_sites()
+    M.engine.set_sites(2, z['g9_dQi'], z['g9_dri'])
+    for samp in (z['g9_samp_target'], None):
+        res = M.damp_sweep(z['g9_damps'], z['g9_m_target'], z['g9_S_target'], samp)
+        np.testing.assert_array_equal(res['global_pd'], z['g9_global_pd'])
+        np.testing.assert_array_equal(res['cav_pd'], z['g9_cav_pd'])
+        np.testing.assert_allclose(res['mses'], z['g9_mses'], rtol=1e-9, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(res['kls'], z['g9_kls'], rtol=1e-9, atol=1e-9, equal_nan=True)
+        if samp is not None:
+            np.testing.assert_allclose(res['lls'], z['g9_lls'], rtol=1e-9, atol=1e-7, equal_nan=True)
+        else:
+            assert np.all(np.isnan(res['lls']))
+    # the sweep leaves the site parameters alone
+    Qi, ri = M.engine.get_sites(0)
+    np.testing.assert_array_equal(Qi, z['g9_Qi'])
+
+
+@pytest.mark.parametrize('d,K', [(17, 9), (66, 24), (130, 6)])
+def test_damp_sweep_matches_oracle_at_larger_sizes(d, K):
+    rng = np.random.RandomState(d)
+    def spd(scale):
+        A = rng.randn(d, d + 5)
+        return np.asfortranarray(A.dot(A.T) / (d + 5) * scale)
+    Q0 = spd(1.0) + np.eye(d)
+    r0 = rng.randn(d)
+    Qi = np.zeros((d, d, K), order='F'); ri = np.zeros((d, K), order='F')
+    dQi = np.zeros((d, d, K), order='F'); dri = np.zeros((d, K), order='F')
+    for k in range(K):
+        Qi[:, :, k] = spd(0.5); ri[:, k] = rng.randn(d)
+        B = rng.randn(d, d) * 0.15
+        dQi[:, :, k] = spd(0.4) - 0.25 * Qi[:, :, k] + 0.5 * (B + B.T); dri[:, k] = rng.randn(d)
+    D = d - 1                                   # m1b_sg: dphi = D + 1
+    X = rng.randn(K * 3, D); y = (rng.rand(K * 3) < 0.5).astype(int)
+    eng = HipEngine('m1b_sg', X, y, np.arange(K + 1) * 3)
+    assert eng.d == d
+    eng.set_prior(Q0, r0); eng.set_sites(0, Qi, ri); eng.set_sites(2, dQi, dri)
+    damps = np.concatenate((np.linspace(0, 1, 33)[1:-1], [2.0, 6.0, 20.0, -3.0]))
+    m_t = rng.randn(d) * 0.1; S_t = spd(0.2) + 0.05 * np.eye(d)
+    samp = rng.multivariate_normal(m_t, S_t, size=64)
+    ref = eo.damp_sweep(Q0, r0, Qi, ri, dQi, dri, damps, m_t, S_t, samp)
+    out = eng.damp_sweep(damps, eng.site_sums(), m_t, S_t, samp)
+    np.testing.assert_array_equal(out[:, :2], ref[:, :2])
+    assert 0 < ref[:, 1].sum() < len(damps)
+    np.testing.assert_allclose(out[:, 2:], ref[:, 2:], rtol=1e-8, atol=1e-8, equal_nan=True)
+
+
+def test_find_damp_driver_on_gpu(tmp_path, monkeypatch):
+    from epstan_amd import fit, find_damp
+    monkeypatch.setattr(fit, 'RES_PATH', str(tmp_path))
+    conf = fit.configurations(J=6, D=4, K=6, npg=30, siter=60, chains=4)
+    rng = np.random.RandomState(0)
+    tgt = dict(m_target=np.zeros(5), S_target=np.eye(5) * 0.5, samp_target=rng.randn(80, 5) * 0.7)
+    out = find_damp.main('m1b', iters=3, target=tgt, conf=conf, seed=2, verbose=False)
+    assert out['kls'].shape == (3, 31)
+    assert np.isfinite(out['kls']).sum() >= 31            # small damping factors are always admissible
+    assert np.all(np.isfinite(out['kls_selected'])) and np.all(out['damps_selected'] > 0)
+    # the selected factor's criteria agree with the sweep entry at the same damping factor when it is on the grid
+    for it in range(3):
+        j = np.argmin(np.abs(out['damps'] - out['damps_selected'][it]))
+        if abs(out['damps'][j] - out['damps_selected'][it]) < 1e-12:
+            assert abs(out['kls'][it, j] - out['kls_selected'][it + 1]) < 1e-7 * max(1.0, abs(out['kls'][it, j]))

@@ -274,3 +274,45 @@ def test_fit_configurations_and_ep_branch_schema(tmp_path, monkeypatch):
         fit.main('m1b', fit.configurations(run_full=True), _engine_factory=factory)
     M = fit.main('m4b', fit.configurations(J=4, D=2, K=4, npg=10), ret_master=True, _engine_factory=factory)
     assert isinstance(M, Master) and M.dphi == 6 and abs(M.df0(1) - 0.5) < 1e-15
+
+
+# ---------------------------------------------------------------- find_damp
+def test_master_damp_sweep_and_find_damp_driver(golden_dir, tmp_path, monkeypatch):
+    from epstan_amd import fit, find_damp
+    from oracle import ep_oracle as eo
+    z = np.load(os.path.join(golden_dir, 'damp_sweep.npz'))
+    runs = np.load(os.path.join(golden_dir, 'master_run.npz'))
+    M = _master(runs, 'smooth', 0.5)
+    M.run(2, verbose=False, seed=3)
+    # put the golden state into the host mirrors: the sweep reads the device copies
+    M.Qi[...] = z['g9_Qi']; M.ri[...] = z['g9_ri']
+    M._upload_sites()
+    M.engine.set_sites(2, z['g9_dQi'], z['g9_dri'])                 # EPX_DQI
+    res = M.damp_sweep(z['g9_damps'], z['g9_m_target'], z['g9_S_target'], z['g9_samp_target'])
+    np.testing.assert_array_equal(res['global_pd'], z['g9_global_pd'])
+    np.testing.assert_array_equal(res['cav_pd'], z['g9_cav_pd'])
+    np.testing.assert_allclose(res['mses'], z['g9_mses'], rtol=1e-9, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(res['kls'], z['g9_kls'], rtol=1e-9, atol=1e-10, equal_nan=True)
+    np.testing.assert_allclose(res['lls'], z['g9_lls'], rtol=1e-9, atol=1e-8, equal_nan=True)
+    # run(..., sweep=...) logs one sweep per iteration and the accepted damping factor
+    M2 = _master(runs, 'smooth', 0.5)
+    sw = dict(damps=find_damp.default_damps(), m_target=z['g9_m_target'], S_target=z['g9_S_target'])
+    assert M2.run(3, verbose=False, seed=3, sweep=sw)[0] == 0
+    assert len(M2.sweep_log) == 3 and len(M2.df_log) == 3 and M2.df_log[0] == 0.5
+    assert M2.sweep_log[0]['kls'].shape == (31,) and np.all(np.isnan(M2.sweep_log[0]['lls']))
+    # the trajectory is the same as without the sweep
+    M3 = _master(runs, 'smooth', 0.5)
+    M3.run(3, verbose=False, seed=3)
+    np.testing.assert_array_equal(M2.Qi, M3.Qi)
+    assert M2.df_log == M3.df_log
+    # the driver: schema of find_damp_K<K>.npz (find_damp.py:246-256)
+    monkeypatch.setattr(fit, 'RES_PATH', str(tmp_path))
+    conf = fit.configurations(J=4, D=3, K=4, npg=15, siter=40, chains=2)
+    tgt = dict(m_target=np.zeros(4), S_target=np.eye(4), samp_target=np.random.RandomState(0).randn(50, 4))
+    out = find_damp.main('m1b', iters=2, target=tgt, conf=conf, seed=1, verbose=False, _engine_factory=factory)
+    assert out['kls'].shape == (2, 31) and out['kls_selected'].shape == (3,) and out['damps'].shape == (31,)
+    assert np.all(np.isfinite(out['kls_selected'])) and np.all(np.isfinite(out['lls_selected']))
+    assert np.all(out['damps_selected'] > 0)
+    saved = np.load(os.path.join(str(tmp_path), 'find_damp_K4.npz'))
+    assert set(saved.files) == {'damps', 'mses', 'lls', 'kls', 'damps_selected', 'mses_selected', 'lls_selected',
+                                'kls_selected'}

@@ -135,3 +135,16 @@ def test_master_run_resume(runs):
     assert M.iter == int(runs['g6_resume_iter'])
     np.testing.assert_allclose(m_s, runs['g6_resume_m'], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(S_s, runs['g6_resume_S'], rtol=1e-8, atol=1e-10)
+
+
+# ---------------------------------------------------------------- damping sweep (find_damp.py:146-173)
+def test_damp_sweep_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'damp_sweep.npz'))
+    out = eo.damp_sweep(z['g9_Q0'], z['g9_r0'], z['g9_Qi'], z['g9_ri'], z['g9_dQi'], z['g9_dri'], z['g9_damps'],
+                        z['g9_m_target'], z['g9_S_target'], z['g9_samp_target'])
+    np.testing.assert_array_equal(out[:, 0] > 0, z['g9_global_pd'])
+    np.testing.assert_array_equal(out[:, 1] > 0, z['g9_cav_pd'])
+    assert z['g9_cav_pd'].sum() >= 31 and (~z['g9_cav_pd']).sum() >= 3 and (~z['g9_global_pd']).sum() >= 1
+    np.testing.assert_allclose(out[:, 2], z['g9_mses'], rtol=RTOL, atol=ATOL, equal_nan=True)
+    np.testing.assert_allclose(out[:, 3], z['g9_kls'], rtol=RTOL, atol=1e-10, equal_nan=True)
+    np.testing.assert_allclose(out[:, 4], z['g9_lls'], rtol=RTOL, atol=1e-8, equal_nan=True)
