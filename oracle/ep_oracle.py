@@ -489,3 +489,36 @@ def site_logdensity(model, theta, X, y, mu, Omega):
         else:
             g[d] = da * sa - eta; g[d + 1:] = db * sb - etb
     return lp, g
+
+
+def site_logdensity_groups(model, theta, X, y, j_ind, mu, Omega):
+    """lp(theta) of the multi-group programs experiment/models/m{1..5}b.stan (K < J): `J` groups
+    in the site, `j_ind[n]` (0-based) the group of row n; theta = [phi, eta (J), etb (J x D)].
+    Value only (the tests differentiate it numerically)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    n, D = X.shape
+    base = model.replace('_sg', '')
+    d = model_dims(base + '_sg', D)[0]
+    j_ind = np.asarray(j_ind)
+    J = int(j_ind.max()) + 1
+    phi = theta[:d]
+    eta = theta[d:d + J]
+    etb = theta[d + J:].reshape(J, D) if base != 'm1b' else None
+    if base == 'm1b':                                   # m1b.stan:24-38
+        alpha = eta * np.exp(phi[0]); beta = np.tile(phi[1:], (J, 1))
+    elif base == 'm2b':                                 # m2b.stan
+        alpha = eta * np.exp(phi[0]); beta = etb * np.exp(phi[1])
+    elif base == 'm3b':                                 # m3b.stan
+        alpha = eta * np.exp(phi[0]); beta = etb * np.exp(phi[1:])[None, :]
+    else:                                               # m4b.stan:33-41, m5b.stan
+        alpha = phi[0] + eta * np.exp(phi[1]); beta = phi[2:2 + D][None, :] + etb * np.exp(phi[2 + D:])[None, :]
+    f = alpha[j_ind] + np.einsum('nd,nd->n', X, beta[j_ind])
+    yy = np.asarray(y, dtype=np.float64)
+    lp = np.sum(yy * f - np.logaddexp(0.0, f))
+    v = phi - mu
+    lp += -0.5 * v.dot(Omega.dot(v))
+    if base == 'm5b':
+        lp += -np.sum(np.abs(eta)) - np.sum(np.abs(etb))
+    else:
+        lp += -0.5 * np.sum(eta**2) - (0.5 * np.sum(etb**2) if etb is not None else 0.0)
+    return lp

@@ -134,10 +134,26 @@ typedef struct {
     const int32_t *y;  /* n, 0/1 */
     const double *mu;  /* d cavity mean   (Worker.vec, method.py:221) */
     const double *Om;  /* d x d cavity precision, symmetric (Worker.Mat, :222) */
-    double *beta;      /* D scratch */
-    double *db;        /* D scratch */
+    /* groups of the site (K < J, experiment/models/m*b.stan `j_ind`): ng contiguous row blocks,
+     * gl[j]..gl[j+1] relative to the site's first row; NULL = one group (the `_sg` programs) */
+    int ng;
+    const int64_t *gl;
+    double *beta;      /* ng x D scratch */
+    double *db;        /* ng x D scratch */
+    double *da;        /* ng scratch */
     double *Ov;        /* d scratch */
 } site_t;
+
+/* sampled coordinates of a site with ng groups: phi (d), eta (ng), etb (ng x D, group-major) */
+int epo_npar_groups(int model, int D, int ng) {
+    const int d = epo_dphi(model, D);
+    if (d < 0 || ng < 1) return -1;
+    return d + ng * (model == M1B ? 1 : 1 + D);
+}
+static size_t site_scratch(int D, int d, int ng) { return (size_t)2 * ng * D + ng + d; }
+static void site_bind_scratch(site_t *s, double *w) {
+    s->beta = w; s->db = w + (size_t)s->ng * s->D; s->da = s->db + (size_t)s->ng * s->D; s->Ov = s->da + s->ng;
+}
 
 /* log(1+exp(-|f|)) and sigmoid(f) sharing one exp */
 static inline void logistic_terms(double f, double y, double *ll, double *g) {
@@ -148,45 +164,41 @@ static inline void logistic_terms(double f, double y, double *ll, double *g) {
     *g = y - s;
 }
 
-/* m*b_sg.stan model blocks; SURVEY.md Appendix A */
+/* m*b_sg.stan / m*b.stan model blocks; SURVEY.md Appendix A.  With ng groups every group j has
+ * its own eta_j (and etb_j), alpha_j, beta_j (m4b.stan:33-41); the hyper-parameters phi are shared. */
 static double site_lp_grad(const site_t *s, const double *th, double *grad) {
-    const int D = s->D, d = s->d, n = s->n, model = s->model;
+    const int D = s->D, d = s->d, model = s->model, ng = s->ng;
     const double *phi = th;
-    const double eta = th[d];
-    const double *etb = th + d + 1;
-    double alpha, sa;
-    double *beta = s->beta;
-    switch (model) {
-    case M1B:
-        sa = exp(phi[0]); alpha = eta * sa;
-        for (int j = 0; j < D; ++j) beta[j] = phi[1 + j];
-        break;
-    case M2B: {
-        sa = exp(phi[0]); alpha = eta * sa;
-        double sb = exp(phi[1]);
-        for (int j = 0; j < D; ++j) beta[j] = etb[j] * sb;
-        break; }
-    case M3B:
-        sa = exp(phi[0]); alpha = eta * sa;
-        for (int j = 0; j < D; ++j) beta[j] = etb[j] * exp(phi[1 + j]);
-        break;
-    default: /* M4B, M5B */
-        sa = exp(phi[1]); alpha = phi[0] + eta * sa;
-        for (int j = 0; j < D; ++j) beta[j] = phi[2 + j] + etb[j] * exp(phi[2 + D + j]);
-        break;
-    }
-    /* y ~ bernoulli_logit(alpha + X*beta): one fused pass over the rows */
-    double ll = 0.0, da = 0.0;
-    double *db = s->db;
-    for (int j = 0; j < D; ++j) db[j] = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const double *x = s->X + (size_t)i * D;
-        double f = alpha;
-        for (int j = 0; j < D; ++j) f += x[j] * beta[j];
-        double l, g;
-        logistic_terms(f, (double)s->y[i], &l, &g);
-        ll += l; da += g;
-        for (int j = 0; j < D; ++j) db[j] += g * x[j];
+    const double *eta = th + d;
+    const double *etb = th + d + ng;                    /* [group][D] */
+    const int laplace = (model == M5B);
+    const double sa = exp(model >= M4B ? phi[1] : phi[0]);
+    const double a0 = model >= M4B ? phi[0] : 0.0;
+    double ll = 0.0;
+    for (int j = 0; j < ng; ++j) {
+        double *beta = s->beta + (size_t)j * D, *db = s->db + (size_t)j * D;
+        const double *eb = etb + (size_t)j * D;
+        const double alpha = a0 + eta[j] * sa;
+        switch (model) {
+        case M1B: for (int c = 0; c < D; ++c) beta[c] = phi[1 + c]; break;
+        case M2B: { const double sb = exp(phi[1]); for (int c = 0; c < D; ++c) beta[c] = eb[c] * sb; break; }
+        case M3B: for (int c = 0; c < D; ++c) beta[c] = eb[c] * exp(phi[1 + c]); break;
+        default:  for (int c = 0; c < D; ++c) beta[c] = phi[2 + c] + eb[c] * exp(phi[2 + D + c]); break;
+        }
+        /* y ~ bernoulli_logit(alpha_j + X*beta_j): one fused pass over the rows of the group */
+        double da = 0.0;
+        for (int c = 0; c < D; ++c) db[c] = 0.0;
+        const int64_t lo = s->gl ? s->gl[j] : 0, hi = s->gl ? s->gl[j + 1] : s->n;
+        for (int64_t i = lo; i < hi; ++i) {
+            const double *x = s->X + (size_t)i * D;
+            double f = alpha;
+            for (int c = 0; c < D; ++c) f += x[c] * beta[c];
+            double l, g;
+            logistic_terms(f, (double)s->y[i], &l, &g);
+            ll += l; da += g;
+            for (int c = 0; c < D; ++c) db[c] += g * x[c];
+        }
+        s->da[j] = da;
     }
     /* phi ~ multi_normal_prec(mu_phi, Omega_phi) */
     double quad = 0.0;
@@ -199,64 +211,71 @@ static double site_lp_grad(const site_t *s, const double *th, double *grad) {
     }
     double lp = -0.5 * quad + ll;
     for (int i = 0; i < d; ++i) grad[i] = -s->Ov[i];
-    const int laplace = (model == M5B);
-    /* eta, etb ~ normal(0,1) (double_exponential(0,1) for m5b_sg.stan:40-41) */
-    if (laplace) lp -= fabs(eta); else lp -= 0.5 * eta * eta;
-    if (model != M1B) {
-        for (int j = 0; j < D; ++j)
-            lp -= laplace ? fabs(etb[j]) : 0.5 * etb[j] * etb[j];
-    }
 #define SGN(v) (((v) > 0) - ((v) < 0))
-    switch (model) {
-    case M1B:
-        grad[0] += da * eta * sa;
-        for (int j = 0; j < D; ++j) grad[1 + j] += db[j];
-        grad[d] = da * sa - eta;
-        break;
-    case M2B: {
-        double sb = exp(phi[1]), dot = 0.0;
-        for (int j = 0; j < D; ++j) dot += db[j] * etb[j];
-        grad[0] += da * eta * sa;
-        grad[1] += dot * sb;
-        grad[d] = da * sa - eta;
-        for (int j = 0; j < D; ++j) grad[d + 1 + j] = db[j] * sb - etb[j];
-        break; }
-    case M3B:
-        grad[0] += da * eta * sa;
-        for (int j = 0; j < D; ++j) {
-            double sb = exp(phi[1 + j]);
-            grad[1 + j] += db[j] * etb[j] * sb;
-            grad[d + 1 + j] = db[j] * sb - etb[j];
+    /* eta, etb ~ normal(0,1) (double_exponential(0,1) for m5b*.stan:40-41), and the chain rule */
+    for (int j = 0; j < ng; ++j) {
+        const double *db = s->db + (size_t)j * D, *eb = etb + (size_t)j * D;
+        const double da = s->da[j], et = eta[j];
+        double *geb = grad + d + ng + (size_t)j * D;
+        lp -= laplace ? fabs(et) : 0.5 * et * et;
+        grad[d + j] = da * sa - (laplace ? (double)SGN(et) : et);
+        if (model != M1B)
+            for (int c = 0; c < D; ++c) lp -= laplace ? fabs(eb[c]) : 0.5 * eb[c] * eb[c];
+        switch (model) {
+        case M1B:
+            grad[0] += da * et * sa;
+            for (int c = 0; c < D; ++c) grad[1 + c] += db[c];
+            break;
+        case M2B: {
+            const double sb = exp(phi[1]);
+            double dot = 0.0;
+            for (int c = 0; c < D; ++c) dot += db[c] * eb[c];
+            grad[0] += da * et * sa;
+            grad[1] += dot * sb;
+            for (int c = 0; c < D; ++c) geb[c] = db[c] * sb - eb[c];
+            break; }
+        case M3B:
+            grad[0] += da * et * sa;
+            for (int c = 0; c < D; ++c) {
+                const double sb = exp(phi[1 + c]);
+                grad[1 + c] += db[c] * eb[c] * sb;
+                geb[c] = db[c] * sb - eb[c];
+            }
+            break;
+        default:
+            grad[0] += da;
+            grad[1] += da * et * sa;
+            for (int c = 0; c < D; ++c) {
+                const double sb = exp(phi[2 + D + c]);
+                grad[2 + c] += db[c];
+                grad[2 + D + c] += db[c] * eb[c] * sb;
+                geb[c] = db[c] * sb - (laplace ? (double)SGN(eb[c]) : eb[c]);
+            }
+            break;
         }
-        grad[d] = da * sa - eta;
-        break;
-    default:
-        grad[0] += da;
-        grad[1] += da * eta * sa;
-        for (int j = 0; j < D; ++j) {
-            double sb = exp(phi[2 + D + j]);
-            grad[2 + j] += db[j];
-            grad[2 + D + j] += db[j] * etb[j] * sb;
-            grad[d + 1 + j] = db[j] * sb - (laplace ? (double)SGN(etb[j]) : etb[j]);
-        }
-        grad[d] = da * sa - (laplace ? (double)SGN(eta) : eta);
-        break;
     }
     return lp;
 }
 
+/* gl: ng+1 row limits relative to the site's first row, or NULL with ng = 1 */
+int epo_logdensity_grad_groups(int model, int n, int D, int ng, const int64_t *gl, const double *X,
+                               const int32_t *y, const double *mu, const double *Omega,
+                               const double *theta, double *lp, double *grad) {
+    site_t s;
+    s.model = model; s.n = n; s.D = D; s.d = epo_dphi(model, D); s.ng = ng; s.gl = gl;
+    s.P = epo_npar_groups(model, D, ng);
+    if (s.d < 0 || s.P < 0) return -1;
+    s.X = X; s.y = y; s.mu = mu; s.Om = Omega;
+    double *w = (double *)malloc(sizeof(double) * site_scratch(D, s.d, ng));
+    site_bind_scratch(&s, w);
+    *lp = site_lp_grad(&s, theta, grad);
+    free(w);
+    return 0;
+}
 int epo_logdensity_grad(int model, int n, int D, const double *X, const int32_t *y,
                         const double *mu, const double *Omega, const double *theta,
                         double *lp, double *grad) {
-    site_t s;
-    s.model = model; s.n = n; s.D = D; s.d = epo_dphi(model, D); s.P = epo_npar(model, D);
-    if (s.d < 0) return -1;
-    s.X = X; s.y = y; s.mu = mu; s.Om = Omega;
-    s.beta = (double *)malloc(sizeof(double) * (2 * D + s.d));
-    s.db = s.beta + D; s.Ov = s.db + D;
-    *lp = site_lp_grad(&s, theta, grad);
-    free(s.beta);
-    return 0;
+    return epo_logdensity_grad_groups(model, n, D, 1, NULL, X, y, mu, Omega, theta, lp, grad);
 }
 
 /* ------------------------------------------------------------ NUTS chain */
@@ -503,7 +522,7 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     const int P = site_in->P, D = site_in->D, d = site_in->d;
     site_t site = *site_in;
     const size_t nvec = 24 + 4 * (size_t)EPO_MAX_DEPTH_CAP;
-    double *buf = (double *)calloc(nvec * P + 2 * D + d, sizeof(double));
+    double *buf = (double *)calloc(nvec * P + site_scratch(D, d, site.ng), sizeof(double));
     double *w = buf;
 #define TAKE(ptr) ptr = w; w += P
     chain_t c;
@@ -518,7 +537,7 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     c.st_psl = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
     c.st_pq = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
     c.st_pg = w; w += (size_t)EPO_MAX_DEPTH_CAP * P;
-    site.beta = w; site.db = w + D; site.Ov = w + 2 * D;
+    site_bind_scratch(&site, w);
     for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0.0;
 
     for (int i = 0; i < P; ++i) c.inv_e[i] = 1.0;
@@ -607,15 +626,55 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
  *   stats: nsites x chains x ST_COUNT
  * (site, chain) pairs are spread over `nthreads` OpenMP threads.
  */
-int epo_nuts_sites(int model, int nsites, int D, const int64_t *k_lim, const double *X,
-                   const int32_t *y, const double *mu, const double *Omega,
-                   const int64_t *seeds, int chains, int iter, int warmup, int thin,
-                   int max_depth, const double *init, double *draws, double *last,
-                   double *stats, int nthreads) {
-    const int d = epo_dphi(model, D), P = epo_npar(model, D);
-    if (d < 0 || max_depth > EPO_MAX_DEPTH_CAP || thin < 1 || warmup > iter) return -1;
+/* Group structure for the *_groups entry points: g_cnt[k] groups in site k (NULL: one each),
+ * g_lim = row limits of ALL groups in site order (sum(g_cnt)+1 entries, absolute rows).  The
+ * per-(site, chain) records of init / draws / last use the stride Pmax = max_k P_k. */
+static int sites_pmax(int model, int D, int nsites, const int32_t *g_cnt) {
+    int pm = -1;
+    for (int k = 0; k < nsites; ++k) {
+        const int p = epo_npar_groups(model, D, g_cnt ? g_cnt[k] : 1);
+        if (p < 0) return -1;
+        if (p > pm) pm = p;
+    }
+    return pm;
+}
+int epo_sites_pmax(int model, int D, int nsites, const int32_t *g_cnt) { return sites_pmax(model, D, nsites, g_cnt); }
+
+static void bind_site(site_t *s, int model, int D, int d, int k, const int64_t *k_lim, const double *X,
+                      const int32_t *y, const double *mu, const double *Omega, const int32_t *g_cnt,
+                      const int64_t *g_off, const int64_t *g_lim, int64_t *gl_rel) {
+    s->model = model; s->D = D; s->d = d;
+    s->n = (int)(k_lim[k + 1] - k_lim[k]);
+    s->X = X + (size_t)k_lim[k] * D; s->y = y + k_lim[k];
+    s->mu = mu + (size_t)k * d; s->Om = Omega + (size_t)k * d * d;
+    s->beta = s->db = s->da = s->Ov = NULL;
+    s->ng = g_cnt ? g_cnt[k] : 1;
+    s->gl = NULL;
+    if (g_cnt) {
+        for (int j = 0; j <= s->ng; ++j) gl_rel[j] = g_lim[g_off[k] + j] - k_lim[k];
+        s->gl = gl_rel;
+    }
+    s->P = epo_npar_groups(model, D, s->ng);
+}
+
+int epo_nuts_sites_groups(int model, int nsites, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                          const int64_t *g_lim, const double *X,
+                          const int32_t *y, const double *mu, const double *Omega,
+                          const int64_t *seeds, int chains, int iter, int warmup, int thin,
+                          int max_depth, const double *init, double *draws, double *last,
+                          double *stats, int nthreads) {
+    const int d = epo_dphi(model, D), Pm = sites_pmax(model, D, nsites, g_cnt);
+    if (d < 0 || Pm < 0 || max_depth > EPO_MAX_DEPTH_CAP || thin < 1 || warmup > iter) return -1;
     const int nkeep = (iter - warmup + thin - 1) / thin;
     const long njobs = (long)nsites * chains;
+    int64_t *g_off = (int64_t *)malloc(sizeof(int64_t) * (nsites + 1));
+    g_off[0] = 0;
+    int ngmax = 1;
+    for (int k = 0; k < nsites; ++k) {
+        const int g = g_cnt ? g_cnt[k] : 1;
+        g_off[k + 1] = g_off[k] + g;
+        if (g > ngmax) ngmax = g;
+    }
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -623,48 +682,91 @@ int epo_nuts_sites(int model, int nsites, int D, const int64_t *k_lim, const dou
     for (long job = 0; job < njobs; ++job) {
         int k = (int)(job / chains), c = (int)(job % chains);
         site_t s;
-        s.model = model; s.D = D; s.d = d; s.P = P;
-        s.n = (int)(k_lim[k + 1] - k_lim[k]);
-        s.X = X + (size_t)k_lim[k] * D; s.y = y + k_lim[k];
-        s.mu = mu + (size_t)k * d; s.Om = Omega + (size_t)k * d * d;
-        s.beta = s.db = s.Ov = NULL;
+        int64_t *gl_rel = (int64_t *)malloc(sizeof(int64_t) * (ngmax + 1));
+        bind_site(&s, model, D, d, k, k_lim, X, y, mu, Omega, g_cnt, g_off, g_lim, gl_rel);
         size_t jc = (size_t)k * chains + c;
+        /* records are Pm wide; a site with fewer coordinates uses the leading P_k of each */
+        double *dr = (double *)calloc((size_t)nkeep * s.P + 2 * (size_t)s.P, sizeof(double));
+        double *la = dr + (size_t)nkeep * s.P, *in0 = la + s.P;
+        if (init) memcpy(in0, init + jc * Pm, sizeof(double) * s.P);
         run_chain(&s, (uint64_t)seeds[k], c, iter, warmup, thin, max_depth,
-                  init ? init + jc * P : NULL, draws + jc * nkeep * P, last + jc * P,
-                  stats + jc * ST_COUNT, -1.0, NULL, 0);
+                  init ? in0 : NULL, dr, la, stats + jc * ST_COUNT, -1.0, NULL, 0);
+        for (int t = 0; t < nkeep; ++t) {
+            double *dst = draws + (jc * nkeep + t) * Pm;
+            memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);
+            for (int e = s.P; e < Pm; ++e) dst[e] = 0.0;
+        }
+        memcpy(last + jc * Pm, la, sizeof(double) * s.P);
+        for (int e = s.P; e < Pm; ++e) last[jc * Pm + e] = 0.0;
+        free(dr); free(gl_rel);
     }
+    free(g_off);
     return 0;
+}
+int epo_nuts_sites(int model, int nsites, int D, const int64_t *k_lim, const double *X,
+                   const int32_t *y, const double *mu, const double *Omega,
+                   const int64_t *seeds, int chains, int iter, int warmup, int thin,
+                   int max_depth, const double *init, double *draws, double *last,
+                   double *stats, int nthreads) {
+    return epo_nuts_sites_groups(model, nsites, D, k_lim, NULL, NULL, X, y, mu, Omega, seeds, chains, iter,
+                                 warmup, thin, max_depth, init, draws, last, stats, nthreads);
 }
 
 /* TEST HOOK: `nt` plain transitions (no adaptation) per (site, chain) from given
  * positions q0 with given step sizes eps (nsites x chains) and diagonal inverse
  * metrics inv_e (nsites x chains x P); the random stream is the one a full run
  * uses at transition t_offset, t_offset+1, ...  draws: nsites x chains x nt x P. */
-int epo_nuts_transitions(int model, int nsites, int D, const int64_t *k_lim, const double *X,
-                         const int32_t *y, const double *mu, const double *Omega,
-                         const int64_t *seeds, int chains, int nt, int t_offset, int max_depth,
-                         const double *q0, const double *eps, const double *inv_e,
-                         double *draws, double *last, double *stats) {
-    const int d = epo_dphi(model, D), P = epo_npar(model, D);
-    if (d < 0 || max_depth > EPO_MAX_DEPTH_CAP) return -1;
+int epo_nuts_transitions_groups(int model, int nsites, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                                const int64_t *g_lim, const double *X,
+                                const int32_t *y, const double *mu, const double *Omega,
+                                const int64_t *seeds, int chains, int nt, int t_offset, int max_depth,
+                                const double *q0, const double *eps, const double *inv_e,
+                                double *draws, double *last, double *stats) {
+    const int d = epo_dphi(model, D), Pm = sites_pmax(model, D, nsites, g_cnt);
+    if (d < 0 || Pm < 0 || max_depth > EPO_MAX_DEPTH_CAP) return -1;
     const long njobs = (long)nsites * chains;
+    int64_t *g_off = (int64_t *)malloc(sizeof(int64_t) * (nsites + 1));
+    g_off[0] = 0;
+    int ngmax = 1;
+    for (int k = 0; k < nsites; ++k) {
+        const int g = g_cnt ? g_cnt[k] : 1;
+        g_off[k + 1] = g_off[k] + g;
+        if (g > ngmax) ngmax = g;
+    }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (long job = 0; job < njobs; ++job) {
         int k = (int)(job / chains), c = (int)(job % chains);
         site_t s;
-        s.model = model; s.D = D; s.d = d; s.P = P;
-        s.n = (int)(k_lim[k + 1] - k_lim[k]);
-        s.X = X + (size_t)k_lim[k] * D; s.y = y + k_lim[k];
-        s.mu = mu + (size_t)k * d; s.Om = Omega + (size_t)k * d * d;
-        s.beta = s.db = s.Ov = NULL;
+        int64_t *gl_rel = (int64_t *)malloc(sizeof(int64_t) * (ngmax + 1));
+        bind_site(&s, model, D, d, k, k_lim, X, y, mu, Omega, g_cnt, g_off, g_lim, gl_rel);
         size_t jc = (size_t)k * chains + c;
-        run_chain(&s, (uint64_t)seeds[k], c, nt, 0, 1, max_depth, q0 + jc * P,
-                  draws + jc * nt * P, last + jc * P, stats + jc * ST_COUNT, eps[jc],
-                  inv_e + jc * P, t_offset);
+        double *dr = (double *)calloc((size_t)nt * s.P + 3 * (size_t)s.P, sizeof(double));
+        double *la = dr + (size_t)nt * s.P, *in0 = la + s.P, *ie = in0 + s.P;
+        memcpy(in0, q0 + jc * Pm, sizeof(double) * s.P);
+        memcpy(ie, inv_e + jc * Pm, sizeof(double) * s.P);
+        run_chain(&s, (uint64_t)seeds[k], c, nt, 0, 1, max_depth, in0, dr, la, stats + jc * ST_COUNT, eps[jc],
+                  ie, t_offset);
+        for (int t = 0; t < nt; ++t) {
+            double *dst = draws + (jc * nt + t) * Pm;
+            memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);
+            for (int e = s.P; e < Pm; ++e) dst[e] = 0.0;
+        }
+        memcpy(last + jc * Pm, la, sizeof(double) * s.P);
+        for (int e = s.P; e < Pm; ++e) last[jc * Pm + e] = 0.0;
+        free(dr); free(gl_rel);
     }
+    free(g_off);
     return 0;
+}
+int epo_nuts_transitions(int model, int nsites, int D, const int64_t *k_lim, const double *X,
+                         const int32_t *y, const double *mu, const double *Omega,
+                         const int64_t *seeds, int chains, int nt, int t_offset, int max_depth,
+                         const double *q0, const double *eps, const double *inv_e,
+                         double *draws, double *last, double *stats) {
+    return epo_nuts_transitions_groups(model, nsites, D, k_lim, NULL, NULL, X, y, mu, Omega, seeds, chains, nt,
+                                       t_offset, max_depth, q0, eps, inv_e, draws, last, stats);
 }
 
 int epo_num_threads(void) {

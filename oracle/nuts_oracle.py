@@ -12,7 +12,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libepx_oracle.so')
 
-MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4}
+MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4,
+             # the multi-group programs (K < J, experiment/models/m*b.stan): same densities, several
+             # (eta, etb) blocks per site
+             'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4}
 STAT_NAMES = ('stepsize_mean', 'stepsize_final', 'nleap', 'ngrad', 'ndiv',
               'accept_mean', 'depth_mean', 'fail')
 _lib = None
@@ -32,6 +35,7 @@ def lib():
         _lib = ctypes.CDLL(LIB)
         _lib.epo_dphi.restype = ctypes.c_int
         _lib.epo_npar.restype = ctypes.c_int
+        _lib.epo_npar_groups.restype = ctypes.c_int
         _lib.epo_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -40,13 +44,27 @@ def _p(a, t=ctypes.c_double):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def dims(model, D):
+def dims(model, D, ng=1):
+    """(dphi, sampled coordinates) of a site with ng groups."""
     L = lib()
     m = MODEL_IDS[model]
-    return L.epo_dphi(m, D), L.epo_npar(m, D)
+    return L.epo_dphi(m, D), L.epo_npar_groups(m, D, int(ng))
 
 
-def logdensity_grad(model, X, y, mu, Omega, theta):
+def _groups(k_lim, g_cnt, g_lim):
+    """Normalise the group structure: g_cnt (K) groups per site, g_lim (sum+1) absolute row limits."""
+    if g_cnt is None:
+        return None, None, None
+    g_cnt = np.ascontiguousarray(g_cnt, dtype=np.int32)
+    g_lim = np.ascontiguousarray(g_lim, dtype=np.int64)
+    assert g_lim.shape[0] == g_cnt.sum() + 1
+    off = np.concatenate(([0], np.cumsum(g_cnt)))
+    assert np.array_equal(g_lim[off], np.asarray(k_lim)), 'group limits must nest in the site limits'
+    return g_cnt, g_lim, off
+
+
+def logdensity_grad(model, X, y, mu, Omega, theta, gl=None):
+    """gl: row limits of the site's groups relative to its first row (ng+1 entries), or None."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.int32)
@@ -56,23 +74,30 @@ def logdensity_grad(model, X, y, mu, Omega, theta):
     n, D = X.shape
     lp = ctypes.c_double()
     g = np.zeros(th.shape[0])
-    rc = L.epo_logdensity_grad(MODEL_IDS[model], n, D, _p(X), _p(y, ctypes.c_int32),
-                               _p(mu), _p(Om), _p(th), ctypes.byref(lp), _p(g))
+    if gl is None:
+        ng, glp = 1, None
+    else:
+        gl = np.ascontiguousarray(gl, dtype=np.int64)
+        ng, glp = gl.shape[0] - 1, _p(gl, ctypes.c_int64)
+    rc = L.epo_logdensity_grad_groups(MODEL_IDS[model], n, D, ng, glp, _p(X), _p(y, ctypes.c_int32),
+                                      _p(mu), _p(Om), _p(th), ctypes.byref(lp), _p(g))
     assert rc == 0
     return lp.value, g
 
 
 def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=None,
-               thin=1, max_depth=10, init=None, nthreads=0):
+               thin=1, max_depth=10, init=None, nthreads=0, g_cnt=None, g_lim=None):
     """Sample every site; returns (draws (K,chains,nkeep,P), last (K,chains,P),
-    stats (K,chains,8)). mu (K,d), Omega (K,d,d) symmetric."""
+    stats (K,chains,8)). mu (K,d), Omega (K,d,d) symmetric.  With groups (g_cnt, g_lim) P is the
+    largest coordinate count over the sites and shorter sites are zero padded."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.int32)
     k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
     K = k_lim.shape[0] - 1
     D = X.shape[1]
-    d, P = dims(model, D)
+    g_cnt, g_lim, _ = _groups(k_lim, g_cnt, g_lim)
+    d, P = dims(model, D, 1 if g_cnt is None else int(g_cnt.max()))
     mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(K, d)
     Om = np.ascontiguousarray(Omega, dtype=np.float64).reshape(K, d, d)
     seeds = np.ascontiguousarray(seeds, dtype=np.int64)
@@ -86,17 +111,19 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
     if init is not None:
         init = np.ascontiguousarray(init, dtype=np.float64).reshape(K, chains, P)
         ip = _p(init)
-    rc = L.epo_nuts_sites(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64), _p(X),
-                          _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
-                          chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
-                          _p(stats), nthreads)
+    rc = L.epo_nuts_sites_groups(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
+                                 None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
+                                 None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
+                                 _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
+                                 chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
+                                 _p(stats), nthreads)
     if rc != 0:
         raise ValueError('epo_nuts_sites rc=%d' % rc)
     return draws, last, stats
 
 
 def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1, t_offset=0,
-                     max_depth=10):
+                     max_depth=10, g_cnt=None, g_lim=None):
     """TEST HOOK: nt un-adapted transitions per (site, chain) from q0 (K,chains,P)
     with step sizes eps (K,chains) and inverse metrics inv_e (K,chains,P)."""
     L = lib()
@@ -105,7 +132,8 @@ def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1,
     k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
     K = k_lim.shape[0] - 1
     D = X.shape[1]
-    d, P = dims(model, D)
+    g_cnt, g_lim, _ = _groups(k_lim, g_cnt, g_lim)
+    d, P = dims(model, D, 1 if g_cnt is None else int(g_cnt.max()))
     q0 = np.ascontiguousarray(q0, dtype=np.float64)
     chains = q0.shape[1]
     mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(K, d)
@@ -116,7 +144,9 @@ def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1,
     draws = np.zeros((K, chains, nt, P))
     last = np.zeros((K, chains, P))
     stats = np.zeros((K, chains, 8))
-    rc = L.epo_nuts_transitions(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64), _p(X),
+    rc = L.epo_nuts_transitions_groups(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
+                                None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
+                                None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
                                 _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
                                 chains, nt, t_offset, max_depth, _p(q0), _p(eps), _p(inv_e),
                                 _p(draws), _p(last), _p(stats))

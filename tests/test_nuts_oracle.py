@@ -109,3 +109,68 @@ def test_thin_and_warm_start_shapes():
     dr2, _, _ = no.nuts_sites('m1b_sg', X, y, [0, 20], mu[None], Om[None], [1], chains=2, iter=40,
                               warmup=10, thin=3)
     np.testing.assert_array_equal(dr, dr2)
+
+
+# ---------------------------------------------------------------- multi-group sites (K < J)
+@pytest.mark.parametrize('model', ['m1b', 'm2b', 'm3b', 'm4b', 'm5b'])
+@pytest.mark.parametrize('D,sizes', [(3, [5, 1, 9]), (6, [20, 13]), (4, [7])])
+def test_multigroup_density_matches_stan_program_and_finite_differences(model, D, sizes):
+    rng = np.random.RandomState(D + len(sizes))
+    n = int(np.sum(sizes)); ng = len(sizes)
+    X = rng.randn(n, D); y = (rng.rand(n) < 0.5).astype(int)
+    gl = np.concatenate(([0], np.cumsum(sizes)))
+    j_ind = np.repeat(np.arange(ng), sizes)
+    d, P = no.dims(model, D, ng)
+    assert P == d + ng * (1 if model == 'm1b' else 1 + D)
+    A = rng.randn(d, d + 2); Om = A.dot(A.T) / d + np.eye(d); mu = rng.randn(d) * 0.3
+    th = rng.randn(P) * 0.4
+    lp, g = no.logdensity_grad(model, X, y, mu, Om, th, gl=gl)
+    assert abs(lp - eo.site_logdensity_groups(model, th, X, y, j_ind, mu, Om)) < 1e-10 * max(1.0, abs(lp))
+    h = 1e-6
+    for e in range(P):
+        tp, tm = th.copy(), th.copy()
+        tp[e] += h; tm[e] -= h
+        fd = (eo.site_logdensity_groups(model, tp, X, y, j_ind, mu, Om)
+              - eo.site_logdensity_groups(model, tm, X, y, j_ind, mu, Om)) / (2 * h)
+        if model == 'm5b' and e >= d and abs(th[e]) < 2 * h:
+            continue                                    # |x| is not differentiable at 0
+        assert abs(fd - g[e]) < 2e-6 * max(1.0, abs(g[e])), (e, fd, g[e])
+    if ng == 1:                                         # one group = the `_sg` program
+        lp1, g1 = no.logdensity_grad(model + '_sg', X, y, mu, Om, th)
+        assert lp1 == lp and np.array_equal(g1, g)
+
+
+def test_multigroup_sampler_against_importance_sampling():
+    """Moments of the multi-group sampler against self-normalised importance sampling of the
+    independent NumPy density (a Gaussian proposal fitted to the draws and widened)."""
+    rng = np.random.RandomState(5)
+    D, sizes = 2, [6, 3, 8]
+    n = int(np.sum(sizes))
+    X = rng.randn(n, D); y = (rng.rand(n) < 0.5).astype(int)
+    k_lim = np.array([0, n]); g_cnt = np.array([3]); g_lim = np.concatenate(([0], np.cumsum(sizes)))
+    j_ind = np.repeat(np.arange(3), sizes)
+    d, P = no.dims('m4b', D, 3)
+    Om = np.diag(rng.uniform(3.0, 8.0, size=d)); mu = rng.randn(d) * 0.2
+    draws, last, stats = no.nuts_sites('m4b', X, y, k_lim, mu[None], Om[None], np.array([3]), chains=4, iter=3000,
+                                       g_cnt=g_cnt, g_lim=g_lim)
+    assert stats[0, :, 7].sum() == 0 and stats[0, :, 4].sum() < 30
+    samp = draws[0].reshape(-1, P)
+    m, C = samp.mean(0), np.cov(samp.T)
+    L = np.linalg.cholesky(C * 1.6)
+    z = rng.randn(30000, P)
+    prop = m + z.dot(L.T)
+    logq = -0.5 * np.sum(z * z, axis=1)
+    logp = np.array([eo.site_logdensity_groups('m4b', t, X, y, j_ind, mu, Om) for t in prop])
+    w = np.exp(logp - logq - np.max(logp - logq)); w /= w.sum()
+    ess = 1.0 / np.sum(w * w)
+    assert ess > 2000, ess
+    m_is = w.dot(prop)
+    sd = np.sqrt(np.diag(C))
+    assert np.all(np.abs(m_is - m) < 0.08 * sd), np.abs(m_is - m) / sd
+    v_is = w.dot((prop - m_is)**2)
+    assert np.all(np.abs(v_is / np.diag(C) - 1.0) < 0.15), v_is / np.diag(C)
+    # one group through the groups entry point = the `_sg` program, bit for bit
+    d1 = no.nuts_sites('m4b_sg', X, y, k_lim, mu[None], Om[None], np.array([3]), chains=2, iter=60)[0]
+    d2 = no.nuts_sites('m4b', X, y, k_lim, mu[None], Om[None], np.array([3]), chains=2, iter=60,
+                       g_cnt=np.array([1]), g_lim=k_lim)[0]
+    assert np.array_equal(d1, d2)
