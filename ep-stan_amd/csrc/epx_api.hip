@@ -39,6 +39,11 @@ struct epx_ctx {
     int64_t N;
     hipStream_t stream;
     std::vector<int64_t> k_lim;
+    // multi-group sites (K < J): groups per site, device copies of the prefix sums / row limits
+    std::vector<int> g_cnt;
+    int *site_g0_d;
+    int64_t *g_lim_d;
+    int multi, ng_max, nt_max, pg;
     int n_max;
     // device buffers
     int64_t *k_lim_d;
@@ -137,6 +142,11 @@ static int set_lds(K kern, size_t bytes) {
 
 int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
                    const int32_t *y, epx_ctx **out) {
+    return epx_ctx_create_groups(device, model, K_local, D, k_lim, nullptr, nullptr, X, y, out);
+}
+
+int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                          const int64_t *g_lim, const double *X, const int32_t *y, epx_ctx **out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -159,6 +169,36 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
         if (n > c->n_max) c->n_max = (int)n;
     }
     if (k_lim[0] != 0) { delete c; return fail("k_lim[0] must be 0 (rows are rank-local)"); }
+    // groups: tiles never straddle two groups, so the tile count of a site depends on them
+    c->pg = model == EPX_M1B_SG ? 1 : 1 + D;
+    c->multi = g_cnt != nullptr;
+    c->ng_max = 1; c->nt_max = 1;
+    std::vector<int> g0((size_t)K_local + 1, 0);
+    {
+        int64_t gi = 0;
+        for (int k = 0; k < K_local; ++k) {
+            const int ng = g_cnt ? g_cnt[k] : 1;
+            if (ng < 1) { delete c; return fail("site %d has %d groups", k, ng); }
+            if (ng > c->ng_max) c->ng_max = ng;
+            int nt = 0;
+            for (int g = 0; g < ng; ++g) {
+                const int64_t lo = g_cnt ? g_lim[gi + g] : k_lim[k], hi = g_cnt ? g_lim[gi + g + 1] : k_lim[k + 1];
+                if (hi <= lo) { delete c; return fail("group %d of site %d is empty", g, k); }
+                nt += (int)((hi - lo + 15) / 16);
+            }
+            if (g_cnt && (g_lim[gi] != k_lim[k] || g_lim[gi + ng] != k_lim[k + 1])) {
+                delete c;
+                return fail("the groups of site %d do not cover its rows", k);
+            }
+            if (nt > c->nt_max) c->nt_max = nt;
+            gi += ng;
+            g0[k + 1] = (int)gi;
+        }
+        if (g_cnt) {
+            c->g_cnt.assign(g_cnt, g_cnt + K_local);
+            c->P = d + c->ng_max * c->pg;           // record stride: the largest site
+        }
+    }
     c->dense_ws = nullptr; c->dense_ws_slots = 0;
     c->draws = c->last = c->chain_stats = c->site_stats = c->stack = nullptr;
     c->seeds_d = nullptr; c->inj = nullptr; c->inj_elems = 0; c->stack_elems = 0;
@@ -169,6 +209,12 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
     HIPCHK(hipEventCreate(&c->ev1));
     const size_t K = K_local, d2 = (size_t)d * d;
     HIPCHK(dalloc(&c->k_lim_d, K + 1));
+    if (c->multi) {
+        HIPCHK(dalloc(&c->site_g0_d, K + 1));
+        HIPCHK(dalloc(&c->g_lim_d, (size_t)g0[K] + 1));
+        HIPCHK(hipMemcpy(c->site_g0_d, g0.data(), (K + 1) * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->g_lim_d, g_lim, ((size_t)g0[K] + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
     // X carries a zeroed KiB behind the last row: the streaming sampler's row DMA reads full
     // 128-column images
     HIPCHK(dalloc(&c->X, (size_t)c->N * D + 128));
@@ -185,7 +231,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
     HIPCHK(dalloc(&c->tilt_mean, K * d)); HIPCHK(dalloc(&c->tilt_scatter, K * d2));
     HIPCHK(dalloc(&c->flags, K));
     HIPCHK(dalloc(&c->iflags, 4));
-    HIPCHK(dalloc(&c->dbg, 2 * (size_t)P + 1));
+    HIPCHK(dalloc(&c->dbg, 2 * (size_t)c->P + 1));
     HIPCHK(dalloc(&c->dbg_seed, 1));
     const int len = 2 * (int)(d2 + d);
     c->nslice = K_local >= 64 ? 32 : 1;
@@ -215,7 +261,7 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -416,6 +462,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     a.chains = o.chains; a.iter = o.iter; a.warmup = o.warmup; a.thin = o.thin; a.nkeep = nkeep;
     a.max_depth = o.max_depth; a.init_mode = o.init;
     a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.y32 = c->y32; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
+    a.site_g0 = c->site_g0_d; a.g_lim = c->g_lim_d; a.ngmax = c->ng_max; a.ntmax = c->nt_max;
     int nv = (c->P + 63) / 64;
     int dp = pad_dp(c->D);
     // resident layouts: enough sites to fill the 256 CUs -> one block per site, else one block
@@ -423,7 +470,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     int layout = o.layout;
     if (layout == 0) layout = count >= 192 ? 1 : 2;
     int wpc = 1;
-    bool resident = dp > 0 && nv <= 2 && layout != 3;
+    bool resident = dp > 0 && nv <= 2 && layout != 3 && !c->multi;      // several groups per site: streaming layout only
     if (resident) {
         if (layout == 1) { wpc = 1; a.cpb = o.chains < 4 ? o.chains : 4; }
         else { wpc = 4; a.cpb = 1; }
@@ -438,7 +485,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         dp = c->D <= 64 ? 64 : 128;
         a.cpb = 4; wpc = 1;
         a.stack_in_lds = 0; a.om_in_lds = 0;
-        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d);
+        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d, c->ng_max, c->nt_max);
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {
@@ -492,6 +539,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     RhatArgs ra;
     ra.k0 = k0; ra.chains = o.chains; ra.nkeep = nkeep; ra.P = c->P;
+    ra.site_g0 = c->site_g0_d; ra.d = c->d; ra.pg = c->pg;
     ra.draws = c->draws; ra.chain_stats = c->chain_stats; ra.site_stats = c->site_stats;
     hipLaunchKernelGGL(k_site_stats, dim3(count), dim3(128), 0, c->stream, ra);
     HIPCHK(hipGetLastError());

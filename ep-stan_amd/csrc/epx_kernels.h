@@ -113,6 +113,12 @@ struct NutsArgs {
     const double *cav_mu;         // K x d
     const int64_t *seeds;         // per site of the batch (index k - k0)
     const int *order;             // optional: workgroup i works on site order[i] of the batch (longest first), or NULL
+    // multi-group sites (K < J; streaming layout only): groups site_g0[k]..site_g0[k+1] with the
+    // absolute row limits g_lim[g]..g_lim[g+1]; NULL = one group per site.  P is then the record
+    // stride (largest coordinate count over the sites).
+    const int *site_g0;
+    const int64_t *g_lim;
+    int ngmax, ntmax;             // streaming layout: most groups / tiles of a site (LDS map)
     double *draws;                // K x chains x nkeep x P
     double *last;                 // K x chains x P (read when init_mode == PREV, always written)
     double *chain_stats;          // K x chains x ST_COUNT
@@ -137,11 +143,13 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
 // an LDS-DMA ring; dpb in {64, 128}, nv = ceil(P/64) <= 7.  a.stack holds, per (site of the
 // batch, chain), nuts_stream_chain_doubles() doubles (tree stack + cold store).
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream);
-size_t nuts_stream_lds_bytes(int nv, int dpb, int d);
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax);
 size_t nuts_stream_chain_doubles(int nv, int max_depth);
 
 struct RhatArgs {
     int k0, chains, nkeep, P;
+    const int *site_g0;           // multi-group sites: coordinates of site k = d + groups * pg (<= P); or NULL
+    int d, pg;
     const double *draws;          // K x chains x nkeep x P
     const double *chain_stats;    // K x chains x ST_COUNT
     double *site_stats;           // count x EPX_ST_COUNT (batch-relative)

@@ -80,30 +80,69 @@ typedef __attribute__((address_space(3))) int lds_i32;
 __device__ inline lds_f64 *lds_d(unsigned byte_off) { return reinterpret_cast<lds_f64 *>(byte_off); }
 __device__ inline lds_i32 *lds_i(unsigned byte_off) { return reinterpret_cast<lds_i32 *>(byte_off); }
 
-// byte offsets from the start of the engine's LDS block (the start of the dynamic segment)
-template <int DPB> struct StreamOffs {
-    using Gm = StreamGeom<DPB>;
-    static constexpr unsigned RING = 0;                                 // NSL slots of TR row images
-    static constexpr unsigned YRING = NSL * Gm::SLOTB;                  // NSL x TR responses (int32)
-    static constexpr unsigned BETA = YRING + NSL * TR * 4;              // DPB x 4 coefficients, [column][chain]
-    static constexpr unsigned PART = BETA + DPB * NCH * 8;              // 2 buffers x 4 waves x [chain][row] forward partials
-    static constexpr unsigned GS = PART + 2 * 4 * 64 * 8;               // 2 buffers x [chain][row] residuals
-    static constexpr unsigned GSUM = GS + 2 * 64 * 8;                   // DPB x 4 gradient wrt the coefficients, [column][chain]
-    static constexpr unsigned RED = GSUM + DPB * NCH * 8;               // 4 chains x {da, ll}
-    static constexpr unsigned ALPHA = RED + NCH * 2 * 8;                // 4 intercepts
-    static constexpr unsigned END = ALPHA + NCH * 8;
+// Byte offsets from the start of the engine's LDS block (the start of the dynamic segment).  The
+// block depends on the largest number of groups per site (K < J: several (eta, etb) blocks per
+// site, each with its own coefficients / gradient) and of tiles per site of the launch.
+struct StreamMap {
+    unsigned ring;      // NSL slots of TR row images
+    unsigned yring;     // NSL x TR responses (int32)
+    unsigned part;      // 2 buffers x 4 waves x [chain][row] forward partials
+    unsigned gs;        // 2 buffers x [chain][row] residuals
+    unsigned red;       // 4 chains x {-, ll}
+    unsigned tdesc;     // per tile: first row (int32), rows valid | group << 8 (int32)
+    unsigned beta;      // groups x DPB x 4 coefficients, [group][column][chain]
+    unsigned gsum;      // groups x DPB x 4 gradient wrt the coefficients
+    unsigned alpha;     // groups x 4 intercepts
+    unsigned da;        // groups x 4 sums of residuals
+    unsigned end;
 };
-template <int DPB> constexpr int stream_lds_bytes() { return (int)StreamOffs<DPB>::END; }
+template <int DPB> __host__ __device__ inline StreamMap stream_map(int ngmax, int ntmax) {
+    using Gm = StreamGeom<DPB>;
+    StreamMap m;
+    unsigned o = 0;
+    m.ring = o; o += NSL * Gm::SLOTB;
+    m.yring = o; o += NSL * TR * 4;
+    m.part = o; o += 2 * 4 * 64 * 8;
+    m.gs = o; o += 2 * 64 * 8;
+    m.red = o; o += NCH * 2 * 8;
+    m.tdesc = o; o += ((unsigned)ntmax * 8 + 15) / 16 * 16;
+    m.beta = o; o += (unsigned)ngmax * DPB * NCH * 8;
+    m.gsum = o; o += (unsigned)ngmax * DPB * NCH * 8;
+    m.alpha = o; o += (unsigned)ngmax * NCH * 8;
+    m.da = o; o += (unsigned)ngmax * NCH * 8;
+    m.end = o;
+    return m;
+}
 
 // what the sampler kernel touches directly (generic pointers into the same block)
 struct StreamLds {
-    double *beta_s, *Gs, *alpha_s;
-    template <int DPB> __device__ void carve(unsigned char *base) {
-        beta_s = reinterpret_cast<double *>(base + StreamOffs<DPB>::BETA);
-        Gs = reinterpret_cast<double *>(base + StreamOffs<DPB>::GSUM);
-        alpha_s = reinterpret_cast<double *>(base + StreamOffs<DPB>::ALPHA);
+    double *beta_s, *Gs, *alpha_s, *da_s;
+    int *tdesc;
+    template <int DPB> __device__ void carve(unsigned char *base, int ngmax, int ntmax) {
+        const StreamMap m = stream_map<DPB>(ngmax, ntmax);
+        beta_s = reinterpret_cast<double *>(base + m.beta);
+        Gs = reinterpret_cast<double *>(base + m.gsum);
+        alpha_s = reinterpret_cast<double *>(base + m.alpha);
+        da_s = reinterpret_cast<double *>(base + m.da);
+        tdesc = reinterpret_cast<int *>(base + m.tdesc);
     }
 };
+
+// tiles of a site: every group's rows are tiled separately (a tile never straddles two groups);
+// returns the number of tiles, fills desc (if not NULL) with {first row, rows | group << 8}
+__host__ __device__ inline int build_tiles(int ng, const long long *glim_rel, int *desc) {
+    int t = 0;
+    for (int g = 0; g < ng; ++g)
+        for (long long r = glim_rel[g]; r < glim_rel[g + 1]; r += TR) {
+            if (desc) {
+                const long long left = glim_rel[g + 1] - r;
+                desc[2 * t] = (int)r;
+                desc[2 * t + 1] = (int)(left < TR ? left : TR) | (g << 8);
+            }
+            ++t;
+        }
+    return t;
+}
 
 // ---------------------------------------------------------------------------------- loader
 // state of one pass (the sampler kernel keeps one per thread and hands its scalars to
@@ -113,6 +152,7 @@ template <int DPB> struct PassArgs {
     const double *Xg;           // first row of the site
     const int *yg;              // its responses (int32)
     int n, D, ntile;
+    int ngmax, ntmax;           // LDS map parameters of the launch
     unsigned lds0;              // LDS byte address of the engine's block
     int slot_f;                 // ring: slot of the next tile to consume
     int slot_i;                 // ring: slot the next DMA goes to       (loader)
@@ -120,7 +160,7 @@ template <int DPB> struct PassArgs {
     int wave, lane;
     unsigned off[StreamGeom<DPB>::NI];   // loader: per-lane byte offsets of the pieces of a full tile
 };
-struct PassOut { double da, ll; int slot_f, slot_i, t_i; };
+struct PassOut { double ll; int slot_f, slot_i, t_i; };
 
 template <int DPB>
 __device__ inline void loader_init(PassArgs<DPB> &pa, int lane) {
@@ -135,13 +175,14 @@ __device__ inline void loader_init(PassArgs<DPB> &pa, int lane) {
 
 // DMA of tile `tt` of the site into ring slot `slot` (executed by the loader wave only)
 template <int DPB>
-__device__ inline void ring_issue(const PassArgs<DPB> &s, int tt, int slot, int lane) {
+__device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, int tt, int slot, int lane) {
     using Gm = StreamGeom<DPB>;
-    using Of = StreamOffs<DPB>;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(s.lds0 + Of::RING + slot * Gm::SLOTB);
-    if ((tt + 1) * TR <= s.n) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(s.lds0 + M.ring + slot * Gm::SLOTB);
+    const int row0 = __builtin_amdgcn_readfirstlane(*lds_i(s.lds0 + M.tdesc + tt * 8));
+    const int nval = __builtin_amdgcn_readfirstlane(*lds_i(s.lds0 + M.tdesc + tt * 8 + 4)) & 255;
+    if (nval == TR) {
         // full tile: one scalar base + the precomputed lane offsets
-        const unsigned long long base = (unsigned long long)(s.Xg + (size_t)tt * TR * s.D);
+        const unsigned long long base = (unsigned long long)(s.Xg + (size_t)row0 * s.D);
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
         const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
         const unsigned long long sbase = ((unsigned long long)bhi << 32) | blo;
@@ -187,30 +228,30 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, int tt, int slot, int 
                 : "memory", "scc");
         }
     } else {
-        // ragged last tile: rows beyond the site are clamped to its last row
+        // ragged last tile of a group: rows beyond it are clamped to its last row
         const int rl = lane / Gm::CPR, sl = lane % Gm::CPR;
 #pragma unroll
         for (int q = 0; q < Gm::NI; ++q) {
             const int r = q * Gm::RPI + rl;
             const int c = sl ^ (r & (Gm::CPR - 1));
-            int row = tt * TR + r;
-            row = row < s.n ? row : s.n - 1;
+            const int row = row0 + (r < nval ? r : nval - 1);
             const unsigned char *src = reinterpret_cast<const unsigned char *>(s.Xg) + ((size_t)row * s.D + 2 * c) * 8;
             glds16(src, dst + q * 1024);
         }
     }
     {
-        int row = tt * TR + (lane & (TR - 1));
-        row = row < s.n ? row : s.n - 1;
-        if (lane < TR) glds4(s.yg + row, s.lds0 + Of::YRING + slot * TR * 4);
+        const int r = lane & (TR - 1);
+        const int row = row0 + (r < nval ? r : nval - 1);
+        if (lane < TR) glds4(s.yg + row, s.lds0 + M.yring + slot * TR * 4);
     }
 }
 
 // Prime the ring: the first three tiles (loader wave; the site must have at least one row).
 template <int DPB>
 __device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
+    const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax);
     for (int i = 0; i < 3; ++i) {
-        ring_issue<DPB>(s, s.t_i, s.slot_i, lane);
+        ring_issue<DPB>(s, M, s.t_i, s.slot_i, lane);
         s.t_i = s.t_i + 1 == s.ntile ? 0 : s.t_i + 1;
         s.slot_i = s.slot_i + 1 == NSL ? 0 : s.slot_i + 1;
     }
@@ -218,43 +259,59 @@ __device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
 
 // ---------------------------------------------------------------------------------- one pass
 // All six waves call stream_pass once per leapfrog (same number of barriers on every path).
-// In: beta, alpha (LDS, published by a barrier before the call).  Out: GSUM (LDS; valid on
-// return, the pass ends with a barrier), and on chain wave c: da = sum of the residuals of
-// chain c, ll = its log likelihood; the new ring position.
+// In: beta, alpha per group (LDS, published by a barrier before the call), the tile table.
+// Out (LDS; valid on return, the pass ends with a barrier): gsum[group][column][chain],
+// da[group][chain]; returned: ll of this wave's chain (chain waves) and the new ring position.
 template <int DPB>
 __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, const int *yg, int n, int D, int ntile,
-                                                             unsigned lds0, int slot_f0, int slot_i0, int t_i0,
-                                                             int wave_, int lane) {
+                                                             int ngmax, int ntmax, unsigned lds0, int slot_f0,
+                                                             int slot_i0, int t_i0, int wave_, int lane) {
     using Gm = StreamGeom<DPB>;
-    using Of = StreamOffs<DPB>;
     PassArgs<DPB> s;
     s.Xg = Xg; s.yg = yg; s.n = n; s.D = D; s.ntile = ntile; s.lds0 = lds0;
+    s.ngmax = __builtin_amdgcn_readfirstlane(ngmax); s.ntmax = __builtin_amdgcn_readfirstlane(ntmax);
     s.slot_f = slot_f0; s.slot_i = slot_i0; s.t_i = t_i0; s.wave = wave_; s.lane = lane;
     const int wave = __builtin_amdgcn_readfirstlane(s.wave);
     if (wave == NCH) loader_init<DPB>(s, lane);
+    const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax);
     const int nt = __builtin_amdgcn_readfirstlane(s.ntile);
-    const int nrow = __builtin_amdgcn_readfirstlane(s.n);
     const unsigned B0 = __builtin_amdgcn_readfirstlane(s.lds0);
     const int l15 = lane & 15, lg = lane >> 4, l3 = lane & 3;
     int slot_f = __builtin_amdgcn_readfirstlane(s.slot_f);      // slot of tile p
     int slot_l = slot_f, slot_b = slot_f;                       // slots of tiles p-1 and p-2 (set as the pipe fills)
     PassOut out;
-    out.da = 0.0; out.ll = 0.0; out.slot_i = s.slot_i; out.t_i = s.t_i;
+    out.ll = 0.0; out.slot_i = s.slot_i; out.t_i = s.t_i;
+    auto tile_group = [&](int t) { return __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + t * 8 + 4)) >> 8; };
     if (wave < NCH) {
         // ------------------------------------------------ chain waves: the two products
-        double bq[Gm::KS];                      // forward B operand: beta[k0 + lg][chain l3]
-#pragma unroll
-        for (int ks = 0; ks < Gm::KS; ++ks) bq[ks] = *lds_d(B0 + Of::BETA + ((wave * Gm::DW + 4 * ks + lg) * NCH + l3) * 8);
+        double bq[Gm::KS];                      // forward B operand: beta[group][k0 + lg][chain l3]
         double acc[Gm::MB];
 #pragma unroll
         for (int mb = 0; mb < Gm::MB; ++mb) acc[mb] = 0.0;
+        int g_bq = -1, g_acc = -1;              // group whose coefficients are in bq / whose gradient is in acc
+        int g_l = 0, g_b = 0;                   // groups of tiles p-1, p-2
         const int frow = 4 * (l15 >> 2) + lg;   // D lane of the forward product -> (row frow, chain l3)
+        auto flush = [&]() {
+#pragma unroll
+            for (int mb = 0; mb < Gm::MB; ++mb) {
+                *lds_d(B0 + M.gsum + ((g_acc * DPB + wave * Gm::DW + 16 * mb + 4 * (l15 >> 2) + lg) * NCH + l3) * 8) = acc[mb];
+                acc[mb] = 0.0;
+            }
+        };
         for (int p = 0; p < nt + 2; ++p) {
             lds_barrier();
             const bool do_f = p < nt, do_b = p >= 2;
+            int g_f = 0;
             double a[Gm::KS], bb[4], aa[4 * Gm::MB];
             if (do_f) {
-                const unsigned tile = B0 + Of::RING + slot_f * Gm::SLOTB + l15 * Gm::ROWB;
+                g_f = tile_group(p);
+                if (g_f != g_bq) {
+#pragma unroll
+                    for (int ks = 0; ks < Gm::KS; ++ks)
+                        bq[ks] = *lds_d(B0 + M.beta + ((g_f * DPB + wave * Gm::DW + 4 * ks + lg) * NCH + l3) * 8);
+                    g_bq = g_f;
+                }
+                const unsigned tile = B0 + M.ring + slot_f * Gm::SLOTB + l15 * Gm::ROWB;
 #pragma unroll
                 for (int ks = 0; ks < Gm::KS; ++ks) {
                     const int col = wave * Gm::DW + 4 * ks + lg;
@@ -262,11 +319,15 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
                 }
             }
             if (do_b) {
-                const unsigned tile = B0 + Of::RING + slot_b * Gm::SLOTB;
+                if (g_b != g_acc) {
+                    if (g_acc >= 0) flush();
+                    g_acc = g_b;
+                }
+                const unsigned tile = B0 + M.ring + slot_b * Gm::SLOTB;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int rk = 2 * ks + (lg >> 1) + 8 * (lg & 1);
-                    bb[ks] = *lds_d(B0 + Of::GS + ((p & 1) * 64 + l3 * 16 + rk) * 8);
+                    bb[ks] = *lds_d(B0 + M.gs + ((p & 1) * 64 + l3 * 16 + rk) * 8);
 #pragma unroll
                     for (int mb = 0; mb < Gm::MB; ++mb) {
                         const int col = wave * Gm::DW + 16 * mb + l15;
@@ -282,7 +343,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
                     f0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks], bq[ks], f0, 0, 0, 0);
                     f1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks + 1], bq[ks + 1], f1, 0, 0, 0);
                 }
-                *lds_d(B0 + Of::PART + (((p & 1) * 4 + wave) * 64 + l3 * 16 + frow) * 8) = f0 + f1;
+                *lds_d(B0 + M.part + (((p & 1) * 4 + wave) * 64 + l3 * 16 + frow) * 8) = f0 + f1;
             }
             if (do_b) {
 #pragma unroll
@@ -292,12 +353,10 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
                         acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[ks * Gm::MB + mb], bb[ks], acc[mb], 0, 0, 0);
             }
             slot_b = slot_l; slot_l = slot_f;
+            g_b = g_l; g_l = g_f;
             if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
         }
-        // publish G[column][chain]
-#pragma unroll
-        for (int mb = 0; mb < Gm::MB; ++mb)
-            *lds_d(B0 + Of::GSUM + ((wave * Gm::DW + 16 * mb + 4 * (l15 >> 2) + lg) * NCH + l3) * 8) = acc[mb];
+        if (g_acc >= 0) flush();                // publish G[group][column][chain] of the last group
     } else if (wave == NCH) {
         // ------------------------------------------------ loader
         int slot_i = __builtin_amdgcn_readfirstlane(s.slot_i), t_i = __builtin_amdgcn_readfirstlane(s.t_i);
@@ -305,7 +364,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
             if (p < nt) wait_vm<2 * Gm::G>();   // tile p has landed; tiles p+1, p+2 stay in flight
             lds_barrier();
             if (p < nt) {
-                ring_issue<DPB>(s, t_i, slot_i, lane);          // tile p+3 -> the slot of tile p-3
+                ring_issue<DPB>(s, M, t_i, slot_i, lane);       // tile p+3 -> the slot of tile p-3
                 t_i = t_i + 1 == nt ? 0 : t_i + 1;
                 slot_i = slot_i + 1 == NSL ? 0 : slot_i + 1;
                 slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
@@ -314,39 +373,47 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
         out.slot_i = slot_i; out.t_i = t_i;
     } else {
         // ------------------------------------------------ logistic terms: lane = (row l15, chain lg)
-        double ll = 0.0, da = 0.0;
-        const double alpha_l = *lds_d(B0 + Of::ALPHA + lg * 8);
+        double ll = 0.0;
+        for (int i = lane; i < s.ngmax * NCH; i += 64) *lds_d(B0 + M.da + i * 8) = 0.0;
         for (int p = 0; p < nt + 2; ++p) {
             lds_barrier();
             if (p >= 1 && p - 1 < nt) {
                 const int pb = (p - 1) & 1;
-                const int row = (p - 1) * TR + l15;
-                double f = alpha_l;
+                const int pk = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + (p - 1) * 8 + 4));
+                const int nval = pk & 255, grp = pk >> 8;
+                double f = *lds_d(B0 + M.alpha + (grp * NCH + lg) * 8);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) f += *lds_d(B0 + Of::PART + ((pb * 4 + w) * 64 + lane) * 8);
+                for (int w = 0; w < 4; ++w) f += *lds_d(B0 + M.part + ((pb * 4 + w) * 64 + lane) * 8);
                 double l = 0.0, g = 0.0;
-                if (row < nrow) logistic_terms(f, (double)*lds_i(B0 + Of::YRING + (slot_l * TR + l15) * 4), l, g);
-                ll += l; da += g;
-                *lds_d(B0 + Of::GS + (pb * 64 + lane) * 8) = g;
+                if (l15 < nval) logistic_terms(f, (double)*lds_i(B0 + M.yring + (slot_l * TR + l15) * 4), l, g);
+                ll += l;
+                *lds_d(B0 + M.gs + (pb * 64 + lane) * 8) = g;
+                // sum of the residuals of the tile -> da[group][chain]
+                double dsum = g;
+                dsum += dpp_d<DPP_QUAD_XOR1>(dsum); dsum += dpp_d<DPP_QUAD_XOR2>(dsum);
+                dsum += dpp_d<DPP_ROW_HALF_MIRROR>(dsum); dsum += dpp_d<DPP_ROW_MIRROR>(dsum);
+                if (l15 == 0) {
+                    lds_f64 *dp = lds_d(B0 + M.da + (grp * NCH + lg) * 8);
+                    *dp = *dp + dsum;
+                }
             }
             slot_b = slot_l; slot_l = slot_f;
             if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
         }
-        // da, ll: sum over the 16 rows of each lane group -> red[chain]
-        da += dpp_d<DPP_QUAD_XOR1>(da); ll += dpp_d<DPP_QUAD_XOR1>(ll);
-        da += dpp_d<DPP_QUAD_XOR2>(da); ll += dpp_d<DPP_QUAD_XOR2>(ll);
-        da += dpp_d<DPP_ROW_HALF_MIRROR>(da); ll += dpp_d<DPP_ROW_HALF_MIRROR>(ll);
-        da += dpp_d<DPP_ROW_MIRROR>(da); ll += dpp_d<DPP_ROW_MIRROR>(ll);
-        if (l15 == 0) { *lds_d(B0 + Of::RED + lg * 16) = da; *lds_d(B0 + Of::RED + lg * 16 + 8) = ll; }
+        // ll: sum over the 16 rows of each lane group -> red[chain]
+        ll += dpp_d<DPP_QUAD_XOR1>(ll); ll += dpp_d<DPP_QUAD_XOR2>(ll);
+        ll += dpp_d<DPP_ROW_HALF_MIRROR>(ll); ll += dpp_d<DPP_ROW_MIRROR>(ll);
+        if (l15 == 0) *lds_d(B0 + M.red + lg * 16 + 8) = ll;
     }
     out.slot_f = slot_f;
     lds_barrier();
-    if (wave < NCH) { out.da = *lds_d(B0 + Of::RED + wave * 16); out.ll = *lds_d(B0 + Of::RED + wave * 16 + 8); }
+    if (wave < NCH) out.ll = *lds_d(B0 + M.red + wave * 16 + 8);
     return out;
 }
 template <int DPB>
 __device__ inline PassOut stream_pass(const PassArgs<DPB> &s) {
-    return stream_pass_impl<DPB>(s.Xg, s.yg, s.n, s.D, s.ntile, s.lds0, s.slot_f, s.slot_i, s.t_i, s.wave, s.lane);
+    return stream_pass_impl<DPB>(s.Xg, s.yg, s.n, s.D, s.ntile, s.ngmax, s.ntmax, s.lds0, s.slot_f, s.slot_i, s.t_i,
+                                 s.wave, s.lane);
 }
 
 }  // namespace epx

@@ -535,9 +535,10 @@ k_site_stats(RhatArgs a) {
     __shared__ double red[16];
     const int sbk = blockIdx.x, k = a.k0 + sbk, tid = threadIdx.x;
     const int C = a.chains, P = a.P;
+    const int Pk = a.site_g0 ? a.d + (a.site_g0[k + 1] - a.site_g0[k]) * a.pg : P;   // this site's coordinates
     const int n = a.nkeep - (a.nkeep % 2), hlen = n / 2;
     double rmax = 0.0;
-    for (int e = tid; e < P; e += blockDim.x) {
+    for (int e = tid; e < Pk; e += blockDim.x) {
         if (hlen < 2) break;
         double mean_of_means = 0.0, var_within = 0.0;
         // two passes per half chain (numerically plain, like NumPy var)

@@ -79,13 +79,18 @@ k_nuts_stream(NutsArgs a) {
     const int k = a.k0 + sb;
     const int chain = cb * NCH + (is_chain ? wave : 0);
     const bool active = is_chain && chain < a.chains;
-    const int D = a.D, d = a.d, P = a.P, model = a.model;
+    const int D = a.D, d = a.d, model = a.model;
     const int64_t row0 = a.k_lim[k];
+    // groups of the site (K < J): ng blocks of rows, each with its own eta (and etb); the site
+    // samples P = d + ng * pg coordinates, records (draws, last, stack) use the stride a.P
+    const int g0 = a.site_g0 ? a.site_g0[k] : 0;
+    const int ng = a.site_g0 ? a.site_g0[k + 1] - g0 : 1;
+    const int P = d + ng * (model == 0 ? 1 : 1 + D);
 
     // ---- LDS carve-up
     StreamLds L;
-    L.template carve<DPB>(smem);
-    double *mu_s = reinterpret_cast<double *>(smem + stream_lds_bytes<DPB>());     // d (padded to even)
+    L.template carve<DPB>(smem, a.ngmax, a.ntmax);
+    double *mu_s = reinterpret_cast<double *>(smem + stream_map<DPB>(a.ngmax, a.ntmax).end);   // d (padded to even)
     double *vs4 = mu_s + ((d + 1) & ~1);                           // d x 4: phi - mu, [e][chain]
     double *Ovs = vs4 + d * NCH;                                   // d x 4: Omega (phi - mu)
     double *q_s = Ovs + d * NCH;                                   // 4 x PMAX
@@ -96,9 +101,28 @@ k_nuts_stream(NutsArgs a) {
 
     PassArgs<DPB> site;
     site.Xg = a.X + (size_t)row0 * D; site.yg = a.y32 + row0;
-    site.n = (int)(a.k_lim[k + 1] - row0); site.D = D; site.ntile = (site.n + TR - 1) / TR;
+    site.n = (int)(a.k_lim[k + 1] - row0); site.D = D;
+    site.ngmax = a.ngmax; site.ntmax = a.ntmax;
     site.lds0 = (unsigned)(size_t)smem; site.slot_f = 0; site.slot_i = 0; site.t_i = 0;
     site.wave = wave; site.lane = lane0;
+    {
+        // tile table: every group's rows are tiled on their own
+        int *nt_s = sh_done + 1;
+        if (tid == 0) {
+            int t = 0;
+            for (int g = 0; g < ng; ++g) {
+                const long long lo = a.g_lim ? a.g_lim[g0 + g] - row0 : 0;
+                const long long hi = a.g_lim ? a.g_lim[g0 + g + 1] - row0 : site.n;
+                for (long long r = lo; r < hi; r += TR, ++t) {
+                    L.tdesc[2 * t] = (int)r;
+                    L.tdesc[2 * t + 1] = (int)(hi - r < TR ? hi - r : TR) | (g << 8);
+                }
+            }
+            *nt_s = t;
+        }
+        __syncthreads();
+        site.ntile = *nt_s;
+    }
     if (wave == NCH) { loader_init<DPB>(site, lane0); ring_prime<DPB>(site, lane0); }
 
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
@@ -138,7 +162,7 @@ k_nuts_stream(NutsArgs a) {
         zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0;
     }
     if (active) {
-        const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        const double *lastp = a.last + ((size_t)k * a.chains + chain) * a.P;
         FORV {
             const int e = lane0 + 64 * i;
             double q0 = 0.0;
@@ -177,7 +201,7 @@ k_nuts_stream(NutsArgs a) {
     if (teacher && active) {
         eps = a.eps_in[(size_t)sb * a.chains + chain];
         if (a.inv_e_in) {
-            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * P;
+            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * a.P;
             FORV { const int e = lane0 + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
@@ -211,7 +235,7 @@ k_nuts_stream(NutsArgs a) {
         // hoists all per-element index arithmetic of the loop body (7 elements x dozens of
         // indices and predicates) out of the loop and spills it
         // (and again after the row pass, so that nothing index-like stays live across it)
-        double kin = 0.0, sa = 0, eta = 0, sb2 = 0, lpt = 0.0, ll = 0.0, da = 0.0;
+        double kin = 0.0, sa = 0, lpt = 0.0, ll = 0.0;
         {
         int lane_v = lane0;
         asm volatile("" : "+v"(lane_v));
@@ -229,25 +253,27 @@ k_nuts_stream(NutsArgs a) {
             // ---- step A (wave = chain): publish q, exp(q); alpha, beta, phi - mu
             double *qc = q_s + wave * PMAX, *eqc = eq_s + wave * PMAX;
             FORV { qc[lane + 64 * i] = zq.v[i]; eqc[lane + 64 * i] = exp_d(zq.v[i]); }
-            double alpha;
-            if (model == 0) { sa = eqc[0]; eta = qc[d]; alpha = eta * sa; }
-            else if (model == 1) { sa = eqc[0]; sb2 = eqc[1]; eta = qc[2]; alpha = eta * sa; }
-            else if (model == 2) { sa = eqc[0]; eta = qc[d]; alpha = eta * sa; }
-            else { sa = eqc[1]; eta = qc[d]; alpha = qc[0] + eta * sa; }
+            // theta = [phi (d) | eta (ng) | etb (ng x D)]; per group j: alpha_j, beta_j (Appendix A of
+            // SURVEY.md, m*b.stan); a0 + eta_j * sa and b0[c] + etb_j[c] * sbv[c]
+            sa = eqc[model >= 3 ? 1 : 0];
+            const double a0 = model >= 3 ? qc[0] : 0.0;
+            for (int g = 0; g < ng; ++g) {
 #pragma unroll
-            for (int b = 0; b < DPB / 64; ++b) {
-                const int j = lane + 64 * b;
-                double bj = 0.0;
-                if (j < D) {
-                    if (model == 0) bj = qc[1 + j];
-                    else if (model == 1) bj = qc[3 + j] * sb2;
-                    else if (model == 2) bj = qc[d + 1 + j] * eqc[1 + j];
-                    else bj = qc[2 + j] + qc[d + 1 + j] * eqc[2 + D + j];
+                for (int b = 0; b < DPB / 64; ++b) {
+                    const int c = lane + 64 * b;
+                    double bj = 0.0;
+                    if (c < D) {
+                        const double eb = model == 0 ? 0.0 : qc[d + ng + g * D + c];
+                        if (model == 0) bj = qc[1 + c];
+                        else if (model == 1) bj = eb * eqc[1];
+                        else if (model == 2) bj = eb * eqc[1 + c];
+                        else bj = qc[2 + c] + eb * eqc[2 + D + c];
+                    }
+                    L.beta_s[(g * DPB + c) * NCH + wave] = bj;
                 }
-                L.beta_s[j * NCH + wave] = bj;
+                if (lane == 0) L.alpha_s[g * NCH + wave] = a0 + qc[d + g] * sa;
             }
             FORV { const int e = lane + 64 * i; if (e < d) vs4[e * NCH + wave] = zq.v[i] - mu_s[e]; }
-            if (lane == 0) L.alpha_s[wave] = alpha;
         }
         STAMP(0);
         lds_barrier();
@@ -295,7 +321,7 @@ k_nuts_stream(NutsArgs a) {
         {
             const PassOut po = stream_pass<DPB>(site);
             site.slot_f = po.slot_f; site.slot_i = po.slot_i; site.t_i = po.t_i;
-            da = po.da; ll = po.ll;
+            ll = po.ll;
         }
         }
         STAMP(2);
@@ -307,46 +333,49 @@ k_nuts_stream(NutsArgs a) {
         {
             // ---- step D (wave = chain): lp and the chain rule back to (phi, eta, etb)
             const double *qc = q_s + wave * PMAX, *eqc = eq_s + wave * PMAX;
-            auto dbat = [&](int j) { return (j >= 0 && j < D) ? L.Gs[j * NCH + wave] : 0.0; };
-            auto gq = [&](int e) { return (e >= 0 && e < P) ? qc[e] : 0.0; };
-            auto geq = [&](int e) { return (e >= 0 && e < P) ? eqc[e] : 0.0; };
+            // G_g[c] = sum over the rows of group g of x[c] * residual, da_g = sum of the residuals
+            auto Gg = [&](int g, int c) { return L.Gs[(g * DPB + c) * NCH + wave]; };
+            auto dag = [&](int g) { return L.da_s[g * NCH + wave]; };
             double dot = 0.0;
             if (model == 1) {
+                // m2b: d log sigma_b = sb * sum_g sum_c G_g[c] etb_g[c]
                 double tsum = 0.0;
-                FORV { const int e = lane + 64 * i; if (e >= 3 && e < P) tsum += dbat(e - 3) * zq.v[i]; }
+                FORV {
+                    const int e = lane + 64 * i;
+                    if (e >= d + ng && e < P) { const int idx = e - d - ng; tsum += Gg(idx / D, idx % D) * zq.v[i]; }
+                }
                 dot = wave_sum(tsum);
             }
+            // sums over the groups that the shared coordinates need
+            double s_da = 0.0, s_daeta = 0.0;
+            for (int g = 0; g < ng; ++g) { const double t = dag(g); s_da += t; s_daeta += t * qc[d + g]; }
             FORV {
                 const int e = lane + 64 * i;
                 const double q = zq.v[i];
                 double g = zg.v[i];                 // cavity part (elements < d), 0 beyond
                 if (e >= d && e < P) lpt -= laplace ? fabs(q) : 0.5 * q * q;
                 const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;
-                if (model == 0) {
-                    if (e == 0) g += da * eta * sa;
-                    else if (e <= D) g += dbat(e - 1);
-                    else if (e == d) g = da * sa - pr;
-                } else if (model == 1) {
-                    if (e == 0) g += da * eta * sa;
-                    else if (e == 1) g += dot * sb2;
-                    else if (e == 2) g = da * sa - pr;
-                    else if (e < P) g = dbat(e - 3) * sb2 - pr;
-                } else if (model == 2) {
-                    const int j = e <= D ? e - 1 : e - d - 1;
-                    const double db = dbat(j);
-                    if (e == 0) g += da * eta * sa;
-                    else if (e <= D) g += db * gq(d + 1 + j) * eqc[e];
-                    else if (e == d) g = da * sa - pr;
-                    else if (e < P) g = db * geq(1 + j) - pr;
-                } else {
-                    const int j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
-                    const double db = dbat(j);
-                    if (e == 0) g += da;
-                    else if (e == 1) g += da * eta * sa;
-                    else if (e < 2 + D) g += db;
-                    else if (e < d) g += db * gq(d + 1 + j) * eqc[e];
-                    else if (e == d) g = da * sa - pr;
-                    else if (e < P) g = db * geq(2 + D + j) - pr;
+                if (e < d) {
+                    // hyper-parameters: every group contributes
+                    const int isa = model >= 3 ? 1 : 0;
+                    if (model >= 3 && e == 0) g += s_da;
+                    else if (e == isa) g += s_daeta * sa;
+                    else if (model == 1) { if (e == 1) g += dot * eqc[1]; }
+                    else {
+                        // slope block(s): m1b beta (1..D); m3b log sigma_b (1..D); m4b/m5b mu_b (2..1+D), log sigma_b (2+D..)
+                        const int c = model >= 3 ? (e < 2 + D ? e - 2 : e - 2 - D) : e - 1;
+                        const bool scale = model == 2 || (model >= 3 && e >= 2 + D);
+                        double acc = 0.0;
+                        for (int gg = 0; gg < ng; ++gg)
+                            acc += scale ? Gg(gg, c) * qc[d + ng + gg * D + c] : Gg(gg, c);
+                        g += scale ? acc * eqc[e] : acc;
+                    }
+                } else if (e < d + ng) {
+                    g = dag(e - d) * sa - pr;                               // eta_g
+                } else if (e < P) {
+                    const int idx = e - d - ng, gg = idx / D, c = idx - gg * D;   // etb_g[c]
+                    const double sbv = model == 1 ? eqc[1] : (model == 2 ? eqc[1 + c] : eqc[2 + D + c]);
+                    g = Gg(gg, c) * sbv - pr;
                 }
                 zg.v[i] = e < P ? g : 0.0;
             }
@@ -382,12 +411,12 @@ k_nuts_stream(NutsArgs a) {
 #endif
     // ------------------------------------------------------------- epilogue
     if (active && !a.dbg) {
-        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
-        FORV { const int e = lane0 + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
+        double *lastp = a.last + ((size_t)k * a.chains + chain) * a.P;
+        FORV { const int e = lane0 + 64 * i; if (e < a.P) lastp[e] = qs.v[i]; }
         if (failed) {
             for (int kk = 0; kk < a.nkeep; ++kk) {
-                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * P;
-                FORV { const int e = lane0 + 64 * i; if (e < P) dst[e] = qs.v[i]; }
+                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * a.P;
+                FORV { const int e = lane0 + 64 * i; if (e < a.P) dst[e] = qs.v[i]; }
             }
         }
         if (lane0 == 0) {
@@ -405,9 +434,9 @@ k_nuts_stream(NutsArgs a) {
 }
 
 // LDS bytes of the streaming kernel
-size_t nuts_stream_lds_bytes(int nv, int dpb, int d) {
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax) {
     const size_t pmax = 64 * (size_t)nv;
-    const size_t eng = dpb == 64 ? stream_lds_bytes<64>() : stream_lds_bytes<128>();
+    const size_t eng = dpb == 64 ? stream_map<64>(ngmax, ntmax).end : stream_map<128>(ngmax, ntmax).end;
     const size_t dbl = (size_t)((d + 1) & ~1) + 2 * (size_t)d * NCH + 2 * NCH * pmax + 2;
     return eng + dbl * 8;
 }
@@ -444,7 +473,7 @@ static int launch_stream_nv(const NutsArgs &a, int nblocks, int nv, size_t lds, 
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream) {
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
-    const size_t lds = nuts_stream_lds_bytes(nv, dpb, a.d);
+    const size_t lds = nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax);
     if (dpb == 64) return launch_stream_nv<64>(a, nblocks, nv, lds, stream);
     if (dpb == 128) return launch_stream_nv<128>(a, nblocks, nv, lds, stream);
     return -1;

@@ -12,7 +12,10 @@ import numpy as np
 from . import _lib
 from ._lib import SamplerOpts, check, dptr
 
-MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4}
+MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4,
+             # the multi-group programs experiment/models/m{1..5}b.stan (K < J): same densities with
+             # several (eta, etb) blocks per site; they need the group structure of the sites
+             'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4}
 PREC_ESTIM_IDS = {'sample': 0, 'olse': 1}
 QI, QI2, DQI = 0, 1, 2
 INIT_IDS = {'random': 0, '0': 1, 0: 1, 'prev': 2}
@@ -34,7 +37,9 @@ def _f64(a, order='F'):
 class HipEngine(object):
     """Sites k = 0..K_local-1 of one rank, resident in HBM."""
 
-    def __init__(self, model, X, y, k_lim, device=0):
+    def __init__(self, model, X, y, k_lim, device=0, g_cnt=None, g_lim=None):
+        """g_cnt (K) groups per site and g_lim (sum+1) row limits of all groups: sites that hold
+        several groups of the hierarchical model (util.distribute_groups, K < J)."""
         self.lib = _lib.load()
         if model not in MODEL_IDS:
             raise ValueError('unknown site model {!r}; built-in models: {}'
@@ -47,13 +52,30 @@ class HipEngine(object):
         self.model = model
         self.K = k_lim.shape[0] - 1
         self.D = X.shape[1]
-        self.d, self.P = model_dims(model, self.D)
+        self.d, self.P = model_dims(model if model.endswith('_sg') else model + '_sg', self.D)
         self.device = device
         ctx = ctypes.c_void_p()
-        check(self.lib.epx_ctx_create(
-            device, MODEL_IDS[model], self.K, self.D,
-            k_lim.ctypes.data_as(_lib.c_int64_p), dptr(X),
-            y32.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ctx)))
+        if g_cnt is None:
+            if not model.endswith('_sg'):
+                raise ValueError('site model {!r} needs the groups of every site (g_cnt, g_lim)'.format(model))
+            check(self.lib.epx_ctx_create(
+                device, MODEL_IDS[model], self.K, self.D,
+                k_lim.ctypes.data_as(_lib.c_int64_p), dptr(X),
+                y32.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ctx)))
+        else:
+            g_cnt = np.ascontiguousarray(g_cnt, dtype=np.int32)
+            g_lim = np.ascontiguousarray(g_lim, dtype=np.int64)
+            if g_cnt.shape[0] != self.K or g_lim.shape[0] != int(g_cnt.sum()) + 1:
+                raise ValueError('g_cnt needs one entry per site and g_lim sum(g_cnt)+1 entries')
+            pg = 1 if MODEL_IDS[model] == 0 else 1 + self.D
+            self.P = self.d + int(g_cnt.max()) * pg          # record stride: the largest site
+            self.site_P = self.d + g_cnt.astype(np.int64) * pg
+            check(self.lib.epx_ctx_create_groups(
+                device, MODEL_IDS[model], self.K, self.D,
+                k_lim.ctypes.data_as(_lib.c_int64_p), g_cnt.ctypes.data_as(_lib.c_int32_p),
+                g_lim.ctypes.data_as(_lib.c_int64_p), dptr(X),
+                y32.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ctx)))
+        self.g_cnt, self.g_lim = g_cnt, g_lim
         self.ctx = ctx
         n = ctypes.c_int()
         check(self.lib.epx_packed_len(self.ctx, ctypes.byref(n)))

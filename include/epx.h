@@ -88,6 +88,16 @@ int epx_model_dims(int model, int D, int *dphi, int *npar);
  */
 int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim,
                    const double *X, const int32_t *y, epx_ctx **out);
+
+/* The same for sites that hold SEVERAL groups of the hierarchical model (K < J, experiment/fit.py:310-324:
+ * `Master(..., A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k+1})` with the multi-group programs
+ * experiment/models/m{1..5}b.stan).  g_cnt[k] = groups in site k; g_lim = row limits of all groups in site
+ * order (sum(g_cnt)+1 entries, rank-local rows): the rows of a group are contiguous and the groups of a site
+ * tile its rows -- what util.distribute_groups (util.py:582-608) produces.  Site k then samples
+ * dphi + g_cnt[k] * (1 [+ D]) coordinates [phi | eta_1.. | etb_1 .. ]; records of draws / last states use the
+ * stride of the largest site.  Runs on the streaming sampler layout. */
+int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                          const int64_t *g_lim, const double *X, const int32_t *y, epx_ctx **out);
 int epx_ctx_destroy(epx_ctx *ctx);
 
 /* prior natural parameters Q0 (d,d) F-order, r0 (d): method.py:772-797 */

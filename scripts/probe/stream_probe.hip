@@ -10,17 +10,19 @@ using namespace epx;
 
 template <int DPB>
 __global__ void __launch_bounds__(STREAM_THREADS)
-k_probe(const double *X, const int *y32, const long long *k_lim, int D, const double *beta, int ticks,
+k_probe(const double *X, const int *y32, const long long *k_lim, int D, int ntmax, const double *beta, int ticks,
         double *G_out, double *dl_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    StreamLds L;
-    L.template carve<DPB>(smem);
     const int k = blockIdx.x;
     PassArgs<DPB> s;
     s.Xg = X + (size_t)k_lim[k] * D; s.yg = y32 + k_lim[k];
     s.n = (int)(k_lim[k + 1] - k_lim[k]); s.D = D; s.ntile = (s.n + TR - 1) / TR;
+    s.ngmax = 1; s.ntmax = ntmax;
     s.lds0 = (unsigned)(size_t)smem; s.slot_f = 0; s.slot_i = 0; s.t_i = 0; s.wave = wave; s.lane = lane;
+    StreamLds L;
+    L.template carve<DPB>(smem, 1, ntmax);
+    if (tid == 0) { const long long gl[2] = {0, s.n}; build_tiles(1, gl, L.tdesc); }
     loader_init<DPB>(s, lane);
     for (int i = tid; i < DPB * NCH; i += STREAM_THREADS) L.beta_s[i] = (i / NCH) < D ? beta[(size_t)k * DPB * NCH + i] : 0.0;
     if (tid < 4) L.alpha_s[tid] = 0.1 * (tid + 1);
@@ -29,8 +31,9 @@ k_probe(const double *X, const int *y32, const long long *k_lim, int D, const do
     double da = 0, ll = 0;
     for (int t = 0; t < ticks; ++t) {
         const PassOut o = stream_pass<DPB>(s);
-        s.slot_f = o.slot_f; s.slot_i = o.slot_i; s.t_i = o.t_i; da = o.da; ll = o.ll;
+        s.slot_f = o.slot_f; s.slot_i = o.slot_i; s.t_i = o.t_i; ll = o.ll;
     }
+    if (wave < NCH) da = L.da_s[wave];
     if (wave == NCH) wait_vm<0>();
     __syncthreads();
     for (int i = tid; i < DPB * NCH; i += STREAM_THREADS) G_out[(size_t)k * DPB * NCH + i] = L.Gs[i];
@@ -59,12 +62,13 @@ int run(int S, int n, int D, int ticks) {
     CK(hipMemcpy(dB, beta.data(), beta.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dy, y.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dk, kl.data(), (S + 1) * 8, hipMemcpyHostToDevice));
-    const size_t lds = stream_lds_bytes<DPB>();
+    const int ntmax = (n + TR - 1) / TR;
+    const size_t lds = stream_map<DPB>(1, ntmax).end;
     auto kern = k_probe<DPB>;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     // correctness: one pass
-    hipLaunchKernelGGL(kern, dim3(S), dim3(STREAM_THREADS), lds, 0, dX, dy, dk, D, dB, 1, dG, dL);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(STREAM_THREADS), lds, 0, dX, dy, dk, D, ntmax, dB, 1, dG, dL);
     CK(hipDeviceSynchronize());
     std::vector<double> G(beta.size()), dl(S * 8);
     CK(hipMemcpy(G.data(), dG, G.size() * 8, hipMemcpyDeviceToHost));
@@ -91,7 +95,7 @@ int run(int S, int n, int D, int ticks) {
     // timing
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(S), dim3(STREAM_THREADS), lds, 0, dX, dy, dk, D, dB, ticks, dG, dL);
+        hipLaunchKernelGGL(kern, dim3(S), dim3(STREAM_THREADS), lds, 0, dX, dy, dk, D, ntmax, dB, ticks, dG, dL);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double bytes = (double)S * ticks * ((double)n * D * 8 + n * 4);

@@ -738,3 +738,96 @@ def test_find_damp_driver_on_gpu(tmp_path, monkeypatch):
         j = np.argmin(np.abs(out['damps'] - out['damps_selected'][it]))
         if abs(out['damps'][j] - out['damps_selected'][it]) < 1e-12:
             assert abs(out['kls'][it, j] - out['kls_selected'][it + 1]) < 1e-7 * max(1.0, abs(out['kls'][it, j]))
+
+
+# ---------------------------------------------------------------- multi-group sites (K < J)
+def _group_problem(model, D, groups, seed, tight=1.0):
+    """Sites with several groups each: `groups` = list (per site) of lists of group sizes."""
+    rng = np.random.RandomState(seed)
+    sizes = [int(np.sum(g)) for g in groups]
+    N = int(np.sum(sizes))
+    X = rng.randn(N, D) * 1.2
+    y = (rng.rand(N) < 0.55).astype(int)
+    k_lim = np.concatenate(([0], np.cumsum(sizes)))
+    g_cnt = np.array([len(g) for g in groups], dtype=np.int32)
+    g_lim = np.concatenate(([0], np.cumsum([n for g in groups for n in g])))
+    d = no.dims(model, D)[0]
+    Oms, mus = [], []
+    for k in range(len(groups)):
+        A = rng.randn(d, d + 3)
+        Oms.append((A.dot(A.T) / (d + 3) + 0.5 * np.eye(d)) * tight)
+        mus.append(0.4 * rng.randn(d))
+    return X, y, k_lim, g_cnt, g_lim, np.array(Oms), np.array(mus), d
+
+
+def _group_engine(model, X, y, k_lim, g_cnt, g_lim, Oms, mus):
+    eng = HipEngine(model, X, y, k_lim, g_cnt=g_cnt, g_lim=g_lim)
+    d = eng.d
+    for k in range(eng.K):
+        assert eng.cavity_site(k, Oms[k] + np.eye(d), Oms[k].dot(mus[k]), np.eye(d), np.zeros(d))
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(eng.K)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(eng.K)])
+    return eng, Om_dev, mu_dev
+
+
+@pytest.mark.parametrize('model', ['m1b', 'm2b', 'm3b', 'm4b', 'm5b'])
+@pytest.mark.parametrize('D,groups', [(3, [[5, 1, 9], [4, 4]]), (16, [[20, 20], [13, 30, 7], [40]]),
+                                      (40, [[30, 25], [17]]), (70, [[33, 16, 16]])])
+def test_multigroup_gradient_matches_oracle(model, D, groups):
+    X, y, k_lim, g_cnt, g_lim, Oms, mus, d = _group_problem(model, D, groups, 11 + D)
+    eng, Om_dev, mu_dev = _group_engine(model, X, y, k_lim, g_cnt, g_lim, Oms, mus)
+    rng = np.random.RandomState(3)
+    off = np.concatenate(([0], np.cumsum(g_cnt)))
+    for k in range(len(groups)):
+        Pk = no.dims(model, D, g_cnt[k])[1]
+        assert eng.P >= Pk and eng.site_P[k] == Pk
+        theta = np.zeros(eng.P)
+        theta[:Pk] = rng.randn(Pk) * 0.3
+        lp, g = eng.logdensity_grad(k, theta)
+        lo, hi = k_lim[k], k_lim[k + 1]
+        gl = g_lim[off[k]:off[k + 1] + 1] - lo
+        lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta[:Pk], gl=gl)
+        assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o)), (k, lp, lp_o)
+        np.testing.assert_allclose(g[:Pk], g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+        assert np.all(g[Pk:] == 0.0)
+
+
+@pytest.mark.parametrize('model,D,groups,chains', [('m4b', 4, [[20, 14, 9], [25, 25]], 4), ('m1b', 16, [[30, 30], [18, 18, 18]], 3),
+                                                   ('m3b', 8, [[40], [16, 24]], 4)])
+def test_multigroup_site_updates_match_oracle(model, D, groups, chains):
+    """Whole short site updates of multi-group sites against the C oracle, chain by chain (same
+    random stream; chains are compared until rounding differences make them part)."""
+    X, y, k_lim, g_cnt, g_lim, Oms, mus, d = _group_problem(model, D, groups, 70 + D, tight=300.0)
+    eng, Om_dev, mu_dev = _group_engine(model, X, y, k_lim, g_cnt, g_lim, Oms, mus)
+    K = len(groups)
+    seeds = np.arange(K, dtype=np.int64) + 31
+    it = 44
+    stats, ms = eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random'))
+    assert eng.last_layout() == 3
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it,
+                                     g_cnt=g_cnt, g_lim=g_lim)
+    cs = eng.get_chain_stats(chains)
+    assert np.all(cs[:, :, 7] == 0) and np.all(np.isfinite(stats))
+    nk = it // 2
+    P = eng.P
+    n_full = 0
+    for k in range(K):
+        dev = eng.get_draws(k, True).reshape(chains, nk, P)
+        assert np.all(dev[:, :, eng.site_P[k]:] == 0.0)
+        err = np.abs(dev - draws_o[k]).max(axis=2) / max(1.0, np.abs(draws_o[k]).max())
+        for c in range(chains):
+            assert np.all(err[c, :3] < 1e-3), (k, c, err[c, :3])
+            if np.all(err[c] < 1e-4):
+                n_full += 1
+                assert cs[k, c, 2] == st_o[k, c, 2] and cs[k, c, 3] == st_o[k, c, 3]
+    assert n_full >= (3 * K * chains) // 4, n_full
+    # one group per site through the groups entry point = the `_sg` model, bit for bit
+    ones = np.ones(K, dtype=np.int32)
+    e1 = HipEngine(model, X, y, k_lim, g_cnt=ones, g_lim=k_lim)
+    e2 = HipEngine(model + '_sg', X, y, k_lim)
+    for e in (e1, e2):
+        for k in range(K):
+            assert e.cavity_site(k, Oms[k] + np.eye(d), Oms[k].dot(mus[k]), np.eye(d), np.zeros(d))
+        e.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=20, init='random', layout=3))
+    for k in range(K):
+        np.testing.assert_array_equal(e1.get_draws(k, True), e2.get_draws(k, True))
