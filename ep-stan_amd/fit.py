@@ -15,7 +15,7 @@ import numpy as np
 
 from . import models
 from .method import Master
-from .util import invert_normal_params
+from .util import invert_normal_params, distribute_groups
 
 CONFS = [
     'J', 'D', 'npg', 'cor_input',
@@ -102,15 +102,18 @@ def main(model_name, conf, ret_master=False, verbose=True, _engine_factory=None,
                           chains=conf.chains, iter=conf.siter, warmup=None, thin=1)      # fit.py:296-305
     if K < 2:
         raise ValueError("K should be at least 2.")
-    elif K < J:
-        raise NotImplementedError("K < J (several groups per site) needs the multi-group densities: "
-                                  "next row of SURVEY.md §8(f)")
     elif K > J:
         raise NotImplementedError("Splitting the groups not implemented.")               # fit.py:339-341
     if _engine_factory is not None:
         master_kwargs['_engine_factory'] = _engine_factory
-    epstan_master = Master(model.site_model, data.X, data.y, site_sizes=data.Nj,
-                           **epstan_options, **master_kwargs)                            # fit.py:326-335
+    if K < J:
+        # several groups per site (fit.py:310-324): the multi-group program m*b.stan
+        Nk, Nj_k, j_ind_k = distribute_groups(J, K, data.Nj)
+        epstan_master = Master(model_name, data.X, data.y, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
+                               site_sizes=Nk, **epstan_options, **master_kwargs)
+    else:
+        epstan_master = Master(model.site_model, data.X, data.y, site_sizes=data.Nj,
+                               **epstan_options, **master_kwargs)                        # fit.py:326-335
     if ret_master:
         return epstan_master
     S_ep_init, m_ep_init = epstan_master.cur_approx()                                    # fit.py:351

@@ -475,11 +475,19 @@ class Master(object):
         device = gpu['device']
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', '0')) if self.comm.world > 1 else 0
+        groups = {}
+        if not self.model_name.endswith('_sg'):
+            # several groups per site (K < J, fit.py:310-324): the multi-group programs take the
+            # number of groups `J` per site (A_k) and the 1-based group index `j_ind` per row (A_n)
+            g_cnt, g_lim = self._site_groups()
+            glo = int(np.sum(g_cnt[:self.k_lo]))
+            ghi = glo + int(np.sum(g_cnt[self.k_lo:self.k_hi]))
+            groups = dict(g_cnt=g_cnt[self.k_lo:self.k_hi], g_lim=g_lim[glo:ghi + 1] - r0w)
         if factory is None:
             self.engine = _engine.HipEngine(self.model_name, self.X[r0w:r1w], self.y[r0w:r1w],
-                                            k_lim_local, device=device)
+                                            k_lim_local, device=device, **groups)
         else:
-            self.engine = factory(self.model_name, self.X[r0w:r1w], self.y[r0w:r1w], k_lim_local)
+            self.engine = factory(self.model_name, self.X[r0w:r1w], self.y[r0w:r1w], k_lim_local, **groups)
         if self.engine.d != self.dphi:
             raise ValueError("Arg. `dphi`/`prior` ({}) does not match site model {} (dphi {})"
                              .format(self.dphi, self.model_name, self.engine.d))
@@ -570,6 +578,29 @@ class Master(object):
                 Qa[:, :, lo:hi] = Ql
                 ra[:, lo:hi] = rl
         self.Q[...], self.r[...] = self.engine.get_global()
+
+    def _site_groups(self):
+        """Group structure of the sites from `A_k['J']` and `A_n['j_ind']` (the data the
+        reference hands to m*b.stan): groups per site and the row limits of all groups.  The
+        rows of a group have to be contiguous and the groups of a site in order -- what
+        `util.distribute_groups` produces."""
+        if 'J' not in self.A_k or 'j_ind' not in self.A_n:
+            raise ValueError("site model {!r} holds several groups per site: give the number of groups per "
+                             "site as A_k['J'] and the 1-based group index of every row as A_n['j_ind'] "
+                             "(fit.py:310-324), or use the single-group model {!r}"
+                             .format(self.model_name, self.model_name + '_sg'))
+        g_cnt = np.asarray(self.A_k['J'], dtype=np.int32)
+        j_ind = np.asarray(self.A_n['j_ind'])
+        lims = [0]
+        for k in range(self.K):
+            jk = j_ind[self.k_lim[k]:self.k_lim[k + 1]]
+            if jk[0] != 1 or jk[-1] != g_cnt[k] or np.any(np.diff(jk) < 0) or np.any(np.diff(jk) > 1):
+                raise ValueError("A_n['j_ind'] of site {}: the rows of a group have to be contiguous and the "
+                                 "groups numbered 1..J in order".format(k))
+            change = np.nonzero(np.diff(jk))[0] + 1
+            lims.extend((self.k_lim[k] + change).tolist())
+            lims.append(int(self.k_lim[k + 1]))
+        return g_cnt, np.asarray(lims, dtype=np.int64)
 
     def damp_sweep(self, damps, m_target, S_target, samp_target=None, packed=None):
         """Score damping factors for the pending site updates `dQi, dri` against a target

@@ -90,3 +90,36 @@ def olse(S, n, P=None, out=None):
     if info[0]:
         raise LinAlgError('matrix is not positive definite')
     return out
+
+
+def distribute_groups(J, K, Nj):
+    """Distribute `J` groups of sizes `Nj` to `K` sites (util.py:541-640 of the reference).
+
+    K < J: consecutive groups are combined, always the adjacent pair with the smallest joint
+    size first (ties: the first such pair), until K sites are left.  Returns `(Nk, Nj_k,
+    j_ind_k)`: rows per site, groups per site, and for every row its 0-based group index
+    WITHIN its site.  K == J: `(Nj, None, None)`.  K > J (splitting groups) is not built."""
+    Nj = np.asarray(Nj)
+    if Nj.shape[0] != J:
+        raise ValueError("J does not match the provided group sizes")
+    if np.any(Nj <= 0):
+        raise ValueError("Every group must have at least one item")
+    if K < 2:
+        raise ValueError("K should be at least 2.")
+    if K == J:
+        return Nj, None, None
+    if K > J:
+        raise NotImplementedError("Splitting the groups (K > J) is not built.")
+    sizes = [int(n) for n in Nj]            # rows of every (merged) site
+    groups = [1] * J                        # groups of every (merged) site
+    while len(sizes) > K:
+        pair = [sizes[i] + sizes[i + 1] for i in range(len(sizes) - 1)]
+        i = pair.index(min(pair))
+        sizes[i] = pair[i]
+        groups[i] += groups[i + 1]
+        del sizes[i + 1], groups[i + 1]
+    Nk = np.array(sizes)
+    Nj_k = np.array(groups)
+    j_ind_k = np.concatenate([np.repeat(np.arange(g), Nj[o:o + g])
+                              for g, o in zip(Nj_k, np.concatenate(([0], np.cumsum(Nj_k)[:-1])))]).astype(np.int32)
+    return Nk, Nj_k, j_ind_k

@@ -19,14 +19,16 @@ QI, QI2, DQI = 0, 1, 2
 
 
 class OracleEngine(object):
-    def __init__(self, model, X, y, k_lim, nthreads=0):
+    def __init__(self, model, X, y, k_lim, nthreads=0, g_cnt=None, g_lim=None):
         self.model = model
+        self.g_cnt = None if g_cnt is None else np.ascontiguousarray(g_cnt, dtype=np.int32)
+        self.g_lim = None if g_lim is None else np.ascontiguousarray(g_lim, dtype=np.int64)
         self.X = np.ascontiguousarray(X, dtype=np.float64)
         self.y = np.ascontiguousarray(y, dtype=np.int32)
         self.k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
         self.K = self.k_lim.shape[0] - 1
         self.D = self.X.shape[1]
-        self.d, self.P = no.dims(model, self.D)
+        self.d, self.P = no.dims(model, self.D, 1 if g_cnt is None else int(np.max(g_cnt)))
         d, K = self.d, self.K
         self.packed_len = 2 * (d * d + d)
         self.nthreads = nthreads
@@ -122,11 +124,15 @@ class OracleEngine(object):
         elif o['init'] in ('0', 0):
             init = np.zeros((count, o['chains'], self.P))
         t0 = time.time()
+        grp = {}
+        if self.g_cnt is not None:
+            off = np.concatenate(([0], np.cumsum(self.g_cnt)))
+            grp = dict(g_cnt=self.g_cnt[sl], g_lim=self.g_lim[off[k0]:off[k0 + count] + 1] - lim[0])
         draws, last, stats = no.nuts_sites(
             self.model, self.X[lim[0]:lim[-1]], self.y[lim[0]:lim[-1]], lim - lim[0],
             self.cav_mu[sl], self.cav_Om[sl], seeds, chains=o['chains'], iter=o['iter'],
             warmup=o['warmup'], thin=o['thin'], max_depth=o['max_depth'], init=init,
-            nthreads=self.nthreads)
+            nthreads=self.nthreads, **grp)
         ms = (time.time() - t0) * 1e3
         if self.draws is None or self.draws.shape[1:] != draws.shape[1:]:
             self.draws = np.zeros((self.K,) + draws.shape[1:])
@@ -185,8 +191,13 @@ class OracleEngine(object):
 
     def logdensity_grad(self, k, theta):
         lo, hi = self.k_lim[k], self.k_lim[k + 1]
+        gl = None
+        if self.g_cnt is not None:
+            off = np.concatenate(([0], np.cumsum(self.g_cnt)))
+            gl = self.g_lim[off[k]:off[k + 1] + 1] - lo
+            theta = np.asarray(theta)[:no.dims(self.model, self.D, self.g_cnt[k])[1]]
         return no.logdensity_grad(self.model, self.X[lo:hi], self.y[lo:hi], self.cav_mu[k],
-                                  self.cav_Om[k], theta)
+                                  self.cav_Om[k], theta, gl=gl)
 
     def invert_normal_params(self, A, b):
         return eo.invert_normal_params(A, b)

@@ -374,6 +374,21 @@ def g9_damp_sweep(method, util, out, models):
     out['g9_global_pd'], out['g9_cav_pd'] = gpd, cpd
 
 
+def g10_distribute_groups(util, out):
+    """util.distribute_groups, K < J branch (util.py:582-608)."""
+    rng = np.random.RandomState(4)
+    cases = [(8, 4, np.array([5, 3, 8, 2, 2, 9, 4, 4])), (64, 32, np.full(64, 20)),
+             (12, 5, rng.randint(1, 30, size=12)), (7, 2, rng.randint(1, 9, size=7)), (6, 5, np.array([3, 3, 3, 3, 3, 3]))]
+    for i, (J, K, Nj) in enumerate(cases):
+        Nk, Nj_k, j_ind_k = util.distribute_groups(J, K, Nj)
+        out['g10_%d_JK' % i] = np.array([J, K])
+        out['g10_%d_Nj' % i] = Nj
+        out['g10_%d_Nk' % i] = Nk
+        out['g10_%d_Nj_k' % i] = Nj_k
+        out['g10_%d_j_ind_k' % i] = j_ind_k
+    out['g10_n'] = np.array(len(cases))
+
+
 def main():
     util, method, tmp = import_reference()
     from models import m1b, m4b
@@ -391,6 +406,7 @@ def main():
         g6_run(method, run, models)
         np.savez_compressed(os.path.join(HERE, 'master_run.npz'), **run)
         swp = {}
+        g10_distribute_groups(util, swp)
         g9_damp_sweep(method, util, swp, models)
         np.savez_compressed(os.path.join(HERE, 'damp_sweep.npz'), **swp)
         sim = {}

@@ -831,3 +831,44 @@ def test_multigroup_site_updates_match_oracle(model, D, groups, chains):
         e.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=20, init='random', layout=3))
     for k in range(K):
         np.testing.assert_array_equal(e1.get_draws(k, True), e2.get_draws(k, True))
+
+
+def test_multigroup_ep_posterior_matches_cpu_path_within_monte_carlo_error():
+    """K < J end to end (the reference's default experiment shape, scaled down: J = 8 groups on
+    K = 4 sites): the EP posterior of the device path against the CPU (oracle) path, tolerance
+    relative to the CPU path's own seed-to-seed spread as in the single-group test above."""
+    from oracle.engine_oracle import OracleEngine
+    from epstan_amd.util import distribute_groups
+    mod = models.m4b(8, 3, 40)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    Nk, Nj_k, j_ind_k = distribute_groups(8, 4, data.Nj)
+
+    def run(seed, **kw):
+        M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
+                   prior={'Q': Q0, 'r': r0}, chains=4, iter=400, df0=0.5, **kw)
+        info, (m_s, S_s) = M.run(6, verbose=False, seed=seed)
+        assert info == 0
+        return m_s[-1], S_s[-1], M
+
+    cpu = lambda m, X, y, kl, **g: OracleEngine(m, X, y, kl, **g)
+    m_g, S_g, Mg = run(1)
+    assert Mg.engine.last_layout() == 3 and Mg.engine.P == 8 + 2 * 4
+    m_c1, S_c1, _ = run(1, _engine_factory=cpu)
+    m_c2, S_c2, _ = run(2, _engine_factory=cpu)
+    sd = np.sqrt(np.diag(S_c1))
+    tol_m = max(0.15, 3 * (np.abs(m_c1 - m_c2) / sd).max())
+    tol_v = max(0.25, 3 * np.abs(np.diag(S_c1) / np.diag(S_c2) - 1).max())
+    assert np.all(np.abs(m_g - m_c1) / sd < tol_m), (np.abs(m_g - m_c1) / sd, tol_m)
+    assert np.all(np.abs(np.diag(S_g) / np.diag(S_c1) - 1) < tol_v), tol_v
+    assert np.all(np.diag(S_g) < 0.8 * np.diag(np.linalg.inv(Q0)))
+
+
+def test_fit_main_with_fewer_sites_than_groups_on_gpu(tmp_path, monkeypatch):
+    from epstan_amd import fit
+    monkeypatch.setattr(fit, 'RES_PATH', str(tmp_path))
+    conf = fit.configurations(J=12, D=4, K=5, npg=15, iter=3, siter=60, run_ep=True, id='kj')
+    res = fit.main('m4b', conf, verbose=False)
+    assert res['m_s_ep'].shape == (4, 10) and np.all(np.isfinite(res['S_s_ep']))
+    assert np.all(np.linalg.eigvalsh(res['S_s_ep'][-1]) > 0)
+    assert os.path.exists(os.path.join(str(tmp_path), 'res_d_m4b_kj.npz'))

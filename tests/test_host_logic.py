@@ -19,8 +19,8 @@ import injectors
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def factory(model, X, y, k_lim):
-    return OracleEngine(model, X, y, k_lim)
+def factory(model, X, y, k_lim, **groups):
+    return OracleEngine(model, X, y, k_lim, **groups)
 
 
 @pytest.fixture(scope='module')
@@ -269,8 +269,6 @@ def test_fit_configurations_and_ep_branch_schema(tmp_path, monkeypatch):
     assert set(saved.files) == {'conf', 'm_s_ep', 'S_s_ep', 'time_s_ep', 'mstepsize_s_ep', 'mrhat_s_ep', 'othertimes'}
     np.testing.assert_allclose(res['S_s_ep'][0], np.eye(d) * 1.5**2, rtol=1e-12)        # the prior (m1b.py:46-50)
     with pytest.raises(NotImplementedError):
-        fit.main('m1b', fit.configurations(J=8, K=4, run_ep=True), _engine_factory=factory)
-    with pytest.raises(NotImplementedError):
         fit.main('m1b', fit.configurations(run_full=True), _engine_factory=factory)
     M = fit.main('m4b', fit.configurations(J=4, D=2, K=4, npg=10), ret_master=True, _engine_factory=factory)
     assert isinstance(M, Master) and M.dphi == 6 and abs(M.df0(1) - 0.5) < 1e-15
@@ -316,3 +314,49 @@ def test_master_damp_sweep_and_find_damp_driver(golden_dir, tmp_path, monkeypatc
     saved = np.load(os.path.join(str(tmp_path), 'find_damp_K4.npz'))
     assert set(saved.files) == {'damps', 'mses', 'lls', 'kls', 'damps_selected', 'mses_selected', 'lls_selected',
                                 'kls_selected'}
+
+
+# ---------------------------------------------------------------- K < J: several groups per site
+def test_distribute_groups_matches_reference(golden_dir):
+    from epstan_amd.util import distribute_groups
+    z = np.load(os.path.join(golden_dir, 'damp_sweep.npz'))
+    for i in range(int(z['g10_n'])):
+        J, K = z['g10_%d_JK' % i]
+        Nk, Nj_k, j_ind_k = distribute_groups(int(J), int(K), z['g10_%d_Nj' % i])
+        np.testing.assert_array_equal(Nk, z['g10_%d_Nk' % i])
+        np.testing.assert_array_equal(Nj_k, z['g10_%d_Nj_k' % i])
+        np.testing.assert_array_equal(j_ind_k, z['g10_%d_j_ind_k' % i])
+    assert distribute_groups(3, 3, np.array([2, 2, 2]))[1] is None
+    with pytest.raises(ValueError):
+        distribute_groups(3, 1, np.array([2, 2, 2]))
+    with pytest.raises(ValueError):
+        distribute_groups(3, 2, np.array([2, 0, 2]))
+    with pytest.raises(NotImplementedError):
+        distribute_groups(3, 4, np.array([2, 2, 2]))
+
+
+def test_multigroup_master_plumbing(tmp_path, monkeypatch):
+    from epstan_amd import fit
+    from epstan_amd.util import distribute_groups
+    monkeypatch.setattr(fit, 'RES_PATH', str(tmp_path))
+    conf = fit.configurations(J=7, D=2, K=3, npg=9, iter=2, siter=30, chains=2, run_ep=True, save_res=False)
+    M = fit.main('m4b', conf, ret_master=True, _engine_factory=factory)
+    Nk, Nj_k, j_ind_k = distribute_groups(7, 3, np.full(7, 9))
+    assert M.K == 3 and M.model_name == 'm4b' and M.dphi == 6
+    np.testing.assert_array_equal(M.engine.g_cnt, Nj_k)
+    np.testing.assert_array_equal(np.diff(M.engine.g_lim), np.full(7, 9))
+    assert M.engine.P == 6 + int(Nj_k.max()) * 3
+    np.testing.assert_array_equal(M.workers[1].data['j_ind'] if hasattr(M.workers[1], 'data') else
+                                  M.A_n['j_ind'][M.k_lim[1]:M.k_lim[2]], j_ind_k[M.k_lim[1]:M.k_lim[2]] + 1)
+    res = fit.main('m4b', conf, verbose=False, _engine_factory=factory)
+    assert res['m_s_ep'].shape == (3, 6) and np.all(np.isfinite(res['m_s_ep']))
+    # the group structure is mandatory for the multi-group programs, and has to be contiguous
+    data = M.X, M.y
+    with pytest.raises(ValueError):
+        Master('m4b', M.X, M.y, site_sizes=Nk, dphi=6, _engine_factory=factory)
+    bad = j_ind_k + 1
+    bad[[0, 1]] = bad[[1, 0]] if bad[0] != bad[1] else bad[[0, 1]]
+    bad[3] = 2 if Nj_k[0] > 1 else bad[3]
+    bad[4] = 1
+    with pytest.raises(ValueError):
+        Master('m4b', M.X, M.y, site_sizes=Nk, dphi=6, A_k={'J': Nj_k}, A_n={'j_ind': bad}, _engine_factory=factory)
