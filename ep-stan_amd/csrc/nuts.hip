@@ -313,14 +313,15 @@ k_nuts(NutsArgs a) {
             STAMP(2);
             // ---- cavity term: Ov = Omega (phi - mu), this wave's share of the columns
             V vv, Ov;
-            FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? zq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
+            int ec[NV];                 // row index of this lane's elements, clamped: every load is in range
+            FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? zq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; ec[i] = e < d ? e : d - 1; }
             {
                 const int jb = (wt * d) / WPC, je = ((wt + 1) * d) / WPC;
 #pragma unroll
                 for (int ii = 0; ii < NV; ++ii) {
                     const int lo = jb > 64 * ii ? jb : 64 * ii;
                     const int hi = je < 64 * (ii + 1) ? je : 64 * (ii + 1);
-                    constexpr int CU = OML ? 2 : 4;     // columns in flight: more when Omega streams from L2
+                    constexpr int CU = OML ? 2 : 8;     // columns in flight: more when Omega streams from L2 (A/B: 2/8 best)
                     for (int j = lo; j < hi; j += CU) {
                         double vj[CU], cc[CU][NV];
 #pragma unroll
@@ -329,13 +330,15 @@ k_nuts(NutsArgs a) {
                             const int ju = ok ? j + u : j;
                             const double t2 = readlane_d(vv.v[ii], ju & 63);
                             vj[u] = ok ? t2 : 0.0;
-                            FORV { const int e = lane + 64 * i; cc[u][i] = e < d ? om_at(ju * d + e) : 0.0; }
+                            // unconditional loads (a per-lane `e < d ? load : 0` costs a branch per load)
+                            FORV cc[u][i] = om_at(ju * d + ec[i]);
                         }
 #pragma unroll
                         for (int u = 0; u < CU; ++u) { FORV Ov.v[i] = fma(cc[u][i], vj[u], Ov.v[i]); }
                     }
                 }
             }
+            FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
             STAMP(3);
             if (WPC > 1) {
                 double *rec = xch + ((size_t)parity * WPC + wt) * XREC;
