@@ -369,46 +369,54 @@ k_nuts(NutsArgs a) {
                 dot = wave_sum(tsum);
             }
             double lpt = 0.0;
+            // Branch-free: every candidate value is computed for every lane and the element's own
+            // case is picked with selects (a divergent if/else chain costs an exec-mask branch per
+            // case on this serial path).  Wave-uniform factors first.
+            const double c_da = da, c_sa = da * eta * sa, c_eta = da * sa;
             FORV {
                 const int e = lane + 64 * i;
                 const double q = zq.v[i];
-                double g = 0.0;
-                if (e < d) { g = -Ov.v[i]; lpt += -0.5 * vv.v[i] * Ov.v[i]; }
-                else if (e < P) lpt -= laplace ? fabs(q) : 0.5 * q * q;
+                const bool in_phi = e < d, in_par = e < P;
+                const double ov = Ov.v[i];
+                double g = in_phi ? -ov : 0.0;
+                const double lp_phi = -0.5 * vv.v[i] * ov;
+                const double lp_pri = laplace ? -fabs(q) : -0.5 * q * q;
+                lpt += in_phi ? lp_phi : (in_par ? lp_pri : 0.0);
                 const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;    // d/dq of the N(0,1)/Laplace term
+                const double g_eta = c_eta - pr;
+                double add = 0.0, g_etb = 0.0;
                 if (model == 0) {
                     const double db = dbat(e - 1);
-                    if (e == 0) g += da * eta * sa;
-                    else if (e <= D) g += db;
-                    else if (e == d) g = da * sa - pr;
+                    add = (e >= 1 && e <= D) ? db : add;
+                    add = e == 0 ? c_sa : add;
                 } else if (model == 1) {
                     const double db = dbat(e - 3);
-                    if (e == 0) g += da * eta * sa;
-                    else if (e == 1) g += dot * sb2;
-                    else if (e == 2) g = da * sa - pr;
-                    else if (e < P) g = db * sb2 - pr;
+                    g_etb = db * sb2 - pr;
+                    add = e == 1 ? dot * sb2 : add;
+                    add = e == 0 ? c_sa : add;
                 } else if (model == 2) {
                     const int j = e <= D ? e - 1 : e - d - 1;
                     const double db = dbat(j);
                     const double etb = gatherV(zq, d + 1 + j);
                     const double sbj = gatherV(eq, 1 + j);
-                    if (e == 0) g += da * eta * sa;
-                    else if (e <= D) g += db * etb * eq.v[i];
-                    else if (e == d) g = da * sa - pr;
-                    else if (e < P) g = db * sbj - pr;
+                    g_etb = db * sbj - pr;
+                    add = (e >= 1 && e <= D) ? db * etb * eq.v[i] : add;
+                    add = e == 0 ? c_sa : add;
                 } else {
                     const int j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
                     const double db = dbat(j);
                     const double etb = gatherV(zq, d + 1 + j);
                     const double sbj = gatherV(eq, 2 + D + j);
-                    if (e == 0) g += da;
-                    else if (e == 1) g += da * eta * sa;
-                    else if (e < 2 + D) g += db;
-                    else if (e < d) g += db * etb * eq.v[i];
-                    else if (e == d) g = da * sa - pr;
-                    else if (e < P) g = db * sbj - pr;
+                    g_etb = db * sbj - pr;
+                    add = (e >= 2 + D && in_phi) ? db * etb * eq.v[i] : add;
+                    add = (e >= 2 && e < 2 + D) ? db : add;
+                    add = e == 1 ? c_sa : add;
+                    add = e == 0 ? c_da : add;
                 }
-                zg.v[i] = e < P ? g : 0.0;
+                g = in_phi ? g + add : g;
+                g = e == d ? g_eta : g;
+                g = (e > d && in_par) ? g_etb : g;
+                zg.v[i] = in_par ? g : 0.0;
             }
             // second half step of the momentum, then ONE reduction for lp and the kinetic energy
             double ks = 0.0;
