@@ -63,6 +63,8 @@ SIGNATURES = {
     'epx_force_pd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, c_uint8_p]),
     'epx_logdensity_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    'epx_logdensity_grad_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int,
+                                                  ctypes.POINTER(ctypes.c_double), c_double_p]),
     'epx_sample_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int64_p,
                                         ctypes.POINTER(SamplerOpts), c_double_p, c_double_p]),
     'epx_nuts_transitions': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int64_p,

@@ -468,16 +468,29 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // resident layouts: enough sites to fill the 256 CUs -> one block per site, else one block
     // per (site, chain) with 4 cooperating waves
     int layout = o.layout;
-    if (layout == 0) layout = count >= 192 ? 1 : 2;
+    const bool many = count >= 192;
+    // layout 4: one block per site, chains in lock step, rows resident in LDS, MFMA products
+    // (the many-sites layout when it fits; also the home of multi-group sites with small D)
+    bool lock = false;
+    if ((layout == 4 || (layout == 0 && (many || c->multi))) && c->D <= 32 && nv <= 7) {
+        const int dpl = c->D <= 16 ? 16 : 32;
+        const size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max);
+        if (lds <= LDS_CAP) {
+            lock = true; layout = 4; dp = dpl;
+            a.cpb = 4; a.n_max = c->n_max; a.stack_in_lds = 0; a.om_in_lds = 0; a.lds_bytes = (int)lds;
+        }
+    }
+    if (layout == 4 && !lock) layout = 0;
+    if (layout == 0) layout = many ? 1 : 2;
     int wpc = 1;
-    bool resident = dp > 0 && nv <= 2 && layout != 3 && !c->multi;      // several groups per site: streaming layout only
+    bool resident = !lock && dp > 0 && nv <= 2 && layout != 3 && !c->multi;      // several groups per site: layouts 3 / 4 only
     if (resident) {
         if (layout == 1) { wpc = 1; a.cpb = o.chains < 4 ? o.chains : 4; }
         else { wpc = 4; a.cpb = 1; }
         const size_t lds = nuts_lds_layout(a, wpc, dp, c->n_max);
         if (lds > LDS_CAP) resident = false;
     }
-    if (!resident) {
+    if (!resident && !lock) {
         // rows (or parameters) do not fit the resident kernel: stream X through an LDS tile
         layout = 3;
         if (c->D > 128) return fail("D = %d > 128 is not supported by the streaming sampler", c->D);
@@ -485,11 +498,11 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         dp = c->D <= 64 ? 64 : 128;
         a.cpb = 4; wpc = 1;
         a.stack_in_lds = 0; a.om_in_lds = 0;
-        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d, c->ng_max, c->nt_max);
+        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d, c->ng_max, c->nt_max, 0);
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {
-        const size_t need = layout == 3 ? (size_t)count * o.chains * nuts_stream_chain_doubles(nv, o.max_depth)
+        const size_t need = layout >= 3 ? (size_t)count * o.chains * nuts_stream_chain_doubles(nv, o.max_depth)
                                         : (size_t)count * o.chains * o.max_depth * (4 * nv * 64 + 2);
         if (c->stack_elems < need) {
             if (c->stack) (void)hipFree(c->stack);
@@ -503,7 +516,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
 }
 
 static int launch_sampler(const NutsArgs &a, int count, int wpc, int dp, int nv, int layout, hipStream_t stream) {
-    if (layout == 3) return launch_nuts_stream(a, count, dp, nv, stream);
+    if (layout >= 3) return launch_nuts_stream(a, count, dp, nv, stream);
     return launch_nuts(a, count, wpc, dp, nv, stream);
 }
 
@@ -717,12 +730,16 @@ int epx_get_chain_stats(epx_ctx *c, int k0, int count, double *out) {
 }
 
 int epx_logdensity_grad(epx_ctx *c, int k, const double *theta, double *lp, double *grad) {
+    return epx_logdensity_grad_layout(c, k, theta, 2, lp, grad);
+}
+
+int epx_logdensity_grad_layout(epx_ctx *c, int k, const double *theta, int layout_req, double *lp, double *grad) {
     CTX(c);
     if (check_range(c, k, 1)) return -1;
     // the sampler kernel itself evaluates the initial point and stops (NutsArgs::dbg)
     epx_sampler_opts o;
     memset(&o, 0, sizeof o);
-    o.chains = 1; o.iter = 2; o.warmup = 1; o.thin = 1; o.init = EPX_INIT_PREV; o.max_depth = 10; o.layout = 2;
+    o.chains = 1; o.iter = 2; o.warmup = 1; o.thin = 1; o.init = EPX_INIT_PREV; o.max_depth = 10; o.layout = layout_req;
     NutsArgs a;
     int wpc, dp, nv, layout;
     if (build_nuts_args(c, k, 1, o, a, &wpc, &dp, &nv, &layout)) return -1;

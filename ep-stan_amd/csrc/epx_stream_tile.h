@@ -416,4 +416,179 @@ __device__ inline PassOut stream_pass(const PassArgs<DPB> &s) {
                                  s.wave, s.lane);
 }
 
+// ====================================================================== resident variant
+// The same lock-step gradient for sites whose rows FIT the LDS (D <= 32; BASELINE configs
+// C3 / C4: n_j = 500, D = 32 -> 128 KB): the row images are loaded once per site update and
+// stay; there is no DMA ring, no loader / logistic wave and no barrier inside the pass.  Every
+// chain wave owns every 4th tile and runs it alone: forward product -> the tile's logistic
+// terms directly on the MFMA result (D layout: one (row, chain) per lane) -> residuals through
+// a wave-private LDS line -> backward product.  Per-wave partial gradients / residual sums are
+// combined after one barrier.
+template <int DPB> struct ResGeom {
+    static constexpr int CPR = DPB / 2;            // 16-byte chunks per row image
+    static constexpr int ROWB = DPB * 8;           // bytes per row image
+    static constexpr int KS = DPB / 4;             // forward k-steps per tile (all columns)
+    static constexpr int MB = DPB / 16;            // backward 16-column blocks
+};
+struct ResMap {
+    unsigned ximg;      // npad row images (site rows, zero padded to a multiple of 16)
+    unsigned yimg;      // npad responses (int32)
+    unsigned tdesc;     // per tile: first row, rows valid | group << 8
+    unsigned beta;      // groups x DPB x 4, [group][column][chain]
+    unsigned gsum;      // groups x DPB x 4 gradient wrt the coefficients (combined)
+    unsigned gpart;     // 4 waves x groups x DPB x 4 partial gradients
+    unsigned alpha;     // groups x 4 intercepts
+    unsigned da;        // groups x 4 residual sums (combined)
+    unsigned dapart;    // 4 waves x groups x 4
+    unsigned gsw;       // 4 waves x [chain][row] residuals of the tile in hand
+    unsigned llpart;    // 4 waves x 4 chains
+    unsigned end;
+};
+template <int DPB> __host__ __device__ inline ResMap res_map(int nmax, int ngmax, int ntmax) {
+    using Gm = ResGeom<DPB>;
+    const unsigned npad = (((unsigned)nmax + 15u) & ~15u) + 16u;     // a tile may start on any row of a group
+    ResMap m;
+    unsigned o = 0;
+    m.ximg = o; o += npad * Gm::ROWB;
+    m.yimg = o; o += npad * 4;
+    m.tdesc = o; o += ((unsigned)ntmax * 8 + 15) / 16 * 16;
+    m.beta = o; o += (unsigned)ngmax * DPB * NCH * 8;
+    m.gsum = o; o += (unsigned)ngmax * DPB * NCH * 8;
+    m.gpart = o; o += 4u * ngmax * DPB * NCH * 8;
+    m.alpha = o; o += (unsigned)ngmax * NCH * 8;
+    m.da = o; o += (unsigned)ngmax * NCH * 8;
+    m.dapart = o; o += 4u * ngmax * NCH * 8;
+    m.gsw = o; o += 4 * 64 * 8;
+    m.llpart = o; o += 4 * NCH * 8;
+    m.end = o;
+    return m;
+}
+
+// byte offset of element (row, col) in the swizzled row image
+template <int DPB> __device__ inline unsigned ximg_off(int row, int col) {
+    using Gm = ResGeom<DPB>;
+    return (unsigned)row * Gm::ROWB + ((((unsigned)col >> 1) ^ (unsigned)row) & (Gm::CPR - 1)) * 16 + (col & 1) * 8;
+}
+
+// Copy the site's rows into the LDS image (all threads of the workgroup; zero padding).
+template <int DPB>
+__device__ inline void res_load_site(const double *Xg, const int *yg, int n, int D, unsigned B0, const ResMap &M,
+                                     int tid, int nthreads) {
+    using Gm = ResGeom<DPB>;
+    const int npad = ((n + 15) & ~15) + 16;
+    for (int idx = tid; idx < npad * Gm::CPR; idx += nthreads) {
+        const int r = idx / Gm::CPR, c = idx % Gm::CPR;
+        double x0 = 0.0, x1 = 0.0;
+        if (r < n) {
+            if (2 * c < D) x0 = Xg[(size_t)r * D + 2 * c];
+            if (2 * c + 1 < D) x1 = Xg[(size_t)r * D + 2 * c + 1];
+        }
+        const unsigned o = B0 + M.ximg + (unsigned)r * Gm::ROWB + (((unsigned)c ^ (unsigned)r) & (Gm::CPR - 1)) * 16;
+        *lds_d(o) = x0; *lds_d(o + 8) = x1;
+    }
+    for (int r = tid; r < npad; r += nthreads) *lds_i(B0 + M.yimg + r * 4) = r < n ? yg[r] : 0;
+}
+
+// One pass of the resident engine, executed by the 4 chain waves.  In: beta, alpha per group
+// (LDS, published by a barrier before the call), the tile table.  Out (valid on return: the
+// pass ends with barriers): gsum, da per group; returns ll of this wave's chain.
+template <int DPB>
+__device__ inline double resident_pass(unsigned B0, const ResMap &M, int nt, int ngmax, int wave, int lane,
+                                       int nthreads, int tid) {
+    using Gm = ResGeom<DPB>;
+    const int l15 = lane & 15, lg = lane >> 4, l3 = lane & 3;
+    const int frow = 4 * (l15 >> 2) + lg;       // D lane of the forward product -> (row frow, chain l3)
+    // wave-private partials start at zero (a wave may own no tile of some group)
+    for (int i = lane; i < ngmax * DPB * NCH; i += 64) *lds_d(B0 + M.gpart + ((unsigned)wave * ngmax * DPB * NCH + i) * 8) = 0.0;
+    for (int i = lane; i < ngmax * NCH; i += 64) *lds_d(B0 + M.dapart + ((unsigned)wave * ngmax * NCH + i) * 8) = 0.0;
+    double bq[Gm::KS];
+    double acc[Gm::MB];
+#pragma unroll
+    for (int mb = 0; mb < Gm::MB; ++mb) acc[mb] = 0.0;
+    int g_cur = -1;
+    double ll = 0.0, da = 0.0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int mb = 0; mb < Gm::MB; ++mb) {
+            // D lane (i = lg, b = l15 >> 2, j = l3) -> G[column 16 mb + 4 b + i][chain j]
+            *lds_d(B0 + M.gpart + (((unsigned)(wave * ngmax + g_cur) * DPB + 16 * mb + 4 * (l15 >> 2) + lg) * NCH + l3) * 8) = acc[mb];
+            acc[mb] = 0.0;
+        }
+        // residual sum of the group: over the lanes of the same chain (all b, all i)
+        double t = da;
+        t += dpp_d<0x124>(t); t += dpp_d<0x128>(t);            // row_ror 4, 8: the four b of a row of 16
+        t += partner_d<4>(t, lane); t += partner_d<5>(t, lane);  // the four i
+        if (lane < NCH) *lds_d(B0 + M.dapart + ((unsigned)(wave * ngmax + g_cur) * NCH + lane) * 8) = t;
+        da = 0.0;
+    };
+    for (int t = wave; t < nt; t += NCH) {
+        const int row0 = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + t * 8));
+        const int pk = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + t * 8 + 4));
+        const int nval = pk & 255, grp = pk >> 8;
+        if (grp != g_cur) {
+            if (g_cur >= 0) flush();
+            g_cur = grp;
+#pragma unroll
+            for (int ks = 0; ks < Gm::KS; ++ks) bq[ks] = *lds_d(B0 + M.beta + (((unsigned)grp * DPB + 4 * ks + lg) * NCH + l3) * 8);
+        }
+        // ---- forward: rows row0 + (0..15), all columns
+        double a[Gm::KS];
+#pragma unroll
+        for (int ks = 0; ks < Gm::KS; ++ks) a[ks] = *lds_d(B0 + M.ximg + ximg_off<DPB>(row0 + l15, 4 * ks + lg));
+        double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < Gm::KS; ks += 2) {
+            f0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks], bq[ks], f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks + 1], bq[ks + 1], f1, 0, 0, 0);
+        }
+        // ---- logistic terms on the product's own lanes: (row frow, chain l3)
+        const double f = (f0 + f1) + *lds_d(B0 + M.alpha + ((unsigned)grp * NCH + l3) * 8);
+        double l = 0.0, g = 0.0;
+        if (frow < nval) logistic_terms(f, (double)*lds_i(B0 + M.yimg + (row0 + frow) * 4), l, g);
+        ll += l; da += g;
+        const unsigned gsw = B0 + M.gsw + (unsigned)wave * 64 * 8;
+        *lds_d(gsw + (l3 * 16 + frow) * 8) = g;
+        // ---- backward: (all columns) x (rows of the tile) x chains; same wave wrote the residuals
+        double bb[4], aa[4 * Gm::MB];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int rk = 2 * ks + (lg >> 1) + 8 * (lg & 1);
+            bb[ks] = *lds_d(gsw + (l3 * 16 + rk) * 8);
+#pragma unroll
+            for (int mb = 0; mb < Gm::MB; ++mb) aa[ks * Gm::MB + mb] = *lds_d(B0 + M.ximg + ximg_off<DPB>(row0 + rk, 16 * mb + l15));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < Gm::MB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[ks * Gm::MB + mb], bb[ks], acc[mb], 0, 0, 0);
+    }
+    if (g_cur >= 0) flush();
+    {
+        double t = ll;
+        t += dpp_d<0x124>(t); t += dpp_d<0x128>(t);
+        t += partner_d<4>(t, lane); t += partner_d<5>(t, lane);
+        if (lane < NCH) *lds_d(B0 + M.llpart + ((unsigned)wave * NCH + lane) * 8) = t;
+    }
+    lds_barrier();
+    // combine the four waves' partials
+    for (int i = tid; i < ngmax * DPB * NCH; i += nthreads) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NCH; ++w) t += *lds_d(B0 + M.gpart + ((unsigned)w * ngmax * DPB * NCH + i) * 8);
+        *lds_d(B0 + M.gsum + i * 8) = t;
+    }
+    for (int i = tid; i < ngmax * NCH; i += nthreads) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NCH; ++w) t += *lds_d(B0 + M.dapart + ((unsigned)w * ngmax * NCH + i) * 8);
+        *lds_d(B0 + M.da + i * 8) = t;
+    }
+    double llc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NCH; ++w) llc += *lds_d(B0 + M.llpart + ((unsigned)w * NCH + wave) * 8);
+    lds_barrier();
+    return llc;
+}
+
 }  // namespace epx

@@ -23,6 +23,7 @@
 #include "epx_device.h"
 #include "epx_kernels.h"
 #include "epx_stream_tile.h"
+#include <type_traits>
 
 namespace epx {
 
@@ -63,11 +64,15 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 
 constexpr int OM_UNROLL = 16;   // columns of Omega in flight per thread
 
-template <int NV, int DPB>
-__global__ void __launch_bounds__(STREAM_THREADS)
+// RES: the resident variant (rows in LDS for the whole site update, 4 chain waves only, D <= 32)
+template <int NV, int DPB, bool RES>
+__global__ void __launch_bounds__(RES ? 256 : STREAM_THREADS)
 k_nuts_stream(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     using V = VecS<NV>;
+    constexpr int NT = RES ? 256 : STREAM_THREADS;
+    // register vectors when they fit (NV <= 2: 23 x 4 VGPRs), cold store otherwise
+    using CV = typename std::conditional<(RES && NV <= 2), VecS<NV>, ColdV>::type;
     constexpr int SREC = 4 * NV * 64 + 2;       // per-level stack record (doubles)
     constexpr int PMAX = 64 * NV;
 
@@ -89,15 +94,27 @@ k_nuts_stream(NutsArgs a) {
 
     // ---- LDS carve-up
     StreamLds L;
-    L.template carve<DPB>(smem, a.ngmax, a.ntmax);
-    double *mu_s = reinterpret_cast<double *>(smem + stream_map<DPB>(a.ngmax, a.ntmax).end);   // d (padded to even)
+    ResMap RM;
+    unsigned eng_end;
+    if constexpr (RES) {
+        RM = res_map<DPB>(a.n_max, a.ngmax, a.ntmax);
+        L.beta_s = reinterpret_cast<double *>(smem + RM.beta); L.Gs = reinterpret_cast<double *>(smem + RM.gsum);
+        L.alpha_s = reinterpret_cast<double *>(smem + RM.alpha); L.da_s = reinterpret_cast<double *>(smem + RM.da);
+        L.tdesc = reinterpret_cast<int *>(smem + RM.tdesc);
+        eng_end = RM.end;
+    } else {
+        L.template carve<DPB>(smem, a.ngmax, a.ntmax);
+        eng_end = stream_map<DPB>(a.ngmax, a.ntmax).end;
+    }
+    double *mu_s = reinterpret_cast<double *>(smem + eng_end);     // d (padded to even)
     double *vs4 = mu_s + ((d + 1) & ~1);                           // d x 4: phi - mu, [e][chain]
     double *Ovs = vs4 + d * NCH;                                   // d x 4: Omega (phi - mu)
     double *q_s = Ovs + d * NCH;                                   // 4 x PMAX
     double *eq_s = q_s + NCH * PMAX;                               // 4 x PMAX
-    int *sh_done = reinterpret_cast<int *>(eq_s + NCH * PMAX);
+    double *opart = eq_s + NCH * PMAX;                             // RES: 4 waves x d x 4 partial Omega products
+    int *sh_done = reinterpret_cast<int *>(opart + (RES ? NCH * d * NCH : 0));
     if (tid == 0) *sh_done = 0;
-    for (int e = tid; e < d; e += STREAM_THREADS) mu_s[e] = a.cav_mu[(size_t)k * d + e];
+    for (int e = tid; e < d; e += NT) mu_s[e] = a.cav_mu[(size_t)k * d + e];
 
     PassArgs<DPB> site;
     site.Xg = a.X + (size_t)row0 * D; site.yg = a.y32 + row0;
@@ -123,7 +140,12 @@ k_nuts_stream(NutsArgs a) {
         __syncthreads();
         site.ntile = *nt_s;
     }
-    if (wave == NCH) { loader_init<DPB>(site, lane0); ring_prime<DPB>(site, lane0); }
+    if constexpr (RES) {
+        res_load_site<DPB>(site.Xg, site.yg, site.n, D, site.lds0, RM, tid, NT);
+        __syncthreads();
+    } else {
+        if (wave == NCH) { loader_init<DPB>(site, lane0); ring_prime<DPB>(site, lane0); }
+    }
 
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
     const size_t chain_slot = (size_t)sb * a.chains + (active ? chain : 0);
@@ -149,8 +171,10 @@ k_nuts_stream(NutsArgs a) {
 
     // ------------------------------------------------------------- state (as in k_nuts)
     V inv_e, zq, zp, zg;                                                // registers, live across leapfrogs
-    ColdV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;    // cold store
-    auto bind = [&](ColdV &x, int which, int ln) { x.v.b = cold + which * PMAX; x.v.lane = ln; };
+    CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;       // cold store (or registers, see CV)
+    auto bind = [&](CV &x, int which, int ln) {
+        if constexpr (std::is_same<CV, ColdV>::value) { x.v.b = cold + which * PMAX; x.v.lane = ln; }
+    };
 #define EPX_BIND_COLD(ln)                                                                              \
     bind(qs, CV_QS, ln); bind(gs, CV_GS, ln); bind(pq, CV_PQ, ln); bind(pp, CV_PP, ln); bind(pg, CV_PG, ln); \
     bind(mq, CV_MQ, ln); bind(mp, CV_MP, ln); bind(mg, CV_MG, ln); bind(rho, CV_RHO, ln);                 \
@@ -259,8 +283,9 @@ k_nuts_stream(NutsArgs a) {
             const double a0 = model >= 3 ? qc[0] : 0.0;
             for (int g = 0; g < ng; ++g) {
 #pragma unroll
-                for (int b = 0; b < DPB / 64; ++b) {
+                for (int b = 0; b < (DPB + 63) / 64; ++b) {
                     const int c = lane + 64 * b;
+                    if (DPB < 64 && c >= DPB) continue;
                     double bj = 0.0;
                     if (c < D) {
                         const double eb = model == 0 ? 0.0 : qc[d + ng + g * D + c];
@@ -278,8 +303,44 @@ k_nuts_stream(NutsArgs a) {
         STAMP(0);
         lds_barrier();
         {
-            // ---- Omega (phi - mu) for all chains in one pass over Omega (thread = row)
-            if (tid < d) {
+            // ---- Omega (phi - mu) for all chains in one pass over Omega
+            if constexpr (RES) {
+                // d <= 66 here: wave = every 4th column, lane = row (two row groups), partial sums per wave
+                const int r0 = lane < d ? lane : d - 1, r1 = lane + 64 < d ? lane + 64 : d - 1;
+                double o[2][NCH] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                constexpr int CUO = 8;
+                for (int j0 = wave; j0 < d; j0 += NCH * CUO) {
+                    double om0[CUO], om1[CUO];
+#pragma unroll
+                    for (int u = 0; u < CUO; ++u) {
+                        const int j = j0 + NCH * u < d ? j0 + NCH * u : d - 1;
+                        om0[u] = Om_g[(size_t)j * d + r0];
+                        om1[u] = Om_g[(size_t)j * d + r1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CUO; ++u) {
+                        const bool ok = j0 + NCH * u < d;
+                        const int j = ok ? j0 + NCH * u : d - 1;
+                        double2 v01 = *reinterpret_cast<const double2 *>(vs4 + j * NCH);
+                        double2 v23 = *reinterpret_cast<const double2 *>(vs4 + j * NCH + 2);
+                        if (!ok) { v01 = make_double2(0.0, 0.0); v23 = v01; }
+                        o[0][0] = fma(om0[u], v01.x, o[0][0]); o[0][1] = fma(om0[u], v01.y, o[0][1]);
+                        o[0][2] = fma(om0[u], v23.x, o[0][2]); o[0][3] = fma(om0[u], v23.y, o[0][3]);
+                        o[1][0] = fma(om1[u], v01.x, o[1][0]); o[1][1] = fma(om1[u], v01.y, o[1][1]);
+                        o[1][2] = fma(om1[u], v23.x, o[1][2]); o[1][3] = fma(om1[u], v23.y, o[1][3]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = lane + 64 * h;
+                    if (e < d) {
+                        double *dst = opart + ((size_t)wave * d + e) * NCH;
+                        *reinterpret_cast<double2 *>(dst) = make_double2(o[h][0], o[h][1]);
+                        *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[h][2], o[h][3]);
+                    }
+                }
+            } else if (tid < d) {
+                // thread = row
                 double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
                 const double *omp = Om_g + tid;
                 int j = 0;
@@ -312,13 +373,20 @@ k_nuts_stream(NutsArgs a) {
                 const int e = lane + 64 * i;
                 double g = 0.0;
                 if (e < d) {
-                    const double ov = Ovs[e * NCH + wave];
+                    double ov;
+                    if constexpr (RES)
+                        ov = (opart[(0 * d + e) * NCH + wave] + opart[(1 * d + e) * NCH + wave])
+                             + (opart[(2 * d + e) * NCH + wave] + opart[(3 * d + e) * NCH + wave]);
+                    else
+                        ov = Ovs[e * NCH + wave];
                     g = -ov; lpt += -0.5 * vs4[e * NCH + wave] * ov;
                 }
                 zg.v[i] = g;
             }
         }
-        {
+        if constexpr (RES) {
+            ll = resident_pass<DPB>(site.lds0, RM, site.ntile, a.ngmax, wave, lane, NT, tid);
+        } else {
             const PassOut po = stream_pass<DPB>(site);
             site.slot_f = po.slot_f; site.slot_i = po.slot_i; site.t_i = po.t_i;
             ll = po.ll;
@@ -401,7 +469,7 @@ k_nuts_stream(NutsArgs a) {
 #undef EPX_CHAIN_EXIT
 #undef EPX_DBG_EXIT
     }
-    if (wave == NCH) wait_vm<0>();       // drain the prefetched tiles before the LDS goes away
+    if constexpr (!RES) { if (wave == NCH) wait_vm<0>(); }      // drain the prefetched tiles before the LDS goes away
 
 #ifdef EPX_STAMPS
     if (a.stamps && wave == 0 && lane0 == 0) {
@@ -434,10 +502,15 @@ k_nuts_stream(NutsArgs a) {
 }
 
 // LDS bytes of the streaming kernel
-size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax) {
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int nmax_res) {
     const size_t pmax = 64 * (size_t)nv;
-    const size_t eng = dpb == 64 ? stream_map<64>(ngmax, ntmax).end : stream_map<128>(ngmax, ntmax).end;
-    const size_t dbl = (size_t)((d + 1) & ~1) + 2 * (size_t)d * NCH + 2 * NCH * pmax + 2;
+    size_t eng;
+    size_t dbl = (size_t)((d + 1) & ~1) + 2 * (size_t)d * NCH + 2 * NCH * pmax + 2;
+    if (nmax_res > 0) {             // resident variant: dpb in {16, 32}
+        eng = dpb == 16 ? res_map<16>(nmax_res, ngmax, ntmax).end : res_map<32>(nmax_res, ngmax, ntmax).end;
+        dbl += (size_t)NCH * d * NCH;
+    } else
+        eng = dpb == 64 ? stream_map<64>(ngmax, ntmax).end : stream_map<128>(ngmax, ntmax).end;
     return eng + dbl * 8;
 }
 // doubles of global memory per chain: tree stack + cold store
@@ -445,37 +518,41 @@ size_t nuts_stream_chain_doubles(int nv, int max_depth) {
     return (size_t)max_depth * (4 * (size_t)nv * 64 + 2) + (size_t)CV_COUNT * 64 * nv;
 }
 
-template <int NV, int DPB>
+template <int NV, int DPB, bool RES>
 static int launch_stream_one(const NutsArgs &a, int nblocks, size_t lds, hipStream_t stream) {
-    auto kern = k_nuts_stream<NV, DPB>;
+    auto kern = k_nuts_stream<NV, DPB, RES>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(STREAM_THREADS), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(RES ? 256 : STREAM_THREADS), lds, stream, a);
     return (int)hipGetLastError();
 }
 
-template <int DPB>
+template <int DPB, bool RES>
 static int launch_stream_nv(const NutsArgs &a, int nblocks, int nv, size_t lds, hipStream_t stream) {
     switch (nv) {
-    case 1: return launch_stream_one<1, DPB>(a, nblocks, lds, stream);
-    case 2: return launch_stream_one<2, DPB>(a, nblocks, lds, stream);
-    case 3: return launch_stream_one<3, DPB>(a, nblocks, lds, stream);
-    case 4: return launch_stream_one<4, DPB>(a, nblocks, lds, stream);
-    case 5: return launch_stream_one<5, DPB>(a, nblocks, lds, stream);
-    case 6: return launch_stream_one<6, DPB>(a, nblocks, lds, stream);
-    case 7: return launch_stream_one<7, DPB>(a, nblocks, lds, stream);
+    case 1: return launch_stream_one<1, DPB, RES>(a, nblocks, lds, stream);
+    case 2: return launch_stream_one<2, DPB, RES>(a, nblocks, lds, stream);
+    case 3: return launch_stream_one<3, DPB, RES>(a, nblocks, lds, stream);
+    case 4: return launch_stream_one<4, DPB, RES>(a, nblocks, lds, stream);
+    case 5: return launch_stream_one<5, DPB, RES>(a, nblocks, lds, stream);
+    case 6: return launch_stream_one<6, DPB, RES>(a, nblocks, lds, stream);
+    case 7: return launch_stream_one<7, DPB, RES>(a, nblocks, lds, stream);
     }
     return -1;
 }
 
-// count sites; dpb in {64, 128}; nv = ceil(P / 64) <= 7; tree stack and cold store live in a.stack
+// count sites; streaming: dpb in {64, 128}; resident (a.n_max rows in LDS): dpb in {16, 32};
+// nv = ceil(P / 64) <= 7; tree stack and cold store live in a.stack
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream) {
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
-    const size_t lds = nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax);
-    if (dpb == 64) return launch_stream_nv<64>(a, nblocks, nv, lds, stream);
-    if (dpb == 128) return launch_stream_nv<128>(a, nblocks, nv, lds, stream);
+    const bool res = dpb <= 32;
+    const size_t lds = nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax, res ? a.n_max : 0);
+    if (dpb == 16) return launch_stream_nv<16, true>(a, nblocks, nv, lds, stream);
+    if (dpb == 32) return launch_stream_nv<32, true>(a, nblocks, nv, lds, stream);
+    if (dpb == 64) return launch_stream_nv<64, false>(a, nblocks, nv, lds, stream);
+    if (dpb == 128) return launch_stream_nv<128, false>(a, nblocks, nv, lds, stream);
     return -1;
 }
 

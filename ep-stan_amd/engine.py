@@ -262,11 +262,11 @@ class HipEngine(object):
         check(self.lib.epx_get_chain_stats(self.ctx, k0, count, dptr(out)))
         return out
 
-    def logdensity_grad(self, k, theta):
+    def logdensity_grad(self, k, theta, layout=2):
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         lp = ctypes.c_double()
         g = np.zeros(self.P)
-        check(self.lib.epx_logdensity_grad(self.ctx, int(k), dptr(theta), ctypes.byref(lp), dptr(g)))
+        check(self.lib.epx_logdensity_grad_layout(self.ctx, int(k), dptr(theta), int(layout), ctypes.byref(lp), dptr(g)))
         return lp.value, g
 
     def invert_normal_params(self, A, b):

@@ -192,6 +192,9 @@ int epx_force_pd(epx_ctx *ctx, double df, double thresh, double min_eig_target, 
 /* TEST HOOK: log density and gradient of site k at theta (P) against the
  * cavity currently held for that site (Appendix A of SURVEY.md). */
 int epx_logdensity_grad(epx_ctx *ctx, int k, const double *theta, double *lp, double *grad);
+/* The same through a chosen sampler layout (epx_sampler_opts.layout; 0 = what a one-site launch would pick):
+ * every layout evaluates the density with its own gradient code. */
+int epx_logdensity_grad_layout(epx_ctx *ctx, int k, const double *theta, int layout, double *lp, double *grad);
 /* TEST HOOK: sampler only (no moment stage) for sites k0..k0+count */
 int epx_sample_batch(epx_ctx *ctx, int k0, int count, const int64_t *seeds,
                      const epx_sampler_opts *opts, double *stats, double *elapsed_ms);

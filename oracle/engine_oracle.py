@@ -189,7 +189,7 @@ class OracleEngine(object):
         count = self.K - k0 if count is None else count
         return self.chain_stats[k0:k0 + count].copy()
 
-    def logdensity_grad(self, k, theta):
+    def logdensity_grad(self, k, theta, layout=0):
         lo, hi = self.k_lim[k], self.k_lim[k + 1]
         gl = None
         if self.g_cnt is not None:

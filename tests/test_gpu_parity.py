@@ -274,6 +274,9 @@ def test_logdensity_gradient_matches_oracle(model, D, n):
     ('m5b_sg', 4, 50, 1, 60, 100.), ('m2b_sg', 6, 80, 2, 60, 100.), ('m3b_sg', 6, 80, 1, 60, 100.),
     ('m4b_sg', 16, 200, 2, 44, 1000.), ('m4b_sg', 16, 200, 1, 44, 1000.), ('m4b_sg', 32, 120, 1, 44, 1000.),
     ('m1b_sg', 32, 300, 2, 60, 100.), ('m3b_sg', 11, 64, 2, 60, 100.), ('m2b_sg', 32, 100, 1, 44, 1000.),
+    # layout 4: chains in lock step, rows resident, MFMA products
+    ('m4b_sg', 4, 50, 4, 60, 100.), ('m1b_sg', 16, 200, 4, 60, 100.), ('m4b_sg', 32, 120, 4, 44, 1000.),
+    ('m5b_sg', 9, 77, 4, 60, 100.), ('m3b_sg', 32, 300, 4, 44, 1000.), ('m2b_sg', 21, 333, 4, 44, 1000.),
 ])
 def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
     """Whole site updates (random init, step-size search, dual averaging, metric
@@ -314,14 +317,17 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
     if n_full == 12:
         np.testing.assert_allclose(stats[:, 2], st_o[:, :, 2].sum(1))
         rh = [max(no.split_rhat(draws_o[k, :, :, e]) for e in range(P)) for k in range(3)]
-        np.testing.assert_allclose(stats[:, 1], rh, rtol=1e-4)
+        rh = np.array(rh)
+        sane = np.isfinite(rh) & (rh < 1e3)        # a coordinate that never moved gives 0/0-like ratios
+        np.testing.assert_allclose(stats[sane, 1], rh[sane], rtol=1e-4)
+        assert np.all(stats[~sane, 1] > 1e3)
         np.testing.assert_allclose(stats[:, 0], st_o[:, :, 0].mean(1), rtol=1e-5)
 
 
 @pytest.mark.parametrize('model,D,n,layout', [
     ('m4b_sg', 4, 50, 1), ('m4b_sg', 4, 50, 2), ('m5b_sg', 8, 64, 2), ('m3b_sg', 16, 100, 1),
     ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1), ('m4b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 2),
-    ('m1b_sg', 32, 500, 1),
+    ('m1b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 4), ('m4b_sg', 16, 200, 4), ('m1b_sg', 32, 500, 4), ('m3b_sg', 7, 45, 4),
 ])
 def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
     """Generic (wide, funnel-shaped) tilted distributions up to BASELINE config
@@ -372,7 +378,7 @@ def test_nuts_layouts_agree_and_are_deterministic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('model,D,n,layout', [('m4b_sg', 8, 90, 1), ('m4b_sg', 8, 90, 2), ('m4b_sg', 40, 70, 3)])
+@pytest.mark.parametrize('model,D,n,layout', [('m4b_sg', 8, 90, 1), ('m4b_sg', 8, 90, 2), ('m4b_sg', 40, 70, 3), ('m4b_sg', 8, 90, 4)])
 def test_site_order_hint_does_not_change_results(model, D, n, layout):
     """epx_set_site_order only permutes which workgroup takes which site."""
     K = 5
@@ -519,8 +525,8 @@ def test_ragged_sites_and_extreme_shapes():
 
 
 def test_many_sites_batch_and_errors():
-    """K = 600 small sites in one launch (more sites than CUs, layout 1 by default), reproducible
-    and equal to sampling the same sites one at a time; unsupported shapes fail loudly."""
+    """K = 600 small sites in one launch (more sites than CUs: the lock-step layout 4 by default),
+    reproducible and equal to sampling the same sites one at a time; unsupported shapes fail loudly."""
     rng = np.random.RandomState(8)
     K, n, D = 600, 12, 3
     X = rng.randn(K * n, D); y = (rng.rand(K * n) < 0.5).astype(int)
@@ -531,10 +537,16 @@ def test_many_sites_batch_and_errors():
     seeds = np.arange(K) + 100
     opts = HipEngine.sampler_opts(chains=4, iter=20)
     eng.sample_batch(seeds, opts)
+    assert eng.last_layout() == 4
     all_draws = np.stack([eng.get_draws(k, True) for k in (0, 299, 599)])
     for j, k in enumerate((0, 299, 599)):
-        eng.sample_batch(seeds[k:k + 1], HipEngine.sampler_opts(chains=4, iter=20, layout=1), k0=k, count=1)
+        eng.sample_batch(seeds[k:k + 1], HipEngine.sampler_opts(chains=4, iter=20, layout=4), k0=k, count=1)
         np.testing.assert_array_equal(eng.get_draws(k, True), all_draws[j])
+    # the one-wave-per-chain layout runs the same algorithm with another summation order
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=20, layout=1))
+    assert eng.last_layout() == 1
+    for j, k in enumerate((0, 299, 599)):
+        np.testing.assert_allclose(eng.get_draws(k, True)[:3], all_draws[j][:3], rtol=1e-6, atol=1e-8)
     with pytest.raises(_lib.EpxError):                      # D > 128: beyond the streaming variant
         e2 = HipEngine('m1b_sg', rng.randn(40, 200), np.zeros(40, dtype=int), np.array([0, 20, 40]))
         e2.set_global(np.eye(201), np.zeros(201)); e2.cavity_batch(QI)
@@ -792,9 +804,10 @@ def test_multigroup_gradient_matches_oracle(model, D, groups):
         assert np.all(g[Pk:] == 0.0)
 
 
+@pytest.mark.parametrize('layout', [3, 4])
 @pytest.mark.parametrize('model,D,groups,chains', [('m4b', 4, [[20, 14, 9], [25, 25]], 4), ('m1b', 16, [[30, 30], [18, 18, 18]], 3),
-                                                   ('m3b', 8, [[40], [16, 24]], 4)])
-def test_multigroup_site_updates_match_oracle(model, D, groups, chains):
+                                                   ('m3b', 8, [[40], [16, 24]], 4), ('m4b', 32, [[17, 40, 5]], 4)])
+def test_multigroup_site_updates_match_oracle(model, D, groups, chains, layout):
     """Whole short site updates of multi-group sites against the C oracle, chain by chain (same
     random stream; chains are compared until rounding differences make them part)."""
     X, y, k_lim, g_cnt, g_lim, Oms, mus, d = _group_problem(model, D, groups, 70 + D, tight=300.0)
@@ -802,8 +815,8 @@ def test_multigroup_site_updates_match_oracle(model, D, groups, chains):
     K = len(groups)
     seeds = np.arange(K, dtype=np.int64) + 31
     it = 44
-    stats, ms = eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random'))
-    assert eng.last_layout() == 3
+    stats, ms = eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=layout))
+    assert eng.last_layout() == layout
     draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it,
                                      g_cnt=g_cnt, g_lim=g_lim)
     cs = eng.get_chain_stats(chains)
@@ -828,7 +841,7 @@ def test_multigroup_site_updates_match_oracle(model, D, groups, chains):
     for e in (e1, e2):
         for k in range(K):
             assert e.cavity_site(k, Oms[k] + np.eye(d), Oms[k].dot(mus[k]), np.eye(d), np.zeros(d))
-        e.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=20, init='random', layout=3))
+        e.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=20, init='random', layout=layout))
     for k in range(K):
         np.testing.assert_array_equal(e1.get_draws(k, True), e2.get_draws(k, True))
 
@@ -853,7 +866,7 @@ def test_multigroup_ep_posterior_matches_cpu_path_within_monte_carlo_error():
 
     cpu = lambda m, X, y, kl, **g: OracleEngine(m, X, y, kl, **g)
     m_g, S_g, Mg = run(1)
-    assert Mg.engine.last_layout() == 3 and Mg.engine.P == 8 + 2 * 4
+    assert Mg.engine.last_layout() == 4 and Mg.engine.P == 8 + 2 * 4
     m_c1, S_c1, _ = run(1, _engine_factory=cpu)
     m_c2, S_c2, _ = run(2, _engine_factory=cpu)
     sd = np.sqrt(np.diag(S_c1))
