@@ -469,10 +469,12 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // per (site, chain) with 4 cooperating waves
     int layout = o.layout;
     const bool many = count >= 192;
-    // layout 4: one block per site, chains in lock step, rows resident in LDS, MFMA products
-    // (the many-sites layout when it fits; also the home of multi-group sites with small D)
+    // layout 4: one block per site, chains in lock step, rows resident in LDS, MFMA products: the
+    // home of multi-group sites with small D (measured 1.05-1.4x faster than streaming them);
+    // for single-group sites layout 1 is still faster at the C3 site size (132 vs 157 ms per
+    // launch), so it is chosen on request only
     bool lock = false;
-    if ((layout == 4 || (layout == 0 && (many || c->multi))) && c->D <= 32 && nv <= 7) {
+    if ((layout == 4 || (layout == 0 && c->multi)) && c->D <= 32 && nv <= 7) {
         const int dpl = c->D <= 16 ? 16 : 32;
         const size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max);
         if (lds <= LDS_CAP) {

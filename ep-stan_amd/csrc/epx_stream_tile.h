@@ -446,7 +446,8 @@ struct ResMap {
 };
 template <int DPB> __host__ __device__ inline ResMap res_map(int nmax, int ngmax, int ntmax) {
     using Gm = ResGeom<DPB>;
-    const unsigned npad = (((unsigned)nmax + 15u) & ~15u) + 16u;     // a tile may start on any row of a group
+    // with several groups a tile may start on any row: its 16-row window can run 15 rows past the site
+    const unsigned npad = (((unsigned)nmax + 15u) & ~15u) + (ngmax > 1 ? 16u : 0u);
     ResMap m;
     unsigned o = 0;
     m.ximg = o; o += npad * Gm::ROWB;
@@ -472,10 +473,10 @@ template <int DPB> __device__ inline unsigned ximg_off(int row, int col) {
 
 // Copy the site's rows into the LDS image (all threads of the workgroup; zero padding).
 template <int DPB>
-__device__ inline void res_load_site(const double *Xg, const int *yg, int n, int D, unsigned B0, const ResMap &M,
-                                     int tid, int nthreads) {
+__device__ inline void res_load_site(const double *Xg, const int *yg, int n, int D, int ngmax, unsigned B0,
+                                     const ResMap &M, int tid, int nthreads) {
     using Gm = ResGeom<DPB>;
-    const int npad = ((n + 15) & ~15) + 16;
+    const int npad = ((n + 15) & ~15) + (ngmax > 1 ? 16 : 0);
     for (int idx = tid; idx < npad * Gm::CPR; idx += nthreads) {
         const int r = idx / Gm::CPR, c = idx % Gm::CPR;
         double x0 = 0.0, x1 = 0.0;
@@ -492,12 +493,83 @@ __device__ inline void res_load_site(const double *Xg, const int *yg, int n, int
 // One pass of the resident engine, executed by the 4 chain waves.  In: beta, alpha per group
 // (LDS, published by a barrier before the call), the tile table.  Out (valid on return: the
 // pass ends with barriers): gsum, da per group; returns ll of this wave's chain.
+// A wave works on UT of its tiles at a time: one tile is a chain of dependent steps (LDS reads
+// -> MFMA chain -> ~90 dependent logistic instructions -> lane exchange -> MFMA chain), and a
+// lone wave per SIMD has nothing else to issue meanwhile; UT independent tiles fill those slots.
+template <int DPB, int UT>
+__device__ inline void resident_tiles(unsigned B0, const ResMap &M, const int (&tt)[UT], int grp, int lane,
+                                      const double (&bq)[ResGeom<DPB>::KS], double (&acc)[ResGeom<DPB>::MB],
+                                      double &ll, double &da) {
+    using Gm = ResGeom<DPB>;
+    const int l15 = lane & 15, lg = lane >> 4, l3 = lane & 3;
+    const int frow = 4 * (l15 >> 2) + lg;       // D lane of the forward product -> (row frow, chain l3)
+    int row0[UT], nval[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        row0[u] = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + tt[u] * 8));
+        nval[u] = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + tt[u] * 8 + 4)) & 255;
+    }
+    // ---- forward: rows row0 + (0..15), all columns
+    double a[UT][Gm::KS];
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int ks = 0; ks < Gm::KS; ++ks) a[u][ks] = *lds_d(B0 + M.ximg + ximg_off<DPB>(row0[u] + l15, 4 * ks + lg));
+    double f0[UT], f1[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) { f0[u] = 0.0; f1[u] = 0.0; }
+#pragma unroll
+    for (int ks = 0; ks < Gm::KS; ks += 2)
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            f0[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][ks], bq[ks], f0[u], 0, 0, 0);
+            f1[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u][ks + 1], bq[ks + 1], f1[u], 0, 0, 0);
+        }
+    // ---- logistic terms on the product's own lanes: (row frow, chain l3)
+    const double alpha = *lds_d(B0 + M.alpha + ((unsigned)grp * NCH + l3) * 8);
+    double g[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        const double f = (f0[u] + f1[u]) + alpha;
+        const double yy = (double)*lds_i(B0 + M.yimg + (row0[u] + frow) * 4);
+        double l = 0.0, gg = 0.0;
+        logistic_terms(f, yy, l, gg);
+        const bool ok = frow < nval[u];
+        l = ok ? l : 0.0; gg = ok ? gg : 0.0;
+        ll += l; da += gg;
+        g[u] = gg;
+    }
+    // ---- backward: (all columns) x (rows of the tile) x chains.  The B operand of k-step ks in
+    // lane (k = lg, j = l3) is the residual of (row rk, chain l3), which sits in the D lane
+    // 16 (rk & 3) + 4 (rk >> 2) + l3: a lane gather, no LDS storage
+    double bb[UT][4], aa[UT][4 * Gm::MB];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int rk = 2 * ks + (lg >> 1) + 8 * (lg & 1);
+        const int src = 16 * (rk & 3) + 4 * (rk >> 2) + l3;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            bb[u][ks] = __shfl(g[u], src, 64);
+#pragma unroll
+            for (int mb = 0; mb < Gm::MB; ++mb)
+                aa[u][ks * Gm::MB + mb] = *lds_d(B0 + M.ximg + ximg_off<DPB>(row0[u] + rk, 16 * mb + l15));
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+            for (int mb = 0; mb < Gm::MB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[u][ks * Gm::MB + mb], bb[u][ks], acc[mb], 0, 0, 0);
+}
+
 template <int DPB>
 __device__ inline double resident_pass(unsigned B0, const ResMap &M, int nt, int ngmax, int wave, int lane,
                                        int nthreads, int tid) {
     using Gm = ResGeom<DPB>;
+    constexpr int UT = 4;
     const int l15 = lane & 15, lg = lane >> 4, l3 = lane & 3;
-    const int frow = 4 * (l15 >> 2) + lg;       // D lane of the forward product -> (row frow, chain l3)
     // wave-private partials start at zero (a wave may own no tile of some group)
     for (int i = lane; i < ngmax * DPB * NCH; i += 64) *lds_d(B0 + M.gpart + ((unsigned)wave * ngmax * DPB * NCH + i) * 8) = 0.0;
     for (int i = lane; i < ngmax * NCH; i += 64) *lds_d(B0 + M.dapart + ((unsigned)wave * ngmax * NCH + i) * 8) = 0.0;
@@ -521,68 +593,54 @@ __device__ inline double resident_pass(unsigned B0, const ResMap &M, int nt, int
         if (lane < NCH) *lds_d(B0 + M.dapart + ((unsigned)(wave * ngmax + g_cur) * NCH + lane) * 8) = t;
         da = 0.0;
     };
-    for (int t = wave; t < nt; t += NCH) {
-        const int row0 = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + t * 8));
-        const int pk = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + t * 8 + 4));
-        const int nval = pk & 255, grp = pk >> 8;
-        if (grp != g_cur) {
-            if (g_cur >= 0) flush();
-            g_cur = grp;
+    auto tile_group = [&](int t) { return __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + t * 8 + 4)) >> 8; };
+    auto enter_group = [&](int grp) {
+        if (grp == g_cur) return;
+        if (g_cur >= 0) flush();
+        g_cur = grp;
 #pragma unroll
-            for (int ks = 0; ks < Gm::KS; ++ks) bq[ks] = *lds_d(B0 + M.beta + (((unsigned)grp * DPB + 4 * ks + lg) * NCH + l3) * 8);
+        for (int ks = 0; ks < Gm::KS; ++ks) bq[ks] = *lds_d(B0 + M.beta + (((unsigned)grp * DPB + 4 * ks + lg) * NCH + l3) * 8);
+    };
+    int t = wave;
+    while (t < nt) {
+        // UT of this wave's tiles together when they exist and belong to one group, else one
+        const int tlast = t + NCH * (UT - 1);
+        bool batch = tlast < nt;
+        const int grp = tile_group(t);
+        if (batch) batch = tile_group(tlast) == grp;     // groups are contiguous: first == last is enough
+        enter_group(grp);
+        if (batch) {
+            int tt[UT];
+#pragma unroll
+            for (int u = 0; u < UT; ++u) tt[u] = t + NCH * u;
+            resident_tiles<DPB, UT>(B0, M, tt, grp, lane, bq, acc, ll, da);
+            t += NCH * UT;
+        } else {
+            const int tt[1] = {t};
+            resident_tiles<DPB, 1>(B0, M, tt, grp, lane, bq, acc, ll, da);
+            t += NCH;
         }
-        // ---- forward: rows row0 + (0..15), all columns
-        double a[Gm::KS];
-#pragma unroll
-        for (int ks = 0; ks < Gm::KS; ++ks) a[ks] = *lds_d(B0 + M.ximg + ximg_off<DPB>(row0 + l15, 4 * ks + lg));
-        double f0 = 0.0, f1 = 0.0;
-#pragma unroll
-        for (int ks = 0; ks < Gm::KS; ks += 2) {
-            f0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks], bq[ks], f0, 0, 0, 0);
-            f1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ks + 1], bq[ks + 1], f1, 0, 0, 0);
-        }
-        // ---- logistic terms on the product's own lanes: (row frow, chain l3)
-        const double f = (f0 + f1) + *lds_d(B0 + M.alpha + ((unsigned)grp * NCH + l3) * 8);
-        double l = 0.0, g = 0.0;
-        if (frow < nval) logistic_terms(f, (double)*lds_i(B0 + M.yimg + (row0 + frow) * 4), l, g);
-        ll += l; da += g;
-        const unsigned gsw = B0 + M.gsw + (unsigned)wave * 64 * 8;
-        *lds_d(gsw + (l3 * 16 + frow) * 8) = g;
-        // ---- backward: (all columns) x (rows of the tile) x chains; same wave wrote the residuals
-        double bb[4], aa[4 * Gm::MB];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int rk = 2 * ks + (lg >> 1) + 8 * (lg & 1);
-            bb[ks] = *lds_d(gsw + (l3 * 16 + rk) * 8);
-#pragma unroll
-            for (int mb = 0; mb < Gm::MB; ++mb) aa[ks * Gm::MB + mb] = *lds_d(B0 + M.ximg + ximg_off<DPB>(row0 + rk, 16 * mb + l15));
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < Gm::MB; ++mb)
-                acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[ks * Gm::MB + mb], bb[ks], acc[mb], 0, 0, 0);
     }
     if (g_cur >= 0) flush();
     {
-        double t = ll;
-        t += dpp_d<0x124>(t); t += dpp_d<0x128>(t);
-        t += partner_d<4>(t, lane); t += partner_d<5>(t, lane);
-        if (lane < NCH) *lds_d(B0 + M.llpart + ((unsigned)wave * NCH + lane) * 8) = t;
+        double tl = ll;
+        tl += dpp_d<0x124>(tl); tl += dpp_d<0x128>(tl);
+        tl += partner_d<4>(tl, lane); tl += partner_d<5>(tl, lane);
+        if (lane < NCH) *lds_d(B0 + M.llpart + ((unsigned)wave * NCH + lane) * 8) = tl;
     }
     lds_barrier();
     // combine the four waves' partials
     for (int i = tid; i < ngmax * DPB * NCH; i += nthreads) {
-        double t = 0.0;
+        double tsum = 0.0;
 #pragma unroll
-        for (int w = 0; w < NCH; ++w) t += *lds_d(B0 + M.gpart + ((unsigned)w * ngmax * DPB * NCH + i) * 8);
-        *lds_d(B0 + M.gsum + i * 8) = t;
+        for (int w = 0; w < NCH; ++w) tsum += *lds_d(B0 + M.gpart + ((unsigned)w * ngmax * DPB * NCH + i) * 8);
+        *lds_d(B0 + M.gsum + i * 8) = tsum;
     }
     for (int i = tid; i < ngmax * NCH; i += nthreads) {
-        double t = 0.0;
+        double tsum = 0.0;
 #pragma unroll
-        for (int w = 0; w < NCH; ++w) t += *lds_d(B0 + M.dapart + ((unsigned)w * ngmax * NCH + i) * 8);
-        *lds_d(B0 + M.da + i * 8) = t;
+        for (int w = 0; w < NCH; ++w) tsum += *lds_d(B0 + M.dapart + ((unsigned)w * ngmax * NCH + i) * 8);
+        *lds_d(B0 + M.da + i * 8) = tsum;
     }
     double llc = 0.0;
 #pragma unroll

@@ -108,8 +108,8 @@ k_nuts_stream(NutsArgs a) {
     }
     double *mu_s = reinterpret_cast<double *>(smem + eng_end);     // d (padded to even)
     double *vs4 = mu_s + ((d + 1) & ~1);                           // d x 4: phi - mu, [e][chain]
-    double *Ovs = vs4 + d * NCH;                                   // d x 4: Omega (phi - mu)
-    double *q_s = Ovs + d * NCH;                                   // 4 x PMAX
+    double *Ovs = vs4 + d * NCH;                                   // d x 4: Omega (phi - mu)   (streaming variant)
+    double *q_s = Ovs + (RES ? 0 : d * NCH);                       // 4 x PMAX
     double *eq_s = q_s + NCH * PMAX;                               // 4 x PMAX
     double *opart = eq_s + NCH * PMAX;                             // RES: 4 waves x d x 4 partial Omega products
     int *sh_done = reinterpret_cast<int *>(opart + (RES ? NCH * d * NCH : 0));
@@ -141,7 +141,7 @@ k_nuts_stream(NutsArgs a) {
         site.ntile = *nt_s;
     }
     if constexpr (RES) {
-        res_load_site<DPB>(site.Xg, site.yg, site.n, D, site.lds0, RM, tid, NT);
+        res_load_site<DPB>(site.Xg, site.yg, site.n, D, a.ngmax, site.lds0, RM, tid, NT);
         __syncthreads();
     } else {
         if (wave == NCH) { loader_init<DPB>(site, lane0); ring_prime<DPB>(site, lane0); }
@@ -308,7 +308,7 @@ k_nuts_stream(NutsArgs a) {
                 // d <= 66 here: wave = every 4th column, lane = row (two row groups), partial sums per wave
                 const int r0 = lane < d ? lane : d - 1, r1 = lane + 64 < d ? lane + 64 : d - 1;
                 double o[2][NCH] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-                constexpr int CUO = 8;
+                constexpr int CUO = 17;             // all of a wave's columns in flight at d <= 68
                 for (int j0 = wave; j0 < d; j0 += NCH * CUO) {
                     double om0[CUO], om1[CUO];
 #pragma unroll
@@ -506,9 +506,9 @@ size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int n
     const size_t pmax = 64 * (size_t)nv;
     size_t eng;
     size_t dbl = (size_t)((d + 1) & ~1) + 2 * (size_t)d * NCH + 2 * NCH * pmax + 2;
-    if (nmax_res > 0) {             // resident variant: dpb in {16, 32}
+    if (nmax_res > 0) {             // resident variant: dpb in {16, 32}; per-wave Omega partials instead of Ovs
         eng = dpb == 16 ? res_map<16>(nmax_res, ngmax, ntmax).end : res_map<32>(nmax_res, ngmax, ntmax).end;
-        dbl += (size_t)NCH * d * NCH;
+        dbl += (size_t)NCH * d * NCH - (size_t)d * NCH;
     } else
         eng = dpb == 64 ? stream_map<64>(ngmax, ntmax).end : stream_map<128>(ngmax, ntmax).end;
     return eng + dbl * 8;

@@ -6,7 +6,10 @@ import numpy as np
 from epstan_amd import _lib
 from epstan_amd.engine import HipEngine, QI
 NAMES = ['A: transforms', 'Omega pass', 'row stream', 'D: chain rule', 'bookkeeping (other)', 'top barrier', 'bookkeeping (plain leaf)']
-K, D, n = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 128, 2000
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
+layout = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 rng = np.random.RandomState(0)
 X = rng.randn(K * n, D) * 0.3
 y = (rng.rand(K * n) < 0.5).astype(int)
@@ -14,7 +17,7 @@ eng = HipEngine('m4b_sg', X, y, np.arange(K + 1) * n)
 d = eng.d
 eng.set_prior(np.eye(d), np.zeros(d)); eng.set_global(np.eye(d) * 2.0, np.zeros(d))
 assert np.all(eng.cavity_batch(QI))
-stats, ms = eng.sample_batch(np.arange(K) + 1, HipEngine.sampler_opts(chains=4, iter=int(sys.argv[2]) if len(sys.argv) > 2 else 8, init="random"))
+stats, ms = eng.sample_batch(np.arange(K) + 1, HipEngine.sampler_opts(chains=4, iter=int(sys.argv[2]) if len(sys.argv) > 2 else 8, init="random", layout=layout))
 lib = _lib.load()
 buf = np.zeros((4096, 8), dtype=np.uint64)
 lib.epx_dbg_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]

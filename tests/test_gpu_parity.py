@@ -525,8 +525,8 @@ def test_ragged_sites_and_extreme_shapes():
 
 
 def test_many_sites_batch_and_errors():
-    """K = 600 small sites in one launch (more sites than CUs: the lock-step layout 4 by default),
-    reproducible and equal to sampling the same sites one at a time; unsupported shapes fail loudly."""
+    """K = 600 small sites in one launch (more sites than CUs, layout 1 by default), reproducible
+    and equal to sampling the same sites one at a time; unsupported shapes fail loudly."""
     rng = np.random.RandomState(8)
     K, n, D = 600, 12, 3
     X = rng.randn(K * n, D); y = (rng.rand(K * n) < 0.5).astype(int)
@@ -537,14 +537,14 @@ def test_many_sites_batch_and_errors():
     seeds = np.arange(K) + 100
     opts = HipEngine.sampler_opts(chains=4, iter=20)
     eng.sample_batch(seeds, opts)
-    assert eng.last_layout() == 4
+    assert eng.last_layout() == 1
     all_draws = np.stack([eng.get_draws(k, True) for k in (0, 299, 599)])
     for j, k in enumerate((0, 299, 599)):
-        eng.sample_batch(seeds[k:k + 1], HipEngine.sampler_opts(chains=4, iter=20, layout=4), k0=k, count=1)
+        eng.sample_batch(seeds[k:k + 1], HipEngine.sampler_opts(chains=4, iter=20, layout=1), k0=k, count=1)
         np.testing.assert_array_equal(eng.get_draws(k, True), all_draws[j])
-    # the one-wave-per-chain layout runs the same algorithm with another summation order
-    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=20, layout=1))
-    assert eng.last_layout() == 1
+    # the lock-step layout runs the same algorithm with another summation order
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=20, layout=4))
+    assert eng.last_layout() == 4
     for j, k in enumerate((0, 299, 599)):
         np.testing.assert_allclose(eng.get_draws(k, True)[:3], all_draws[j][:3], rtol=1e-6, atol=1e-8)
     with pytest.raises(_lib.EpxError):                      # D > 128: beyond the streaming variant
