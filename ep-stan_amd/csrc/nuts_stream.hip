@@ -158,13 +158,8 @@ k_nuts_stream(NutsArgs a) {
     };
     double *stk_g = uniform_ptr(a.stack + chain_slot * ((size_t)a.max_depth * SREC + (size_t)CV_COUNT * PMAX));
     double *cold = stk_g + (size_t)a.max_depth * SREC;
-#ifdef EPX_EXP_NOSTK
-    auto ld_stk = [&](int off) -> double { return 1e-3 * off; };
-    auto st_stk = [&](int off, double v) { };
-#else
     auto ld_stk = [&](int off) -> double { return stk_g[off]; };
     auto st_stk = [&](int off, double v) { stk_g[off] = v; };
-#endif
 
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
