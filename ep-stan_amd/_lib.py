@@ -71,6 +71,7 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     'epx_last_layout': (ctypes.c_int, [ctypes.c_void_p]),
+    'epx_mix_sums': (ctypes.c_int, [ctypes.c_void_p, c_double_p]),
     'epx_damp_sweep': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, ctypes.c_void_p,
                                       c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p, ctypes.c_int,
                                       c_double_p]),

@@ -321,6 +321,27 @@ k_site_sums_final(SumArgs a) {
     a.out[e] = s;
 }
 
+// Pooled tilted moments (Master.mix_phi, method.py:1250-1296): sums over the sites of the
+// scatter matrices, of the means and of the outer products of the means; same slicing as above
+// (a.Qi = tilted scatter, a.ri = tilted mean; len = 2 d^2 + d).
+__global__ void __launch_bounds__(256)
+k_mix_partial(SumArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (e >= a.len) return;
+    const int d2 = a.d * a.d, d = a.d;
+    const int per = (a.K + a.nslice - 1) / a.nslice;
+    const int kb = b * per, ke = min(a.K, kb + per);
+    double s = 0.0;
+    if (e < d2) { for (int k = kb; k < ke; ++k) s += a.Qi[(size_t)k * d2 + e]; }
+    else if (e < d2 + d) { for (int k = kb; k < ke; ++k) s += a.ri[(size_t)k * d + (e - d2)]; }
+    else {
+        const int i = (e - d2 - d) % d, j = (e - d2 - d) / d;
+        for (int k = kb; k < ke; ++k) s += a.ri[(size_t)k * d + i] * a.ri[(size_t)k * d + j];
+    }
+    a.partial[(size_t)b * a.len + e] = s;
+}
+
 // ------------------------------------------------------------------ global
 // Q = Q0 + sum Qi + df sum dQi, r likewise (method.py:1071-1074), Cholesky
 // check (:1077-1080); with want_moments also S = Q^-1, m = S r (:1211-1216).

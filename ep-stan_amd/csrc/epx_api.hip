@@ -783,6 +783,22 @@ int epx_site_sums(epx_ctx *c, double *packed_host, double *packed_dev) {
     return 0;
 }
 
+int epx_mix_sums(epx_ctx *c, double *out) {
+    CTX(c);
+    if (!c->nsamp) return fail("no tilted moments yet");
+    SumArgs a;
+    a.K = c->K; a.d = c->d; a.len = 2 * c->d * c->d + c->d; a.nslice = c->nslice;
+    a.Qi = c->tilt_scatter; a.ri = c->tilt_mean; a.dQi = nullptr; a.dri = nullptr;
+    a.partial = c->partial; a.out = c->packed;
+    const int nb = (a.len + 255) / 256;
+    hipLaunchKernelGGL(k_mix_partial, dim3(nb, a.nslice), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_site_sums_final, dim3(nb), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, a.out, (size_t)a.len * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 static int launch_global(epx_ctx *c, const double *packed_dev, double df, int want_moments,
                          const double *tgt = nullptr, double *crit = nullptr) {
     GlobalArgs a;

@@ -88,6 +88,7 @@ __global__ void k_site_sums_partial(SumArgs a);
 __global__ void k_site_sums_final(SumArgs a);
 __global__ void k_global(GlobalArgs a);
 __global__ void k_axpy(double *out, const double *x, const double *dx, double df, size_t n);
+__global__ void k_mix_partial(SumArgs a);
 __global__ void k_sweep_flag(const int *all_flag, double *crit);
 __global__ void k_all_flags(const uint8_t *flags, int k0, int count, int *out);
 __global__ void k_invert(InvertArgs a);

@@ -328,6 +328,12 @@ class HipEngine(object):
                                       dptr(xs) if xs is not None else None, int(ns), dptr(out)))
         return out
 
+    def mix_sums(self):
+        """[sum_k scatter_k, sum_k mean_k, sum_k mean_k mean_k'] of the local sites' tilted moments."""
+        out = np.zeros(2 * self.d * self.d + self.d)
+        check(self.lib.epx_mix_sums(self.ctx, dptr(out)))
+        return out
+
     def accept(self, df):
         check(self.lib.epx_accept(self.ctx, float(df)))
 

@@ -579,6 +579,30 @@ class Master(object):
                 ra[:, lo:hi] = rl
         self.Q[...], self.r[...] = self.engine.get_global()
 
+    def mix_phi(self, out_S=None, out_m=None):
+        """Posterior approximation of phi from the pooled tilted samples of the last iteration
+        (method.py:1250-1296): mean of the site means and the pooled covariance
+        `(sum_k scatter_k + sum_k n_k (m_k - m)(m_k - m)') / (n_tot - 1)`.  The reference walks the
+        workers' saved samples; here the per-site tilted means / scatters are already on the
+        device, so three sums over the sites (and one all-reduce) give the same numbers."""
+        if self.iter == 0:
+            raise RuntimeError("Can not mix samples before at least one iteration has been done.")
+        d, K = self.dphi, self.K
+        sums = self.comm.allreduce_sum(self.engine.mix_sums())
+        n = self.engine.get_tilted(0)[2]                # draws per site (the same for every site)
+        sS = sums[:d * d].reshape(d, d, order='F')
+        sm = sums[d * d:d * d + d]
+        smm = sums[d * d + d:].reshape(d, d, order='F')
+        m = sm / K
+        S = (sS + n * (smm - K * np.outer(m, m))) / (n * K - 1)
+        if out_S is None:
+            out_S = np.zeros((d, d), order='F')
+        if out_m is None:
+            out_m = np.zeros(d)
+        out_S[...] = S
+        out_m[...] = m
+        return out_S, out_m
+
     def _site_groups(self):
         """Group structure of the sites from `A_k['J']` and `A_n['j_ind']` (the data the
         reference hands to m*b.stan): groups per site and the row limits of all groups.  The

@@ -207,6 +207,11 @@ int epx_nuts_transitions(epx_ctx *ctx, int k0, int count, const int64_t *seeds, 
                          int t_offset, int layout, const double *q0, const double *eps,
                          const double *inv_e, double *q_out, double *chain_stats);
 /* chain stats of the last sampling call: (count, chains, EPX_ST_COUNT) */
+/* Sums for Master.mix_phi (method.py:1250-1296, the posterior approximation from the pooled tilted
+ * samples): out = [sum_k scatter_k (d*d, column-major), sum_k mean_k (d), sum_k mean_k mean_k' (d*d)] over this
+ * context's sites, from the tilted moments of the last epx_tilted_batch / epx_moments_batch. */
+int epx_mix_sums(epx_ctx *ctx, double *out);
+
 /* Damping sweep (experiment/find_damp.py:146-173, the loop `for di, df in enumerate(damps)`): for every
  * dfs[i] form the proposal Q = Q0 + sum(Qi + df dQi), r likewise, factorise, S = Q^-1, m = S r, all cavities,
  * and score the proposal against a target posterior: out[i*5 + {0..4}] =

@@ -252,6 +252,10 @@ class OracleEngine(object):
                 out[di, 2:] = eo.damp_criteria(Q, r, m_target, S_target, samp_target)
         return out
 
+    def mix_sums(self):
+        mm = np.einsum('ki,kj->ij', self.tilt_mean, self.tilt_mean)
+        return np.concatenate([self.tilt_scatter.sum(0).ravel(order='F'), self.tilt_mean.sum(0), mm.ravel(order='F')])
+
     def accept(self, df):
         self.Qi += df * self.dQi
         self.ri += df * self.dri

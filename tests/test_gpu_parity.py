@@ -885,3 +885,22 @@ def test_fit_main_with_fewer_sites_than_groups_on_gpu(tmp_path, monkeypatch):
     assert res['m_s_ep'].shape == (4, 10) and np.all(np.isfinite(res['S_s_ep']))
     assert np.all(np.linalg.eigvalsh(res['S_s_ep'][-1]) > 0)
     assert os.path.exists(os.path.join(str(tmp_path), 'res_d_m4b_kj.npz'))
+
+
+def test_mix_phi_on_gpu_equals_pooled_sample_moments():
+    """Master.mix_phi (method.py:1250-1296) from the device's per-site tilted moments against the
+    pooled mean / covariance of the actual draws."""
+    mod = models.m1b(6, 3, 30)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=80, df0=0.5)
+    assert M.run(2, verbose=False, seed=4)[0] == 0
+    S, m = M.mix_phi()
+    draws = [M.engine.get_draws(k) for k in range(M.K)]
+    means = np.stack([dk.mean(0) for dk in draws])
+    mref = means.mean(0)
+    allc = np.concatenate([dk - mk for dk, mk in zip(draws, means)])
+    n = draws[0].shape[0]
+    Sref = (allc.T.dot(allc) + n * sum(np.outer(mk - mref, mk - mref) for mk in means)) / (n * M.K - 1)
+    np.testing.assert_allclose(m, mref, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(S, Sref, rtol=1e-8, atol=1e-12)

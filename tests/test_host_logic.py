@@ -360,3 +360,20 @@ def test_multigroup_master_plumbing(tmp_path, monkeypatch):
     bad[4] = 1
     with pytest.raises(ValueError):
         Master('m4b', M.X, M.y, site_sizes=Nk, dphi=6, A_k={'J': Nj_k}, A_n={'j_ind': bad}, _engine_factory=factory)
+
+
+def test_mix_phi_pools_the_tilted_samples(runs):
+    """Master.mix_phi (method.py:1250-1296) against the pooled moments of the samples themselves."""
+    M = _master(runs, 'smooth', 0.5)
+    with pytest.raises(RuntimeError):
+        M.mix_phi()
+    assert M.run(2, verbose=False, seed=3)[0] == 0
+    S, m = M.mix_phi()
+    # from the per-site tilted moments (what the reference computes from saved_samp)
+    means = np.stack([M.engine.get_tilted(k)[1] for k in range(M.K)])
+    scat = sum(M.engine.get_tilted(k)[0] for k in range(M.K))
+    nk = M.engine.get_tilted(0)[2]
+    mref = means.mean(0)
+    Sref = (scat + nk * sum(np.outer(mk - mref, mk - mref) for mk in means)) / (nk * M.K - 1)
+    np.testing.assert_allclose(m, mref, rtol=1e-12)
+    np.testing.assert_allclose(S, Sref, rtol=1e-10, atol=1e-14)
