@@ -36,7 +36,7 @@ def _worker(rank, world, port, mode, outdir):
     import injectors
     tdist.init_process_group('gloo', rank=rank, world_size=world)
     comm = dist.TorchComm()
-    fac = lambda m, X, y, kl: OracleEngine(m, X, y, kl, nthreads=2)
+    fac = lambda m, X, y, kl, **g: OracleEngine(m, X, y, kl, nthreads=2, **g)
     runs = np.load(os.path.join(ROOT, 'tests', 'golden', 'master_run.npz'))
     if mode == 'injected':
         M = Master('m1b_sg', runs['g6_X'], runs['g6_y'], site_sizes=runs['g6_Nj'],
@@ -55,6 +55,20 @@ def _worker(rank, world, port, mode, outdir):
         info, (m_s, S_s) = M.run(4, verbose=False, seed=1)
         np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri,
                  Q=M.Q, klo=M.k_lo, khi=M.k_hi)
+    elif mode == 'groups':
+        # K < J: 7 groups on 3 sites (sharded 1 + 2), with a damping sweep and the pooled moments
+        from epstan_amd.util import distribute_groups
+        mod = models.m4b(7, 2, 25)
+        data = mod.simulate_data(Sigma_x='rand', rng=100)
+        _, _, Q0, r0 = mod.get_prior()
+        Nk, Nj_k, j_ind_k = distribute_groups(7, 3, data.Nj)
+        M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
+                   prior={'Q': Q0, 'r': r0}, chains=4, iter=100, df0=0.4, comm=comm, _engine_factory=fac)
+        sw = dict(damps=np.array([0.1, 0.4, 0.9, -50.0]), m_target=np.zeros(6), S_target=np.eye(6))
+        info, (m_s, S_s) = M.run(1, verbose=False, seed=3, sweep=sw)
+        Sm, mm = M.mix_phi()
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
+                 klo=M.k_lo, khi=M.k_hi, kls=M.sweep_log[0]['kls'], cav=M.sweep_log[0]['cav_pd'], Sm=Sm, mm=mm)
     else:   # real sampler (C oracle NUTS), 6 sites of m4b
         mod = models.m4b(6, 3, 60)
         data = mod.simulate_data(Sigma_x='rand', rng=100)
@@ -116,3 +130,34 @@ def test_sharding_does_not_change_results_with_real_sampler(tmp_path):
         np.testing.assert_allclose(r['Qi'], M.Qi, rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(r['msteps'], an[1], rtol=1e-12)     # max over ALL sites (method.py:1044)
         np.testing.assert_allclose(r['mrhats'], an[2], rtol=1e-12)
+
+
+def test_two_ranks_with_groups_sweep_and_mix(tmp_path):
+    """K < J sharded over two ranks (the group limits are cut at the rank boundary), the damping
+    sweep's flags min-reduced over the ranks, mix_phi's sums all-reduced: all equal to one rank."""
+    sys.path.insert(0, ROOT)
+    from epstan_amd import models
+    from epstan_amd.method import Master
+    from epstan_amd.util import distribute_groups
+    from oracle.engine_oracle import OracleEngine
+    res = _spawn('groups', tmp_path)
+    mod = models.m4b(7, 2, 25)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    Nk, Nj_k, j_ind_k = distribute_groups(7, 3, data.Nj)
+    M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
+               prior={'Q': Q0, 'r': r0}, chains=4, iter=100, df0=0.4,
+               _engine_factory=lambda m, X, y, kl, **g: OracleEngine(m, X, y, kl, nthreads=2, **g))
+    sw = dict(damps=np.array([0.1, 0.4, 0.9, -50.0]), m_target=np.zeros(6), S_target=np.eye(6))
+    info, (m_s, S_s) = M.run(1, verbose=False, seed=3, sweep=sw)
+    Sm, mm = M.mix_phi()
+    assert [(int(r['klo']), int(r['khi'])) for r in res] == [(0, 1), (1, 3)]
+    for r in res:
+        assert int(r['info']) == info == 0
+        np.testing.assert_allclose(r['m'], m_s, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['Qi'], M.Qi, rtol=1e-9, atol=1e-10)
+        np.testing.assert_array_equal(r['cav'], M.sweep_log[0]['cav_pd'])
+        np.testing.assert_allclose(r['kls'], M.sweep_log[0]['kls'], rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(r['mm'], mm, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r['Sm'], Sm, rtol=1e-9, atol=1e-12)
+    assert M.sweep_log[0]['cav_pd'][0] and not M.sweep_log[0]['cav_pd'][-1]
