@@ -463,6 +463,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     a.max_depth = o.max_depth; a.init_mode = o.init;
     a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.y32 = c->y32; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
     a.site_g0 = c->site_g0_d; a.g_lim = c->g_lim_d; a.ngmax = c->ng_max; a.ntmax = c->nt_max;
+    const int no_spec = o.reserved & 1;           // flag: bookkeeping on the gradient waves (A/B and tests)
     int nv = (c->P + 63) / 64;
     int dp = pad_dp(c->D);
     // resident layouts: enough sites to fill the 256 CUs -> one block per site, else one block
@@ -513,6 +514,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         }
         a.stack = c->stack;
     }
+    a.no_spec = no_spec;
     *wpc_out = wpc; *dp_out = dp; *nv_out = nv; *layout_out = layout;
     return 0;
 }

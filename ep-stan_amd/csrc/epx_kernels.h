@@ -134,6 +134,8 @@ struct NutsArgs {
     int off_y, off_Om, off_mu, off_xch, off_stack, lds_bytes;
     int stack_in_lds;
     int om_in_lds;
+    int off_spec;                 // > 0: LDS offset of the speculative kernel's mailbox / control records (layout 2)
+    int no_spec;                  // 1: keep the bookkeeping on the gradient waves (k_nuts) even when off_spec > 0
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int

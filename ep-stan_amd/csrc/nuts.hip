@@ -251,180 +251,7 @@ k_nuts(NutsArgs a) {
 #endif
     for (;;) {
         STAMP(6);
-        // =================================================== leapfrog (single site of the gradient)
-        double kin = 0.0;
-        FORV zp.v[i] += 0.5 * eps_l * zg.v[i];
-        FORV zq.v[i] += eps_l * inv_e.v[i] * zp.v[i];
-        {
-            V eq;
-            FORV eq.v[i] = exp_d(zq.v[i]);
-            double alpha, sa, eta, sb2 = 0.0;
-            double beta_l;
-            if (model == 0) {
-                sa = elemU(eq, 0); eta = elemU(zq, d);
-                alpha = eta * sa; beta_l = gatherV(zq, 1 + lane);
-            } else if (model == 1) {
-                sa = elemU(eq, 0); sb2 = elemU(eq, 1); eta = elemU(zq, 2);
-                alpha = eta * sa; beta_l = gatherV(zq, 3 + lane) * sb2;
-            } else if (model == 2) {
-                sa = elemU(eq, 0); eta = elemU(zq, d);
-                alpha = eta * sa; beta_l = gatherV(zq, d + 1 + lane) * gatherV(eq, 1 + lane);
-            } else {
-                sa = elemU(eq, 1); eta = elemU(zq, d);
-                alpha = elemU(zq, 0) + eta * sa;
-                beta_l = gatherV(zq, 2 + lane) + gatherV(zq, d + 1 + lane) * gatherV(eq, 2 + D + lane);
-            }
-            if (lane >= D) beta_l = 0.0;
-            double bs[DP];
-#pragma unroll
-            for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
-
-            STAMP(0);
-            // ---- fused row pass: f = alpha + x.beta, g = y - sigmoid(f), acc += g x
-            double acc[DP];
-#pragma unroll
-            for (int j = 0; j < DP; ++j) acc[j] = 0.0;
-            double da = 0.0, ll = 0.0;
-            for (int r = wt * 64 + lane; r < n; r += 64 * WPC) {
-                const double2 *rowp = reinterpret_cast<const double2 *>(Xs + (size_t)r * DP);
-                const int sw = (r / RPL) & (SPR - 1);
-                double x[DP];
-#pragma unroll
-                for (int jp = 0; jp < SPR; ++jp) {
-                    const double2 v = rowp[jp ^ sw];
-                    x[2 * jp] = v.x; x[2 * jp + 1] = v.y;
-                }
-                double f0 = alpha, f1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < DP; j += 2) { f0 = fma(x[j], bs[j], f0); f1 = fma(x[j + 1], bs[j + 1], f1); }
-                const double f = f0 + f1;
-                double l, g;
-                logistic_terms(f, (double)ys[r], l, g);
-                ll += l; da += g;
-#pragma unroll
-                for (int j = 0; j < DP; ++j) acc[j] = fma(g, x[j], acc[j]);
-            }
-            STAMP(1);
-            // ---- transposing butterfly: lane ends with the 64-lane sum of acc[lane >> (6-LOG)]
-            butterfly<DP, 5>(acc, lane);
-            wave_sum2(da, ll);
-            double dbl = acc[0];
-
-            STAMP(2);
-            // ---- cavity term: Ov = Omega (phi - mu), this wave's share of the columns
-            V vv, Ov;
-            int ec[NV];                 // row index of this lane's elements, clamped: every load is in range
-            FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? zq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; ec[i] = e < d ? e : d - 1; }
-            {
-                const int jb = (wt * d) / WPC, je = ((wt + 1) * d) / WPC;
-#pragma unroll
-                for (int ii = 0; ii < NV; ++ii) {
-                    const int lo = jb > 64 * ii ? jb : 64 * ii;
-                    const int hi = je < 64 * (ii + 1) ? je : 64 * (ii + 1);
-                    constexpr int CU = OML ? 2 : 8;     // columns in flight: more when Omega streams from L2 (A/B: 2/8 best)
-                    for (int j = lo; j < hi; j += CU) {
-                        double vj[CU], cc[CU][NV];
-#pragma unroll
-                        for (int u = 0; u < CU; ++u) {
-                            const bool ok = j + u < hi;
-                            const int ju = ok ? j + u : j;
-                            const double t2 = readlane_d(vv.v[ii], ju & 63);
-                            vj[u] = ok ? t2 : 0.0;
-                            // unconditional loads (a per-lane `e < d ? load : 0` costs a branch per load)
-                            FORV cc[u][i] = om_at(ju * d + ec[i]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < CU; ++u) { FORV Ov.v[i] = fma(cc[u][i], vj[u], Ov.v[i]); }
-                    }
-                }
-            }
-            FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
-            STAMP(3);
-            if (WPC > 1) {
-                double *rec = xch + ((size_t)parity * WPC + wt) * XREC;
-                rec[lane] = dbl;
-                FORV rec[64 * (1 + i) + lane] = Ov.v[i];
-                if (lane == 0) { rec[64 * (1 + NV)] = da; rec[64 * (1 + NV) + 1] = ll; }
-                __syncthreads();
-                dbl = 0.0; da = 0.0; ll = 0.0;
-                FORV Ov.v[i] = 0.0;
-#pragma unroll
-                for (int w = 0; w < WPC; ++w) {
-                    const double *rw = xch + ((size_t)parity * WPC + w) * XREC;
-                    dbl += rw[lane];
-                    FORV Ov.v[i] += rw[64 * (1 + i) + lane];
-                    da += rw[64 * (1 + NV)];
-                    ll += rw[64 * (1 + NV) + 1];
-                }
-                parity ^= 1;
-            }
-            STAMP(4);
-            da = uniform_d(da); ll = uniform_d(ll);
-            // ---- lp and the chain rule back to (phi, eta, etb)
-            auto dbat = [&](int j) { return __shfl(dbl, (j << (6 - LOG)) & 63, 64); };
-            double dot = 0.0;
-            if (model == 1) {
-                double tsum = 0.0;
-                FORV { const int e = lane + 64 * i; const double t2 = dbat(e - 3); if (e >= 3 && e < P) tsum += t2 * zq.v[i]; }
-                dot = wave_sum(tsum);
-            }
-            double lpt = 0.0;
-            // Branch-free: every candidate value is computed for every lane and the element's own
-            // case is picked with selects (a divergent if/else chain costs an exec-mask branch per
-            // case on this serial path).  Wave-uniform factors first.
-            const double c_da = da, c_sa = da * eta * sa, c_eta = da * sa;
-            FORV {
-                const int e = lane + 64 * i;
-                const double q = zq.v[i];
-                const bool in_phi = e < d, in_par = e < P;
-                const double ov = Ov.v[i];
-                double g = in_phi ? -ov : 0.0;
-                const double lp_phi = -0.5 * vv.v[i] * ov;
-                const double lp_pri = laplace ? -fabs(q) : -0.5 * q * q;
-                lpt += in_phi ? lp_phi : (in_par ? lp_pri : 0.0);
-                const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;    // d/dq of the N(0,1)/Laplace term
-                const double g_eta = c_eta - pr;
-                double add = 0.0, g_etb = 0.0;
-                if (model == 0) {
-                    const double db = dbat(e - 1);
-                    add = (e >= 1 && e <= D) ? db : add;
-                    add = e == 0 ? c_sa : add;
-                } else if (model == 1) {
-                    const double db = dbat(e - 3);
-                    g_etb = db * sb2 - pr;
-                    add = e == 1 ? dot * sb2 : add;
-                    add = e == 0 ? c_sa : add;
-                } else if (model == 2) {
-                    const int j = e <= D ? e - 1 : e - d - 1;
-                    const double db = dbat(j);
-                    const double etb = gatherV(zq, d + 1 + j);
-                    const double sbj = gatherV(eq, 1 + j);
-                    g_etb = db * sbj - pr;
-                    add = (e >= 1 && e <= D) ? db * etb * eq.v[i] : add;
-                    add = e == 0 ? c_sa : add;
-                } else {
-                    const int j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
-                    const double db = dbat(j);
-                    const double etb = gatherV(zq, d + 1 + j);
-                    const double sbj = gatherV(eq, 2 + D + j);
-                    g_etb = db * sbj - pr;
-                    add = (e >= 2 + D && in_phi) ? db * etb * eq.v[i] : add;
-                    add = (e >= 2 && e < 2 + D) ? db : add;
-                    add = e == 1 ? c_sa : add;
-                    add = e == 0 ? c_da : add;
-                }
-                g = in_phi ? g + add : g;
-                g = e == d ? g_eta : g;
-                g = (e > d && in_par) ? g_etb : g;
-                zg.v[i] = in_par ? g : 0.0;
-            }
-            // second half step of the momentum, then ONE reduction for lp and the kinetic energy
-            double ks = 0.0;
-            FORV { zp.v[i] += 0.5 * eps_l * zg.v[i]; ks += inv_e.v[i] * zp.v[i] * zp.v[i]; }
-            wave_sum2(lpt, ks);
-            zlp = lpt + ll;
-            kin = 0.5 * ks;
-        }
+#include "nuts_gradient.inc"
         ngrad += 1.0;
         STAMP(5);
 
@@ -468,6 +295,266 @@ k_nuts(NutsArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// k_nuts_spec: layout 2 (one workgroup = one chain, four cooperating gradient waves) with the
+// tree bookkeeping on a FIFTH wave, one leapfrog behind.
+//
+// In k_nuts every wave runs the bookkeeping / adaptation state machine after each gradient
+// (28 % of a leapfrog at C2) although, along a trajectory, the next leapfrog does not depend on
+// it.  Here the four gradient waves (GW) integrate ahead speculatively -- leapfrog after
+// leapfrog from their own copy of (q, p, grad), publishing every finished state in an LDS
+// mailbox -- and the bookkeeping wave (BK) consumes those states in order with the SAME state
+// machine (nuts_state_machine.inc).  When BK's decision changes the integration state (a new
+// doubling from the other tree end, a new transition, a step-size search trial, a metric
+// update) it posts a restart record; the GWs pick it up two leapfrogs later and drop what they
+// integrated in between.  Accepted states are exactly those of the sequential algorithm, so the
+// draws are bit-identical to k_nuts; the price is two wasted gradients per change of direction
+// (1 % of a depth-10 transition; short trees pay more, but they are not the chains a launch
+// waits for).  Synchronisation: the ONE workgroup barrier per leapfrog that the gradient's
+// exchange needs anyway; mailbox and control records are double buffered by leapfrog parity.
+//   tick s of a GW : gradient (barrier s inside) -> publish state s -> read BK's record of
+//                    interval s-1 -> maybe restart
+//   interval s of BK (between barriers s and s+1): take state s-1 -> state machine -> maybe
+//                    post record s
+enum { SPEC_NONE = 0, SPEC_RESTART = 1, SPEC_EXIT = 2 };
+#pragma push_macro("STAMP")
+#undef STAMP
+#define STAMP(i) do { } while (0)
+
+template <int NV, int DP>
+__global__ void __launch_bounds__(320)
+k_nuts_spec(NutsArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    using V = Vec<NV>;
+    constexpr int WPC = 4;
+    constexpr bool OML = true, STL = true;
+    constexpr int LOG = Log2<DP>::v;
+    constexpr int SPR = DP / 2;
+    constexpr int RPL = DP >= 32 ? 1 : 32 / DP;
+    constexpr int XREC = 64 * (1 + NV) + 2;
+    constexpr int SREC = 4 * NV * 64 + 2;
+    constexpr int MREC = 3 * NV * 64 + 4;             // mailbox: q, p, grad, lp, kin, generation
+    constexpr int CREC = 4 * NV * 64 + 4;             // control: q, p, grad, metric, eps_l, command, stamp
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool is_bk = wave == WPC;
+    const int team = 0, wt = is_bk ? 0 : wave;
+    const int sb = a.order ? a.order[blockIdx.x / a.chains] : (int)(blockIdx.x / a.chains);
+    const int chain = blockIdx.x % a.chains;
+    const int k = a.k0 + sb;
+    const int D = a.D, d = a.d, P = a.P, model = a.model;
+    const int64_t row0 = a.k_lim[k];
+    const int n = (int)(a.k_lim[k + 1] - row0);
+
+    double *Xs = reinterpret_cast<double *>(smem);
+    uint8_t *ys = smem + a.off_y;
+    double *xch = reinterpret_cast<double *>(smem + a.off_xch);
+    double *mbox = reinterpret_cast<double *>(smem + a.off_spec);            // 2 x MREC
+    double *ctrl = mbox + 2 * MREC;                                         // 2 x CREC
+    {
+        const double *Xg = a.X + (size_t)row0 * D;
+        const int nslot = n * SPR;
+        for (int s = tid; s < nslot; s += blockDim.x) {
+            const int r = s / SPR, jp = s % SPR, c0 = 2 * jp;
+            double2 v;
+            if ((D & 1) == 0 && c0 + 1 < D) v = *reinterpret_cast<const double2 *>(Xg + (size_t)r * D + c0);
+            else {
+                v.x = c0 < D ? Xg[(size_t)r * D + c0] : 0.0;
+                v.y = c0 + 1 < D ? Xg[(size_t)r * D + c0 + 1] : 0.0;
+            }
+            const int sw = (r / RPL) & (SPR - 1);
+            *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
+        }
+        for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r];
+    }
+    const double *Om_g = a.cav_Om + (size_t)k * d * d;
+    double *Oms = reinterpret_cast<double *>(smem + a.off_Om);
+    for (int idx = tid; idx < d * d; idx += blockDim.x) Oms[idx] = Om_g[idx];
+    if (tid < 2) { ctrl[tid * CREC + 4 * NV * 64 + 2] = -5.0; mbox[tid * MREC + 3 * NV * 64 + 2] = -5.0; }
+    auto om_at = [&](int idx) -> double { return Oms[idx]; };
+    (void)om_at;
+    const bool laplace = (model == 4);
+    V mu, inv_e, zq, zp, zg;
+    FORV {
+        const int e = lane + 64 * i;
+        mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
+        inv_e.v[i] = 1.0; zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0;
+    }
+    double eps_l = 0.0, zlp = 0.0;
+
+    if (!is_bk) {
+        // =========================================================== gradient waves
+        __syncthreads();                        // rows, Omega and BK's first record are in place
+        int gen = 0, parity = 0;
+        {
+            const double *c = ctrl + 1 * CREC;  // initial record (stamp -1)
+            FORV { zq.v[i] = c[(0 * NV + i) * 64 + lane]; zp.v[i] = c[(1 * NV + i) * 64 + lane];
+                   zg.v[i] = c[(2 * NV + i) * 64 + lane]; inv_e.v[i] = c[(3 * NV + i) * 64 + lane]; }
+            eps_l = c[4 * NV * 64];
+        }
+        for (int s = 0;; ++s) {
+#include "nuts_gradient.inc"
+            (void)kin;
+            if (wt == 0) {
+                double *m = mbox + (s & 1) * MREC;
+                FORV { m[(0 * NV + i) * 64 + lane] = zq.v[i]; m[(1 * NV + i) * 64 + lane] = zp.v[i];
+                       m[(2 * NV + i) * 64 + lane] = zg.v[i]; }
+                if (lane == 0) { m[3 * NV * 64] = zlp; m[3 * NV * 64 + 1] = kin; m[3 * NV * 64 + 2] = (double)gen; }
+            }
+            // BK's word of interval s-1 (complete: it was written before barrier s)
+            const double *c = ctrl + ((s + 1) & 1) * CREC;
+            if (s >= 1 && c[4 * NV * 64 + 2] == (double)(s - 1)) {
+                const int cmd = (int)c[4 * NV * 64 + 1];
+                if (cmd == SPEC_EXIT) break;
+                if (cmd == SPEC_RESTART) {
+                    FORV { zq.v[i] = c[(0 * NV + i) * 64 + lane]; zp.v[i] = c[(1 * NV + i) * 64 + lane];
+                           zg.v[i] = c[(2 * NV + i) * 64 + lane]; inv_e.v[i] = c[(3 * NV + i) * 64 + lane]; }
+                    eps_l = c[4 * NV * 64];
+                    ++gen;
+                }
+            }
+        }
+        return;
+    }
+
+    // =============================================================== bookkeeping wave
+    double *stk_l = reinterpret_cast<double *>(smem + a.off_stack);
+    auto ld_stk = [&](int off) -> double { return stk_l[off]; };
+    auto st_stk = [&](int off, double v) { stk_l[off] = v; };
+    const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
+    V qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, sent_e, in_q, in_p, in_g;
+    double lps = 0, plp = 0, mlp = 0;
+    FORV {
+        wmean.v[i] = 0.0; wm2.v[i] = 0.0; gs.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
+        mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
+    }
+    {
+        const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        FORV {
+            const int e = lane + 64 * i;
+            double q0 = 0.0;
+            if (e < P) {
+                if (a.init_mode == 2) q0 = lastp[e];
+                else if (a.init_mode == 0) {
+                    double u1, u2;
+                    rng_u2(key, 0, K_INIT, (uint32_t)(e >> 1), 0, u1, u2);
+                    q0 = -2.0 + 4.0 * ((e & 1) ? u2 : u1);
+                }
+            }
+            qs.v[i] = q0;
+        }
+    }
+    const double DELTA = 0.8, GAMMA = 0.05, T0 = 10.0, KAPPA = 0.75, LOG08 = -0.2231435513142097558;
+    double eps = 1.0, da_mu = log(10.0), s_bar = 0, x_bar = 0, da_count = 0;
+    int va_init_buf = 75, va_term = 50, va_base = 25;
+    if (va_init_buf + va_base + va_term > a.warmup && a.warmup >= 20) {
+        va_init_buf = (int)(0.15 * a.warmup);
+        va_term = (int)(0.1 * a.warmup);
+        va_base = a.warmup - (va_init_buf + va_term);
+    }
+    int va_counter = 0, va_wsize = va_base, va_next = va_init_buf + va_base - 1;
+    double va_n = 0;
+    double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
+    int ndiv = 0, npost = 0, kept = 0, failed = 0;
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
+    uint32_t ss_t = 0;
+    double H0 = 0, lsw = 0, sum_metro = 0;
+    double u_dir = 0.0, gum = 0.0;
+    double dhb = 0.0, lw_m = -INFINITY, lw_s = 0.0;
+    FORV { zq.v[i] = qs.v[i]; }
+    const bool teacher = a.eps_in != nullptr;
+    if (teacher) {
+        eps = a.eps_in[(size_t)sb * a.chains + chain];
+        if (a.inv_e_in) {
+            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * P;
+            FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
+        }
+    }
+    const uint32_t toff = (uint32_t)a.t_offset + 1u;
+    auto flush_dh = [&](int cnt) {
+        const bool ok = lane < cnt;
+        const double dh = ok ? dhb : -INFINITY;
+        const double mb = wave_max(dh);
+        const double m_new = fmax(lw_m, mb);
+        double w = 0.0, me = 0.0;
+        if (ok) {
+            w = (m_new == -INFINITY) ? 0.0 : exp(dh - m_new);
+            me = dh > 0 ? 1.0 : exp(dh);
+        }
+        wave_sum2(w, me);
+        const double scale = (lw_m == -INFINITY) ? 0.0 : exp(lw_m - m_new);
+        lw_s = lw_s * scale + w;
+        lw_m = m_new;
+        sum_metro += me;
+    };
+    // post the integration state the GWs have to continue from (stamp = interval)
+    double sent_eps = 0.0;
+    auto post = [&](int stamp, int cmd) {
+        double *c = ctrl + (stamp & 1) * CREC;
+        FORV { c[(0 * NV + i) * 64 + lane] = zq.v[i]; c[(1 * NV + i) * 64 + lane] = zp.v[i];
+               c[(2 * NV + i) * 64 + lane] = zg.v[i]; c[(3 * NV + i) * 64 + lane] = inv_e.v[i]; sent_e.v[i] = inv_e.v[i]; }
+        if (lane == 0) { c[4 * NV * 64] = eps_l; c[4 * NV * 64 + 1] = (double)cmd; c[4 * NV * 64 + 2] = (double)stamp; }
+        sent_eps = eps_l;
+    };
+    int gen = 0;
+    post(-1, SPEC_RESTART);                     // the initial point, eps_l = 0: the first "leapfrog" is its gradient
+    __syncthreads();
+    for (int s = 0;; ++s) {
+        __syncthreads();                        // barrier s
+        if (s == 0) continue;
+        const double *m = mbox + ((s - 1) & 1) * MREC;
+        if ((int)m[3 * NV * 64 + 2] != gen) continue;           // integrated past a change of state: dropped
+        FORV { in_q.v[i] = m[(0 * NV + i) * 64 + lane]; in_p.v[i] = m[(1 * NV + i) * 64 + lane];
+               in_g.v[i] = m[(2 * NV + i) * 64 + lane];
+               zq.v[i] = in_q.v[i]; zp.v[i] = in_p.v[i]; zg.v[i] = in_g.v[i]; }
+        zlp = m[3 * NV * 64];
+        const double kin = m[3 * NV * 64 + 1];
+        ngrad += 1.0;
+        V n_rho, n_psl, n_pq, n_pg, psr;
+        double n_key = 0, n_plp = 0;
+#define EPX_CHAIN_EXIT { post(s, SPEC_EXIT); __syncthreads(); break; }
+#define EPX_DBG_EXIT { post(s, SPEC_EXIT); __syncthreads(); return; }
+#define STAMP_LEAF do { } while (0)
+#include "nuts_state_machine.inc"
+#undef STAMP_LEAF
+#undef EPX_CHAIN_EXIT
+#undef EPX_DBG_EXIT
+        // the GWs keep integrating from the state they published; tell them only if that is no
+        // longer where (or how) the trajectory continues
+        int moved = (eps_l != sent_eps) ? 1 : 0;
+        FORV {
+            moved |= (zq.v[i] != in_q.v[i]) | (zp.v[i] != in_p.v[i]) | (zg.v[i] != in_g.v[i]) | (inv_e.v[i] != sent_e.v[i]);
+        }
+        if (__any(moved)) { post(s, SPEC_RESTART); ++gen; }
+    }
+
+    // ------------------------------------------------------------- epilogue (BK owns the chain)
+    {
+        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
+        if (failed) {
+            for (int kk = 0; kk < a.nkeep; ++kk) {
+                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * P;
+                FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
+            }
+        }
+        if (lane == 0) {
+            double *st = a.chain_stats + ((size_t)k * a.chains + chain) * ST_COUNT;
+            st[ST_STEPSIZE_MEAN] = a.iter > 0 && !failed ? eps_sum / a.iter : 0.0;
+            st[ST_STEPSIZE_FINAL] = eps;
+            st[ST_NLEAP] = nleap_tot;
+            st[ST_NGRAD] = ngrad;
+            st[ST_NDIV] = ndiv;
+            st[ST_ACCEPT_MEAN] = npost ? acc_sum / npost : 0.0;
+            st[ST_DEPTH_MEAN] = npost ? depth_sum / npost : 0.0;
+            st[ST_FAIL] = failed;
+        }
+    }
+}
+
+#pragma pop_macro("STAMP")
+
+// ---------------------------------------------------------------------------
 // host side: LDS layout + dispatch over the instantiated shapes
 size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     const int nv = (a.P + 63) / 64;
@@ -488,8 +575,25 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
         a.om_in_lds = 0;
         off = (size_t)a.off_Om;
     }
+    // layout 2 with everything resident: room for the speculative kernel's mailbox / control records?
+    a.off_spec = 0;
+    if (wpc == 4 && a.cpb == 1 && a.om_in_lds && a.stack_in_lds) {
+        const size_t rec = (size_t)2 * ((3 * nv * 64 + 4) + (4 * nv * 64 + 4)) * 8;
+        off = (off + 15) & ~(size_t)15;
+        if (off + rec <= cap) { a.off_spec = (int)off; off += rec; }
+    }
     a.lds_bytes = (int)off;
     return off;
+}
+
+template <int NV, int DP>
+static int launch_spec(const NutsArgs &a, int nblocks, hipStream_t stream) {
+    auto kern = k_nuts_spec<NV, DP>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(320), a.lds_bytes, stream, a);
+    return (int)hipGetLastError();
 }
 
 template <int NV, int DP, int WPC, bool OML, bool STL>
@@ -507,6 +611,7 @@ template <int NV, int DP>
 static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t stream) {
     // (Omega in LDS, stack in LDS): layout 2 has both or neither; layout 1 may have Omega only
     if (wpc == 4) {
+        if (a.off_spec > 0 && !a.no_spec) return launch_spec<NV, DP>(a, nblocks, stream);
         if (a.om_in_lds && a.stack_in_lds) return launch_one<NV, DP, 4, true, true>(a, nblocks, stream);
         return launch_one<NV, DP, 4, false, false>(a, nblocks, stream);
     }

@@ -156,8 +156,9 @@ class HipEngine(object):
     # ---- tilted
     @staticmethod
     def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random',
-                     max_depth=10, layout=0):
+                     max_depth=10, layout=0, flags=0):
         o = SamplerOpts()
+        o.reserved = int(flags)          # bit 0: layout 2 without the speculative bookkeeping wave
         o.chains, o.iter, o.thin = int(chains), int(iter), int(thin)
         o.warmup = -1 if warmup is None else int(warmup)
         if init not in INIT_IDS:

@@ -55,9 +55,11 @@ typedef struct epx_sampler_opts {
     int32_t init;        /* enum epx_init */
     int32_t max_depth;   /* Stan max_treedepth, default 10 */
     int32_t layout;      /* 0 auto, 1 one block per site (rows resident in LDS), 2 one block per
-                            (site, chain), 3 streaming (rows through an LDS tile, chains in lock step;
-                            chosen automatically when the rows do not fit LDS or D > 32) */
-    int32_t reserved;
+                            (site, chain), 3 streaming (rows through an LDS-DMA ring, chains in lock step;
+                            chosen automatically when the rows do not fit LDS or D > 32), 4 lock step with
+                            the rows resident in LDS (D <= 32; default for multi-group sites) */
+    int32_t reserved;    /* flags; bit 0: layout 2 without the speculative bookkeeping wave (same draws,
+                            used for A/B measurements and tests) */
 } epx_sampler_opts;
 
 /* per-site sampler statistics written by epx_tilted_batch (doubles) */

@@ -108,7 +108,7 @@ class OracleEngine(object):
 
     # ---- tilted
     @staticmethod
-    def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random', max_depth=10, layout=0):
+    def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random', max_depth=10, layout=0, flags=0):
         return dict(chains=chains, iter=iter, warmup=warmup, thin=thin, init=init, max_depth=max_depth)
 
     def sample_batch(self, seeds, opts, k0=0, count=None):

@@ -361,6 +361,25 @@ def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
     assert nbad <= 1, nbad
 
 
+@pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m1b_sg', 4, 50), ('m4b_sg', 32, 150), ('m5b_sg', 7, 33)])
+def test_speculative_bookkeeping_wave_gives_identical_draws(model, D, n):
+    """Layout 2 with the tree bookkeeping on a fifth wave (gradient waves integrate ahead and drop
+    what they integrated past a change of state) against the sequential kernel: bit-identical
+    draws, statistics and gradient counts."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 17 + D, K=3, tight=3.0)
+    eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([41, 42, 43], dtype=np.int64)
+    res = []
+    for flags in (1, 0):
+        opts = HipEngine.sampler_opts(chains=4, iter=50, init='random', layout=2, flags=flags)
+        stats, ms = eng.sample_batch(seeds, opts)
+        res.append((np.stack([eng.get_draws(k, True) for k in range(3)]), eng.get_chain_stats(4), stats))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    assert res[0][1][:, :, 2].max() >= 7           # trees of several doublings were built
+
+
 def test_nuts_layouts_agree_and_are_deterministic():
     X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 8, 90, 3, K=2, tight=100.0)
     eng, _, _ = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
