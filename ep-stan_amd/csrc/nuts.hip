@@ -316,9 +316,6 @@ k_nuts(NutsArgs a) {
 //   interval s of BK (between barriers s and s+1): take state s-1 -> state machine -> maybe
 //                    post record s
 enum { SPEC_NONE = 0, SPEC_RESTART = 1, SPEC_EXIT = 2 };
-#pragma push_macro("STAMP")
-#undef STAMP
-#define STAMP(i) do { } while (0)
 
 template <int NV, int DP>
 __global__ void __launch_bounds__(320)
@@ -385,6 +382,11 @@ k_nuts_spec(NutsArgs a) {
         // =========================================================== gradient waves
         __syncthreads();                        // rows, Omega and BK's first record are in place
         int gen = 0, parity = 0;
+#ifdef EPX_STAMPS
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nticks = 0;
+        unsigned long long tprev = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
         {
             const double *c = ctrl + 1 * CREC;  // initial record (stamp -1)
             FORV { zq.v[i] = c[(0 * NV + i) * 64 + lane]; zp.v[i] = c[(1 * NV + i) * 64 + lane];
@@ -392,8 +394,13 @@ k_nuts_spec(NutsArgs a) {
             eps_l = c[4 * NV * 64];
         }
         for (int s = 0;; ++s) {
+            STAMP(6);
 #include "nuts_gradient.inc"
             (void)kin;
+            STAMP(5);
+#ifdef EPX_STAMPS
+            ++nticks;
+#endif
             if (wt == 0) {
                 double *m = mbox + (s & 1) * MREC;
                 FORV { m[(0 * NV + i) * 64 + lane] = zq.v[i]; m[(1 * NV + i) * 64 + lane] = zp.v[i];
@@ -404,7 +411,15 @@ k_nuts_spec(NutsArgs a) {
             const double *c = ctrl + ((s + 1) & 1) * CREC;
             if (s >= 1 && c[4 * NV * 64 + 2] == (double)(s - 1)) {
                 const int cmd = (int)c[4 * NV * 64 + 1];
-                if (cmd == SPEC_EXIT) break;
+                if (cmd == SPEC_EXIT) {
+#ifdef EPX_STAMPS
+                    if (a.stamps && wt == 0 && lane == 0) {
+                        for (int i = 0; i < 7; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
+                        a.stamps[(size_t)blockIdx.x * 8 + 7] = nticks;
+                    }
+#endif
+                    break;
+                }
                 if (cmd == SPEC_RESTART) {
                     FORV { zq.v[i] = c[(0 * NV + i) * 64 + lane]; zp.v[i] = c[(1 * NV + i) * 64 + lane];
                            zg.v[i] = c[(2 * NV + i) * 64 + lane]; inv_e.v[i] = c[(3 * NV + i) * 64 + lane]; }
@@ -551,8 +566,6 @@ k_nuts_spec(NutsArgs a) {
         }
     }
 }
-
-#pragma pop_macro("STAMP")
 
 // ---------------------------------------------------------------------------
 // host side: LDS layout + dispatch over the instantiated shapes
