@@ -251,7 +251,11 @@ k_nuts(NutsArgs a) {
 #endif
     for (;;) {
         STAMP(6);
+#define EPX_AFTER_EXCHANGE_BARRIER do { } while (0)
+#define EPX_DEFER_ENERGY 0
 #include "nuts_gradient.inc"
+#undef EPX_DEFER_ENERGY
+#undef EPX_AFTER_EXCHANGE_BARRIER
         ngrad += 1.0;
         STAMP(5);
 
@@ -329,7 +333,7 @@ k_nuts_spec(NutsArgs a) {
     constexpr int RPL = DP >= 32 ? 1 : 32 / DP;
     constexpr int XREC = 64 * (1 + NV) + 2;
     constexpr int SREC = 4 * NV * 64 + 2;
-    constexpr int MREC = 3 * NV * 64 + 4;             // mailbox: q, p, grad, lp, kin, generation
+    constexpr int MREC = 3 * NV * 64 + 4 + 64;        // mailbox: q, p, grad, ll, -, generation, -, per-lane lp terms
     constexpr int CREC = 4 * NV * 64 + 4;             // control: q, p, grad, metric, eps_l, command, stamp
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -395,7 +399,15 @@ k_nuts_spec(NutsArgs a) {
         }
         for (int s = 0;; ++s) {
             STAMP(6);
+            // BK's word of interval s-1 is complete once barrier s has passed: fetch stamp and
+            // command right there, their latency hides behind the chain rule
+            const double *c = ctrl + ((s + 1) & 1) * CREC;
+            double c_stamp = -9.0, c_cmd = 0.0, lp_lane = 0.0, ll_u = 0.0;
+#define EPX_AFTER_EXCHANGE_BARRIER do { c_stamp = c[4 * NV * 64 + 2]; c_cmd = c[4 * NV * 64 + 1]; } while (0)
+#define EPX_DEFER_ENERGY 1
 #include "nuts_gradient.inc"
+#undef EPX_DEFER_ENERGY
+#undef EPX_AFTER_EXCHANGE_BARRIER
             (void)kin;
             STAMP(5);
 #ifdef EPX_STAMPS
@@ -405,12 +417,11 @@ k_nuts_spec(NutsArgs a) {
                 double *m = mbox + (s & 1) * MREC;
                 FORV { m[(0 * NV + i) * 64 + lane] = zq.v[i]; m[(1 * NV + i) * 64 + lane] = zp.v[i];
                        m[(2 * NV + i) * 64 + lane] = zg.v[i]; }
-                if (lane == 0) { m[3 * NV * 64] = zlp; m[3 * NV * 64 + 1] = kin; m[3 * NV * 64 + 2] = (double)gen; }
+                m[3 * NV * 64 + 4 + lane] = lp_lane;
+                if (lane == 0) { m[3 * NV * 64] = ll_u; m[3 * NV * 64 + 2] = (double)gen; }
             }
-            // BK's word of interval s-1 (complete: it was written before barrier s)
-            const double *c = ctrl + ((s + 1) & 1) * CREC;
-            if (s >= 1 && c[4 * NV * 64 + 2] == (double)(s - 1)) {
-                const int cmd = (int)c[4 * NV * 64 + 1];
+            if (s >= 1 && c_stamp == (double)(s - 1)) {
+                const int cmd = (int)c_cmd;
                 if (cmd == SPEC_EXIT) {
 #ifdef EPX_STAMPS
                     if (a.stamps && wt == 0 && lane == 0) {
@@ -522,8 +533,12 @@ k_nuts_spec(NutsArgs a) {
         FORV { in_q.v[i] = m[(0 * NV + i) * 64 + lane]; in_p.v[i] = m[(1 * NV + i) * 64 + lane];
                in_g.v[i] = m[(2 * NV + i) * 64 + lane];
                zq.v[i] = in_q.v[i]; zp.v[i] = in_p.v[i]; zg.v[i] = in_g.v[i]; }
-        zlp = m[3 * NV * 64];
-        const double kin = m[3 * NV * 64 + 1];
+        // lp and the kinetic energy: the reductions the gradient waves left to this wave
+        double lpt = m[3 * NV * 64 + 4 + lane], ks = 0.0;
+        FORV ks += inv_e.v[i] * zp.v[i] * zp.v[i];
+        wave_sum2(lpt, ks);
+        zlp = lpt + m[3 * NV * 64];
+        const double kin = 0.5 * ks;
         ngrad += 1.0;
         V n_rho, n_psl, n_pq, n_pg, psr;
         double n_key = 0, n_plp = 0;
@@ -591,7 +606,7 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     // layout 2 with everything resident: room for the speculative kernel's mailbox / control records?
     a.off_spec = 0;
     if (wpc == 4 && a.cpb == 1 && a.om_in_lds && a.stack_in_lds) {
-        const size_t rec = (size_t)2 * ((3 * nv * 64 + 4) + (4 * nv * 64 + 4)) * 8;
+        const size_t rec = (size_t)2 * ((3 * nv * 64 + 4 + 64) + (4 * nv * 64 + 4)) * 8;
         off = (off + 15) & ~(size_t)15;
         if (off + rec <= cap) { a.off_spec = (int)off; off += rec; }
     }
