@@ -477,10 +477,13 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     bool lock = false;
     if ((layout == 4 || (layout == 0 && c->multi)) && c->D <= 32 && nv <= 7) {
         const int dpl = c->D <= 16 ? 16 : 32;
-        const size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max);
+        size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max);
         if (lds <= LDS_CAP) {
             lock = true; layout = 4; dp = dpl;
-            a.cpb = 4; a.n_max = c->n_max; a.stack_in_lds = 0; a.om_in_lds = 0; a.lds_bytes = (int)lds;
+            a.cpb = 4; a.n_max = c->n_max; a.stack_in_lds = 0; a.om_in_lds = 0;
+            const size_t om = (size_t)c->d * c->d * 8;
+            if (lds + om <= LDS_CAP) { a.om_in_lds = 1; lds += om; }       // small sites: Omega next to the rows
+            a.lds_bytes = (int)lds;
         }
     }
     if (layout == 4 && !lock) layout = 0;

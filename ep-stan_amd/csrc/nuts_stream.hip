@@ -112,7 +112,8 @@ k_nuts_stream(NutsArgs a) {
     double *q_s = Ovs + (RES ? 0 : d * NCH);                       // 4 x PMAX
     double *eq_s = q_s + NCH * PMAX;                               // 4 x PMAX
     double *opart = eq_s + NCH * PMAX;                             // RES: 4 waves x d x 4 partial Omega products
-    int *sh_done = reinterpret_cast<int *>(opart + (RES ? NCH * d * NCH : 0));
+    double *Om_s = opart + (RES ? NCH * d * NCH : 0);              // RES: Omega itself when it fits (a.om_in_lds)
+    int *sh_done = reinterpret_cast<int *>(Om_s + ((RES && a.om_in_lds) ? d * d : 0));
     if (tid == 0) *sh_done = 0;
     for (int e = tid; e < d; e += NT) mu_s[e] = a.cav_mu[(size_t)k * d + e];
 
@@ -148,6 +149,9 @@ k_nuts_stream(NutsArgs a) {
     }
 
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
+    if constexpr (RES) {
+        if (a.om_in_lds) { for (int i = tid; i < d * d; i += NT) Om_s[i] = Om_g[i]; }
+    }
     const size_t chain_slot = (size_t)sb * a.chains + (active ? chain : 0);
     // wave-uniform base pointers (held in scalar registers; lanes add lane*8)
     auto uniform_ptr = [](double *p) -> double * {
@@ -304,27 +308,32 @@ k_nuts_stream(NutsArgs a) {
                 const int r0 = lane < d ? lane : d - 1, r1 = lane + 64 < d ? lane + 64 : d - 1;
                 double o[2][NCH] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
                 constexpr int CUO = 17;             // all of a wave's columns in flight at d <= 68
-                for (int j0 = wave; j0 < d; j0 += NCH * CUO) {
-                    double om0[CUO], om1[CUO];
+                auto omega_cols = [&](auto load) {
+                    for (int j0 = wave; j0 < d; j0 += NCH * CUO) {
+                        double om0[CUO], om1[CUO];
 #pragma unroll
-                    for (int u = 0; u < CUO; ++u) {
-                        const int j = j0 + NCH * u < d ? j0 + NCH * u : d - 1;
-                        om0[u] = Om_g[(size_t)j * d + r0];
-                        om1[u] = Om_g[(size_t)j * d + r1];
-                    }
+                        for (int u = 0; u < CUO; ++u) {
+                            const int j = j0 + NCH * u < d ? j0 + NCH * u : d - 1;
+                            om0[u] = load(j * d + r0);
+                            om1[u] = load(j * d + r1);
+                        }
 #pragma unroll
-                    for (int u = 0; u < CUO; ++u) {
-                        const bool ok = j0 + NCH * u < d;
-                        const int j = ok ? j0 + NCH * u : d - 1;
-                        double2 v01 = *reinterpret_cast<const double2 *>(vs4 + j * NCH);
-                        double2 v23 = *reinterpret_cast<const double2 *>(vs4 + j * NCH + 2);
-                        if (!ok) { v01 = make_double2(0.0, 0.0); v23 = v01; }
-                        o[0][0] = fma(om0[u], v01.x, o[0][0]); o[0][1] = fma(om0[u], v01.y, o[0][1]);
-                        o[0][2] = fma(om0[u], v23.x, o[0][2]); o[0][3] = fma(om0[u], v23.y, o[0][3]);
-                        o[1][0] = fma(om1[u], v01.x, o[1][0]); o[1][1] = fma(om1[u], v01.y, o[1][1]);
-                        o[1][2] = fma(om1[u], v23.x, o[1][2]); o[1][3] = fma(om1[u], v23.y, o[1][3]);
+                        for (int u = 0; u < CUO; ++u) {
+                            const bool ok = j0 + NCH * u < d;
+                            const int j = ok ? j0 + NCH * u : d - 1;
+                            double2 v01 = *reinterpret_cast<const double2 *>(vs4 + j * NCH);
+                            double2 v23 = *reinterpret_cast<const double2 *>(vs4 + j * NCH + 2);
+                            if (!ok) { v01 = make_double2(0.0, 0.0); v23 = v01; }
+                            o[0][0] = fma(om0[u], v01.x, o[0][0]); o[0][1] = fma(om0[u], v01.y, o[0][1]);
+                            o[0][2] = fma(om0[u], v23.x, o[0][2]); o[0][3] = fma(om0[u], v23.y, o[0][3]);
+                            o[1][0] = fma(om1[u], v01.x, o[1][0]); o[1][1] = fma(om1[u], v01.y, o[1][1]);
+                            o[1][2] = fma(om1[u], v23.x, o[1][2]); o[1][3] = fma(om1[u], v23.y, o[1][3]);
+                        }
                     }
-                }
+                };
+                // Omega from LDS when the site leaves room for it (small sites), else from L2
+                if (a.om_in_lds) omega_cols([&](int idx) { return Om_s[idx]; });
+                else omega_cols([&](int idx) { return Om_g[idx]; });
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int e = lane + 64 * h;
@@ -543,7 +552,7 @@ int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
     const bool res = dpb <= 32;
-    const size_t lds = nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax, res ? a.n_max : 0);
+    const size_t lds = res ? (size_t)a.lds_bytes : nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax, 0);
     if (dpb == 16) return launch_stream_nv<16, true>(a, nblocks, nv, lds, stream);
     if (dpb == 32) return launch_stream_nv<32, true>(a, nblocks, nv, lds, stream);
     if (dpb == 64) return launch_stream_nv<64, false>(a, nblocks, nv, lds, stream);
