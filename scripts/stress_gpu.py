@@ -1,0 +1,100 @@
+"""Randomised cross-checks of the sampler kernels on the GPU (not part of the test suite):
+  * layout 2 with / without the bookkeeping wave: bit-identical draws and statistics,
+  * layouts 3 and 4 against layout 1 (same algorithm, other summation order): first draws,
+  * multi-group gradients (layouts 3, 4) against the C oracle.
+Usage: python scripts/stress_gpu.py [seconds]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from epstan_amd.engine import HipEngine
+from oracle import nuts_oracle as no
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.RandomState(int(os.environ.get('STRESS_SEED', '0')))
+MODELS = ['m1b', 'm2b', 'm3b', 'm4b', 'm5b']
+t0 = time.time()
+nspec = nlay = ngrp = 0
+
+
+def cavities(eng, rng, tight):
+    d = eng.d
+    for k in range(eng.K):
+        A = rng.randn(d, d + 3)
+        Om = (A.dot(A.T) / (d + 3) + 0.5 * np.eye(d)) * tight
+        mu = 0.4 * rng.randn(d)
+        assert eng.cavity_site(k, Om + np.eye(d), Om.dot(mu), np.eye(d), np.zeros(d))
+
+
+while time.time() - t0 < budget:
+    model = MODELS[rng.randint(5)]
+    D = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 21, 32]))
+    K = int(rng.randint(1, 5))
+    sizes = rng.randint(1, 260, size=K)
+    N = int(sizes.sum())
+    X = rng.randn(N, D) * rng.choice([0.3, 1.0, 2.0])
+    y = (rng.rand(N) < rng.uniform(0.2, 0.8)).astype(int)
+    k_lim = np.concatenate(([0], np.cumsum(sizes)))
+    chains = int(rng.choice([1, 2, 3, 4, 5]))
+    it = int(rng.choice([6, 20, 41]))
+    thin = int(rng.choice([1, 1, 2]))
+    depth = int(rng.choice([2, 5, 10]))
+    tight = float(rng.choice([1.0, 30.0, 1000.0]))
+    seeds = rng.randint(1, 2**31 - 1, size=K).astype(np.int64)
+    eng = HipEngine(model + '_sg', X, y, k_lim)
+    cavities(eng, rng, tight)
+    P = eng.P
+    # ---- bookkeeping wave vs sequential kernel
+    out = []
+    for flags in (1, 0):
+        o = HipEngine.sampler_opts(chains=chains, iter=it, thin=thin, init='random', max_depth=depth, layout=2, flags=flags)
+        st, ms = eng.sample_batch(seeds, o)
+        out.append((np.stack([eng.get_draws(k, True) for k in range(K)]), eng.get_chain_stats(chains), st))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b, equal_nan=True), ('spec', model, D, sizes, chains, it, thin, depth, tight)
+    nspec += 1
+    # ---- lock-step layouts vs one wave per chain
+    ref = None
+    for layout in (1, 3, 4):
+        o = HipEngine.sampler_opts(chains=chains, iter=it, thin=thin, init='random', max_depth=depth, layout=layout)
+        eng.sample_batch(seeds, o)
+        assert eng.last_layout() == layout, (layout, eng.last_layout())
+        dr = np.stack([eng.get_draws(k, True) for k in range(K)])
+        fails = eng.get_chain_stats(chains)[:, :, 7]
+        if ref is None:
+            ref, ref_f = dr, fails
+        else:
+            if it > 6:          # trajectories are chaotic: rounding differences grow past any tolerance
+                assert np.isfinite(dr).all()
+                continue
+            nk = dr.shape[1] // chains
+            first = dr.reshape(K, chains, nk, P)[:, :, :1]
+            first_r = ref.reshape(K, chains, nk, P)[:, :, :1]
+            err = np.abs(first - first_r).max() / max(1.0, np.abs(first_r).max())
+            assert err < 1e-5, ('layout', layout, model, D, sizes, chains, it, depth, tight, err)
+    nlay += 1
+    # ---- multi-group gradients
+    if D <= 16 and model != 'm1b' or rng.rand() < 0.5:
+        groups = [list(rng.randint(1, 60, size=rng.randint(1, 5))) for _ in range(K)]
+        sz = [int(np.sum(g)) for g in groups]
+        Ng = int(np.sum(sz))
+        Xg = rng.randn(Ng, D); yg = (rng.rand(Ng) < 0.5).astype(int)
+        kl = np.concatenate(([0], np.cumsum(sz)))
+        g_cnt = np.array([len(g) for g in groups], dtype=np.int32)
+        g_lim = np.concatenate(([0], np.cumsum([n for g in groups for n in g])))
+        if no.dims(model, D, int(g_cnt.max()))[1] <= 448:
+            eg = HipEngine(model, Xg, yg, kl, g_cnt=g_cnt, g_lim=g_lim)
+            cavities(eg, rng, 1.0)
+            off = np.concatenate(([0], np.cumsum(g_cnt)))
+            for k in range(K):
+                Pk = int(eg.site_P[k])
+                th = np.zeros(eg.P); th[:Pk] = rng.randn(Pk) * 0.3
+                Om, mu = eg.get_cavity(k)
+                gl = g_lim[off[k]:off[k + 1] + 1] - kl[k]
+                lpo, go = no.logdensity_grad(model, Xg[kl[k]:kl[k + 1]], yg[kl[k]:kl[k + 1]], mu, Om, th[:Pk], gl=gl)
+                for layout in (3, 4):
+                    lp, g = eg.logdensity_grad(k, th, layout=layout)
+                    assert abs(lp - lpo) <= 1e-9 * max(1.0, abs(lpo)), ('mg lp', layout, model, D, groups)
+                    assert np.allclose(g[:Pk], go, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go).max())), ('mg grad', layout, model, D, groups)
+            ngrp += 1
+print('stress ok: %d spec comparisons, %d layout comparisons, %d multi-group gradient sets in %.0f s'
+      % (nspec, nlay, ngrp, time.time() - t0))
