@@ -76,6 +76,9 @@ SIGNATURES = {
                                       c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p, ctypes.c_int,
                                       c_double_p]),
     'epx_set_site_order': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    'epx_set_site_split': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'epx_last_split': (ctypes.c_int, [ctypes.c_void_p]),
+    'epx_cu_count': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_get_chain_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p]),
     'epx_rng_probe': (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32,
                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_double_p]),

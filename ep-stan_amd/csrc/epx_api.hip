@@ -73,6 +73,9 @@ struct epx_ctx {
     int nsamp;                // draws per site of the last tilted/moments call
     double last_df;
     hipEvent_t ev0, ev1;
+    hipStream_t stream2;            // second queue of a split sampling launch (epx_set_site_split)
+    hipEvent_t ev_fork, ev_join;
+    int split_n, last_split, n_cu;
     unsigned long long *stamps;
     size_t stamps_n, stamps_last;
     int last_layout;
@@ -207,6 +210,22 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
+    {
+        // own priority level = own hardware queue: normal-priority streams share 4 queues round-robin
+        // by first use, and two streams on one queue run their kernels one after the other (measured:
+        // scripts/probe/concurrent.hip)
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+    }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->split_n = 0; c->last_split = 0;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        c->n_cu = prop.multiProcessorCount;
+    }
     const size_t K = K_local, d2 = (size_t)d * d;
     HIPCHK(dalloc(&c->k_lim_d, K + 1));
     if (c->multi) {
@@ -268,6 +287,9 @@ int epx_ctx_destroy(epx_ctx *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -455,7 +477,8 @@ static int pad_dp(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 
 // layout (out): 1 = one block per site (wave = chain, X resident in LDS), 2 = one block per
 // (site, chain) with 4 cooperating waves, 3 = streaming (chains in lock step, X through an LDS tile)
 static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts &o, NutsArgs &a,
-                           int *wpc_out, int *dp_out, int *nv_out, int *layout_out) {
+                           int *wpc_out, int *dp_out, int *nv_out, int *layout_out, int stack_sites = 0) {
+    if (stack_sites < count) stack_sites = count;       // the HBM tree stack is indexed by site: a split launch sizes it for all
     const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
     memset(&a, 0, sizeof a);
     a.model = c->model; a.D = c->D; a.d = c->d; a.P = c->P; a.k0 = k0;
@@ -508,8 +531,8 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {
-        const size_t need = layout >= 3 ? (size_t)count * o.chains * nuts_stream_chain_doubles(nv, o.max_depth)
-                                        : (size_t)count * o.chains * o.max_depth * (4 * nv * 64 + 2);
+        const size_t need = layout >= 3 ? (size_t)stack_sites * o.chains * nuts_stream_chain_doubles(nv, o.max_depth)
+                                        : (size_t)stack_sites * o.chains * o.max_depth * (4 * nv * 64 + 2);
         if (c->stack_elems < need) {
             if (c->stack) (void)hipFree(c->stack);
             HIPCHK(dalloc(&c->stack, need));
@@ -539,7 +562,33 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
     a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
+    // Split launch (epx_set_site_split): the leading sites of the order -- the ones expected to
+    // need the most leapfrogs -- run one workgroup per chain (layout 2, shorter leapfrog) on a
+    // second queue while the rest run one workgroup per site (layout 1, more chains per CU).
+    // The launch ends with its slowest chain; this takes that chain at the faster tick.
+    NutsArgs a2;
+    int wpc2 = 0, dp2 = 0, nv2 = 0, n_lead = 0;
+    if (o.layout == 0 && layout == 1 && a.order && c->split_n > 0 && !eps_dev) {
+        n_lead = c->split_n < count ? c->split_n : count - 1;
+        const int cap = c->n_cu / (2 * o.chains);          // at most half of the CUs for the lead sites
+        if (n_lead > cap) n_lead = cap;
+        if (n_lead > 0) {
+            epx_sampler_opts o2 = o;
+            o2.layout = 2;
+            int layout2;
+            if (build_nuts_args(c, k0, n_lead, o2, a2, &wpc2, &dp2, &nv2, &layout2, count)) return -1;
+            if (layout2 != 2) n_lead = 0;
+            else {
+                a2.seeds = c->seeds_d; a2.draws = c->draws; a2.last = c->last; a2.chain_stats = c->chain_stats;
+                a2.eps_in = nullptr; a2.inv_e_in = nullptr; a2.t_offset = t_offset;
+                a2.order = a.order;
+                a.order = a.order + n_lead;
+            }
+        }
+    }
+    c->last_split = n_lead;
 #ifdef EPX_STAMPS
+    n_lead = 0; a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr; c->last_split = 0;
     {
         const int nblk = count * ((o.chains + a.cpb - 1) / a.cpb);
         if (c->stamps_n < (size_t)nblk) {
@@ -554,7 +603,15 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
 #endif
     HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    int rc = launch_sampler(a, count, wpc, dp, nv, layout, c->stream);
+    int rc = 0;
+    if (n_lead > 0) {
+        HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        rc = launch_sampler(a2, n_lead, wpc2, dp2, nv2, 2, c->stream2);
+        HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    }
+    if (rc == 0) rc = launch_sampler(a, count - n_lead, wpc, dp, nv, layout, c->stream);
+    if (n_lead > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (rc != 0) return fail("NUTS kernel launch failed (%d: %s)", rc, rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     RhatArgs ra;
@@ -720,6 +777,23 @@ int epx_set_site_order(epx_ctx *c, const int32_t *order, int count) {
     HIPCHK(hipMemcpy(c->order_d, order, (size_t)count * sizeof(int), hipMemcpyHostToDevice));
     c->order_n = count;
     return 0;
+}
+
+int epx_set_site_split(epx_ctx *c, int n_lead) {
+    CTX(c);
+    if (n_lead < 0 || n_lead > c->K) return fail("site split %d outside 0..%d", n_lead, c->K);
+    c->split_n = n_lead;
+    return 0;
+}
+
+int epx_last_split(epx_ctx *c) {
+    if (!c) return fail("null context");
+    return c->last_split;
+}
+
+int epx_cu_count(epx_ctx *c) {
+    if (!c) return fail("null context");
+    return c->n_cu;
 }
 
 int epx_last_layout(epx_ctx *c) {

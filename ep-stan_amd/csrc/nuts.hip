@@ -321,13 +321,13 @@ k_nuts(NutsArgs a) {
 //                    post record s
 enum { SPEC_NONE = 0, SPEC_RESTART = 1, SPEC_EXIT = 2 };
 
-template <int NV, int DP>
+template <int NV, int DP, bool RES>
 __global__ void __launch_bounds__(320)
 k_nuts_spec(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     using V = Vec<NV>;
     constexpr int WPC = 4;
-    constexpr bool OML = true, STL = true;
+    constexpr bool OML = RES, STL = RES;              // Omega and the tree stack: both in LDS, or L2 / HBM
     constexpr int LOG = Log2<DP>::v;
     constexpr int SPR = DP / 2;
     constexpr int RPL = DP >= 32 ? 1 : 32 / DP;
@@ -369,9 +369,11 @@ k_nuts_spec(NutsArgs a) {
     }
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);
-    for (int idx = tid; idx < d * d; idx += blockDim.x) Oms[idx] = Om_g[idx];
+    if constexpr (OML) {
+        for (int idx = tid; idx < d * d; idx += blockDim.x) Oms[idx] = Om_g[idx];
+    }
     if (tid < 2) { ctrl[tid * CREC + 4 * NV * 64 + 2] = -5.0; mbox[tid * MREC + 3 * NV * 64 + 2] = -5.0; }
-    auto om_at = [&](int idx) -> double { return Oms[idx]; };
+    auto om_at = [&](int idx) -> double { if constexpr (OML) return Oms[idx]; else return Om_g[idx]; };
     (void)om_at;
     const bool laplace = (model == 4);
     V mu, inv_e, zq, zp, zg;
@@ -444,8 +446,9 @@ k_nuts_spec(NutsArgs a) {
 
     // =============================================================== bookkeeping wave
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack);
-    auto ld_stk = [&](int off) -> double { return stk_l[off]; };
-    auto st_stk = [&](int off, double v) { stk_l[off] = v; };
+    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
+    auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     V qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, sent_e, in_q, in_p, in_g;
     double lps = 0, plp = 0, mlp = 0;
@@ -603,9 +606,9 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
         a.om_in_lds = 0;
         off = (size_t)a.off_Om;
     }
-    // layout 2 with everything resident: room for the speculative kernel's mailbox / control records?
+    // layout 2: room for the speculative kernel's mailbox / control records?
     a.off_spec = 0;
-    if (wpc == 4 && a.cpb == 1 && a.om_in_lds && a.stack_in_lds) {
+    if (wpc == 4 && a.cpb == 1 && a.om_in_lds == a.stack_in_lds) {
         const size_t rec = (size_t)2 * ((3 * nv * 64 + 4 + 64) + (4 * nv * 64 + 4)) * 8;
         off = (off + 15) & ~(size_t)15;
         if (off + rec <= cap) { a.off_spec = (int)off; off += rec; }
@@ -614,9 +617,9 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     return off;
 }
 
-template <int NV, int DP>
+template <int NV, int DP, bool RES>
 static int launch_spec(const NutsArgs &a, int nblocks, hipStream_t stream) {
-    auto kern = k_nuts_spec<NV, DP>;
+    auto kern = k_nuts_spec<NV, DP, RES>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return (int)e;
@@ -639,7 +642,8 @@ template <int NV, int DP>
 static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t stream) {
     // (Omega in LDS, stack in LDS): layout 2 has both or neither; layout 1 may have Omega only
     if (wpc == 4) {
-        if (a.off_spec > 0 && !a.no_spec) return launch_spec<NV, DP>(a, nblocks, stream);
+        if (a.off_spec > 0 && !a.no_spec)
+            return a.om_in_lds ? launch_spec<NV, DP, true>(a, nblocks, stream) : launch_spec<NV, DP, false>(a, nblocks, stream);
         if (a.om_in_lds && a.stack_in_lds) return launch_one<NV, DP, 4, true, true>(a, nblocks, stream);
         return launch_one<NV, DP, 4, false, false>(a, nblocks, stream);
     }

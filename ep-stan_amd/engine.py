@@ -246,6 +246,17 @@ class HipEngine(object):
         order = np.ascontiguousarray(order, dtype=np.int32)
         check(self.lib.epx_set_site_order(self.ctx, order.ctypes.data, int(order.shape[0])))
 
+    def set_site_split(self, n_lead):
+        """The first `n_lead` sites of the site order run one workgroup per chain, concurrently
+        with the others (see include/epx.h: epx_set_site_split)."""
+        check(self.lib.epx_set_site_split(self.ctx, int(n_lead)))
+
+    def last_split(self):
+        return int(self.lib.epx_last_split(self.ctx))
+
+    def cu_count(self):
+        return int(self.lib.epx_cu_count(self.ctx))
+
     def row_passes(self, chains, k0=0, count=None):
         """Passes over the site rows made by the last sampling call: in the streaming layout the
         (up to 4) chains of a workgroup advance in lock step and share one pass per leapfrog;

@@ -235,6 +235,19 @@ int epx_damp_sweep(epx_ctx *ctx, int ndf, const double *dfs, const double *packe
  * No reference counterpart (the reference runs its sites one after the other, method.py:1005-1023). */
 int epx_set_site_order(epx_ctx *ctx, const int32_t *order, int count);
 
+/* With a site order set and the layout left to the library (epx_sampler_opts.layout 0) on a batch
+ * large enough for layout 1: the first n_lead sites of the order run one workgroup per chain
+ * (layout 2) on a second queue, concurrently with layout 1 for the others.  A sampling launch ends
+ * with its slowest chain (max_treedepth leapfrogs in every transition); listing the sites expected
+ * to hold such chains first lets them run at layout 2's shorter leapfrog.  n_lead is clamped so
+ * that the lead sites occupy at most half of the CUs; 0 (default) disables.  Draws of a site are
+ * those of the layout it ran in.  epx_last_split: lead sites of the last sampling call.
+ * No reference counterpart. */
+int epx_set_site_split(epx_ctx *ctx, int n_lead);
+int epx_last_split(epx_ctx *ctx);
+/* Compute units of the context's device (the host-side scheduling heuristics size themselves by it). */
+int epx_cu_count(epx_ctx *ctx);
+
 /* Thread layout the last sampling call ran with (1, 2 or 3, see epx_sampler_opts.layout; 0 before
  * the first call).  Measurement aid: layout 3 streams the rows from HBM once per leapfrog, so its
  * roofline is the HBM one (bench.py).  No reference counterpart. */

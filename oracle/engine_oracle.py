@@ -182,6 +182,15 @@ class OracleEngine(object):
     def set_site_order(self, order=None):
         pass
 
+    def set_site_split(self, n_lead):
+        pass
+
+    def last_split(self):
+        return 0
+
+    def cu_count(self):
+        return 256
+
     def row_passes(self, chains, k0=0, count=None):
         return self.get_chain_stats(chains, k0, count)[:, :, 3].sum(axis=1)
 

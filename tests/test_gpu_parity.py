@@ -361,7 +361,8 @@ def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
     assert nbad <= 1, nbad
 
 
-@pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m1b_sg', 4, 50), ('m4b_sg', 32, 150), ('m5b_sg', 7, 33)])
+@pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m1b_sg', 4, 50), ('m4b_sg', 32, 150), ('m5b_sg', 7, 33),
+                                       ('m4b_sg', 32, 500)])       # last: Omega in L2 and the tree stack in HBM
 def test_speculative_bookkeeping_wave_gives_identical_draws(model, D, n):
     """Layout 2 with the tree bookkeeping on a fifth wave (gradient waves integrate ahead and drop
     what they integrated past a change of state) against the sequential kernel: bit-identical
@@ -418,6 +419,46 @@ def test_site_order_hint_does_not_change_results(model, D, n, layout):
     eng.sample_batch(seeds, opts)
     np.testing.assert_array_equal(np.stack([eng.get_draws(k, True) for k in range(K)]), ref)
     assert eng.last_layout() == layout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model,D,n', [('m1b_sg', 4, 30), ('m4b_sg', 32, 300)])
+def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n):
+    """epx_set_site_split: the leading sites of the order give exactly the draws of layout 2, the
+    others those of layout 1, whatever the split (the two launches share every buffer)."""
+    K = 200
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 5, K=K, tight=30.0)
+    eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.arange(K, dtype=np.int64) + 11
+    ref = {}
+    for layout in (1, 2):
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', layout=layout, max_depth=6))
+        assert eng.last_layout() == layout and eng.last_split() == 0
+        ref[layout] = (np.stack([eng.get_draws(k, True) for k in range(K)]), eng.get_chain_stats(4))
+    order = np.random.RandomState(1).permutation(K)
+    eng.set_site_order(order)
+    opts = HipEngine.sampler_opts(chains=4, iter=12, init='random', max_depth=6)
+    for n_lead in (7, 1, 150):
+        eng.set_site_split(n_lead)
+        stats, ms = eng.sample_batch(seeds, opts)
+        m = eng.last_split()
+        assert eng.last_layout() == 1 and 1 <= m <= n_lead
+        assert m == n_lead or n_lead == 150          # clamped to half of the CUs
+        dr = np.stack([eng.get_draws(k, True) for k in range(K)])
+        cs = eng.get_chain_stats(4)
+        lead, rest = order[:m], order[m:]
+        np.testing.assert_array_equal(dr[lead], ref[2][0][lead])
+        np.testing.assert_array_equal(cs[lead], ref[2][1][lead])
+        np.testing.assert_array_equal(dr[rest], ref[1][0][rest])
+        np.testing.assert_array_equal(cs[rest], ref[1][1][rest])
+    eng.set_site_split(0)
+    eng.sample_batch(seeds, opts)
+    assert eng.last_split() == 0
+    np.testing.assert_array_equal(np.stack([eng.get_draws(k, True) for k in range(K)]), ref[1][0])
+    # an explicit layout is never split
+    eng.set_site_split(5)
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', layout=1, max_depth=6))
+    assert eng.last_split() == 0
 
 
 @pytest.mark.gpu

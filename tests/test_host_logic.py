@@ -377,3 +377,19 @@ def test_mix_phi_pools_the_tilted_samples(runs):
     Sref = (scat + nk * sum(np.outer(mk - mref, mk - mref) for mk in means)) / (nk * M.K - 1)
     np.testing.assert_allclose(m, mref, rtol=1e-12)
     np.testing.assert_allclose(S, Sref, rtol=1e-10, atol=1e-14)
+
+
+def test_site_schedule_puts_the_slow_sites_first():
+    """Master._site_schedule: sites whose slowest chain is within LEAD_FRACTION of the slowest one
+    lead (by slowest chain); the others follow by total work; no lead set without a tail."""
+    from epstan_amd.method import Master
+    lf = np.full((40, 4), 1000.0)
+    lf[7] = [900, 50000, 800, 700]          # one slow chain
+    lf[3] = [30000, 30000, 30000, 30000]    # all slow
+    lf[20] = [5000, 5000, 5000, 5000]       # heavy, but not near the slowest
+    order, n_lead = Master._site_schedule(lf.sum(axis=1), lf)
+    assert n_lead == 2 and list(order[:3]) == [7, 3, 20]
+    assert sorted(order) == list(range(40))
+    # every site about equally slow (first iteration): nothing to single out
+    order, n_lead = Master._site_schedule(np.full(40, 4e5), np.full((40, 4), 1e5))
+    assert n_lead == 0 and sorted(order) == list(range(40))
