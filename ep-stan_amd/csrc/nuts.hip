@@ -427,7 +427,8 @@ k_nuts_spec(NutsArgs a) {
                 if (cmd == SPEC_EXIT) {
 #ifdef EPX_STAMPS
                     if (a.stamps && wt == 0 && lane == 0) {
-                        for (int i = 0; i < 7; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
+                        // slot 6 belongs to the bookkeeping wave: its busy time between barriers
+                        for (int i = 0; i < 6; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
                         a.stamps[(size_t)blockIdx.x * 8 + 7] = nticks;
                     }
 #endif
@@ -528,8 +529,17 @@ k_nuts_spec(NutsArgs a) {
     int gen = 0;
     post(-1, SPEC_RESTART);                     // the initial point, eps_l = 0: the first "leapfrog" is its gradient
     __syncthreads();
+#ifdef EPX_STAMPS
+    unsigned long long bk_busy = 0, bk_in = 0;
+#endif
     for (int s = 0;; ++s) {
+#ifdef EPX_STAMPS
+        if (s > 0) { __builtin_amdgcn_s_waitcnt(0xC07F); bk_busy += __builtin_amdgcn_s_memtime() - bk_in; }
+#endif
         __syncthreads();                        // barrier s
+#ifdef EPX_STAMPS
+        bk_in = __builtin_amdgcn_s_memtime();
+#endif
         if (s == 0) continue;
         const double *m = mbox + ((s - 1) & 1) * MREC;
         if ((int)m[3 * NV * 64 + 2] != gen) continue;           // integrated past a change of state: dropped
@@ -562,6 +572,9 @@ k_nuts_spec(NutsArgs a) {
     }
 
     // ------------------------------------------------------------- epilogue (BK owns the chain)
+#ifdef EPX_STAMPS
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = bk_busy;
+#endif
     {
         double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }

@@ -8,7 +8,8 @@ from epstan_amd import models, _lib
 from epstan_amd.engine import HipEngine
 from epstan_amd.method import Master
 
-NAMES = ['prep(beta)', 'row loop', 'butterfly', 'Omega matvec', 'exchange', 'chain rule', 'state machine']
+NAMES = ['prep(beta)', 'row loop', 'butterfly', 'Omega matvec', 'exchange', 'chain rule',
+         'state machine (layout 2: busy time of the bookkeeping wave, concurrent)']
 
 def run(name, J, D, n, layout, it=30):
     mod = models.MODELS[name](J, D, n)
