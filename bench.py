@@ -147,11 +147,14 @@ def main():
     hbm_alg = sites_local * wg_per_site * (n_rows * args.D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
         + sites_local * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_c2_pmc_hbm.json')
-    if (os.path.exists(pmc) and (args.sites, args.D, args.n, args.model, args.chains, args.siter)
-            == (64, 16, 200, 'm4b', 4, 200)):
+    for pmc in ('r01_c2_pmc_hbm.json', 'r01_c3_pmc_hbm.json'):
         # measured separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
-        traffic = json.load(open(pmc))['hbm_bytes_per_launch_corrected']
+        # (scripts/profile_round.sh, scripts/profile_summarise.py)
+        pmc = os.path.join(ROOT, 'profiles', pmc)
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            if pj.get('workload_key') == [args.sites, args.D, args.n, args.model, args.chains, args.siter]:
+                traffic = pj['hbm_bytes_per_launch_corrected']
     roof = {'kernel': 'k_nuts (sampler)', 'bound': 'mfma', 'achieved': achieved_tf,
             'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / FP64_PEAK_TFLOPS,
             'traffic': traffic,
@@ -172,7 +175,7 @@ def main():
         pmc3 = os.path.join(ROOT, 'profiles', 'r01_stream_pmc_hbm.json')
         if os.path.exists(pmc3):
             pj = json.load(open(pmc3))
-            if pj.get('workload') == [args.sites, args.D, args.n, args.model, args.chains, args.siter]:
+            if pj.get('workload_key', pj.get('workload')) == [args.sites, args.D, args.n, args.model, args.chains, args.siter]:
                 tr = pj['hbm_bytes_per_launch_corrected']
         roof = {'kernel': 'k_nuts_stream (sampler)', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr,

@@ -282,4 +282,17 @@ __device__ inline void logistic_terms(double f, double y, double &ll, double &g)
     g = y - s;
 }
 
+// The same terms with the logarithm left to the caller: log-likelihood term = lin - log(w),
+// w = 1 + exp(-|f|) in [1, 2].  A caller that sums many terms multiplies the w's and takes ONE
+// logarithm per few hundred of them (the streaming sampler's logistic wave: the ~35 dependent
+// instructions of log1p per tile were on the critical path of every tile phase).
+__device__ inline void logistic_split(double f, double y, double &lin, double &w, double &g) {
+    const double e = exp_d(-fabs(f));
+    w = 1.0 + e;
+    const double inv = rcp_d(w);
+    const double s = (f >= 0) ? inv : e * inv;
+    lin = y * f - fmax(f, 0.0);
+    g = y - s;
+}
+
 }  // namespace epx

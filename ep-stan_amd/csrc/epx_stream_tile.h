@@ -290,6 +290,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
         for (int mb = 0; mb < Gm::MB; ++mb) acc[mb] = 0.0;
         int g_bq = -1, g_acc = -1;              // group whose coefficients are in bq / whose gradient is in acc
         int g_l = 0, g_b = 0;                   // groups of tiles p-1, p-2
+        int g_n = tile_group(0);                // group of the tile of the coming phase (fetched one phase ahead)
         const int frow = 4 * (l15 >> 2) + lg;   // D lane of the forward product -> (row frow, chain l3)
         auto flush = [&]() {
 #pragma unroll
@@ -303,8 +304,9 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
             const bool do_f = p < nt, do_b = p >= 2;
             int g_f = 0;
             double a[Gm::KS], bb[4], aa[4 * Gm::MB];
+            const int g_next = *lds_i(B0 + M.tdesc + (p + 1 < nt ? p + 1 : nt - 1) * 8 + 4);
             if (do_f) {
-                g_f = tile_group(p);
+                g_f = g_n;
                 if (g_f != g_bq) {
 #pragma unroll
                     for (int ks = 0; ks < Gm::KS; ++ks)
@@ -354,6 +356,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
             }
             slot_b = slot_l; slot_l = slot_f;
             g_b = g_l; g_l = g_f;
+            g_n = __builtin_amdgcn_readfirstlane(g_next) >> 8;
             if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
         }
         if (g_acc >= 0) flush();                // publish G[group][column][chain] of the last group
@@ -373,33 +376,50 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
         out.slot_i = slot_i; out.t_i = t_i;
     } else {
         // ------------------------------------------------ logistic terms: lane = (row l15, chain lg)
-        double ll = 0.0;
+        // The tile descriptor is fetched one phase ahead and alpha / the residual sum stay in
+        // registers while the group does not change: a phase is as long as its slowest wave, and
+        // two dependent LDS round trips plus a read-modify-write per tile made it this one.
+        double ll = 0.0, da_acc = 0.0, alpha_l = 0.0;
+        double wprod = 1.0, wlog = 0.0;         // log-likelihood = sum(lin) - log(prod(w)), see logistic_split
         for (int i = lane; i < s.ngmax * NCH; i += 64) *lds_d(B0 + M.da + i * 8) = 0.0;
+        int pk_n = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + 4));       // tile 0
+        int g_cur = -1;
+        auto flush_da = [&]() {                 // residual sum of the group's tiles -> da[group][chain]
+            double dsum = da_acc;
+            dsum += dpp_d<DPP_QUAD_XOR1>(dsum); dsum += dpp_d<DPP_QUAD_XOR2>(dsum);
+            dsum += dpp_d<DPP_ROW_HALF_MIRROR>(dsum); dsum += dpp_d<DPP_ROW_MIRROR>(dsum);
+            if (l15 == 0) *lds_d(B0 + M.da + (g_cur * NCH + lg) * 8) = dsum;
+            da_acc = 0.0;
+        };
         for (int p = 0; p < nt + 2; ++p) {
             lds_barrier();
             if (p >= 1 && p - 1 < nt) {
                 const int pb = (p - 1) & 1;
-                const int pk = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + (p - 1) * 8 + 4));
+                const int pk = pk_n;
+                const int pk_next = *lds_i(B0 + M.tdesc + (p < nt ? p : nt - 1) * 8 + 4);      // used next phase
                 const int nval = pk & 255, grp = pk >> 8;
-                double f = *lds_d(B0 + M.alpha + (grp * NCH + lg) * 8);
+                if (grp != g_cur) {
+                    if (g_cur >= 0) flush_da();
+                    g_cur = grp;
+                    alpha_l = *lds_d(B0 + M.alpha + (grp * NCH + lg) * 8);
+                }
+                double f = alpha_l;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) f += *lds_d(B0 + M.part + ((pb * 4 + w) * 64 + lane) * 8);
-                double l = 0.0, g = 0.0;
-                if (l15 < nval) logistic_terms(f, (double)*lds_i(B0 + M.yring + (slot_l * TR + l15) * 4), l, g);
-                ll += l;
+                double l = 0.0, w = 1.0, g = 0.0;
+                logistic_split(f, (double)*lds_i(B0 + M.yring + (slot_l * TR + l15) * 4), l, w, g);
+                const bool ok = l15 < nval;
+                g = ok ? g : 0.0;
                 *lds_d(B0 + M.gs + (pb * 64 + lane) * 8) = g;
-                // sum of the residuals of the tile -> da[group][chain]
-                double dsum = g;
-                dsum += dpp_d<DPP_QUAD_XOR1>(dsum); dsum += dpp_d<DPP_QUAD_XOR2>(dsum);
-                dsum += dpp_d<DPP_ROW_HALF_MIRROR>(dsum); dsum += dpp_d<DPP_ROW_MIRROR>(dsum);
-                if (l15 == 0) {
-                    lds_f64 *dp = lds_d(B0 + M.da + (grp * NCH + lg) * 8);
-                    *dp = *dp + dsum;
-                }
+                ll += ok ? l : 0.0; wprod *= ok ? w : 1.0; da_acc += g;
+                if ((p & 255) == 0) { wlog += log(wprod); wprod = 1.0; }       // w <= 2: no overflow in 256 factors
+                pk_n = __builtin_amdgcn_readfirstlane(pk_next);
             }
             slot_b = slot_l; slot_l = slot_f;
             if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
         }
+        if (g_cur >= 0) flush_da();
+        ll -= wlog + log(wprod);
         // ll: sum over the 16 rows of each lane group -> red[chain]
         ll += dpp_d<DPP_QUAD_XOR1>(ll); ll += dpp_d<DPP_QUAD_XOR2>(ll);
         ll += dpp_d<DPP_ROW_HALF_MIRROR>(ll); ll += dpp_d<DPP_ROW_MIRROR>(ll);

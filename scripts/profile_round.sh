@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): bench lines, rocprofv3 kernel traces and the two PMC passes
+# (FETCH_SIZE / WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes) for the three
+# workloads quoted in DESIGN.md section 6.  Outputs under gpurun_out/round/; summarise locally with
+# scripts/profile_summarise.py.
+set -u
+REPO=$PWD
+OUT=$REPO/gpurun_out/round
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+prof() {   # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $OUT/${name}_trace -o run -- python3 $REPO/bench.py "$@" --cpu-sites 0 > $OUT/${name}_trace.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${name}_fetch -o run -- python3 $REPO/bench.py "$@" --cpu-sites 0 > $OUT/${name}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${name}_write -o run -- python3 $REPO/bench.py "$@" --cpu-sites 0 > $OUT/${name}_write.log 2>&1
+}
+python3 $REPO/bench.py > $OUT/c2_bench.json 2> $OUT/c2_bench.err
+prof c2 --steps 3 --warmup 1
+python3 $REPO/bench.py --sites 512 --D 32 --n 500 --steps 6 --warmup 3 --cpu-sites 0 > $OUT/c3_bench.json 2> $OUT/c3_bench.err
+prof c3 --sites 512 --D 32 --n 500 --steps 3 --warmup 3
+if [ "${SKIP_STREAM:-0}" != "1" ]; then
+  python3 $REPO/bench.py --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1 --cpu-sites 0 > $OUT/stream_bench.json 2> $OUT/stream_bench.err
+  prof stream --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1
+fi
+ls -R $OUT | head -60

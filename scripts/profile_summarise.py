@@ -1,0 +1,99 @@
+"""Turns the rocprofv3 outputs of scripts/profile_round.sh (gpurun_out/round/) into the tracked
+summaries under profiles/: per-kernel time statistics (CSV, as --stats prints them) and the HBM
+bytes of the sampler kernels from the FETCH_SIZE / WRITE_SIZE passes (JSON; KiB units, FETCH_SIZE x2
+for wide reads on gfx950 as MI355X_MICROARCH.md prescribes, WRITE_SIZE as reported).
+Usage: python scripts/profile_summarise.py [round_tag]"""
+import glob, json, os, shutil, sqlite3, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'gpurun_out', 'round')
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+
+
+def dbs(d):
+    return sorted(glob.glob(os.path.join(SRC, d, '**', '*.db'), recursive=True))
+
+
+def kernel_rows(db):
+    con = sqlite3.connect(db)
+    tabs = [r[0] for r in con.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")]
+    if not tabs:
+        return None, None
+    suf = tabs[0].replace('rocpd_kernel_dispatch', '')
+    n = con.execute('select count(*) from rocpd_kernel_dispatch%s' % suf).fetchone()[0]
+    return (con, suf) if n else (None, None)
+
+
+def pmc_sums(d, warmup):
+    """Counter value and duration of the sampler kernels per EP iteration of the profiled command
+    (a split launch runs two sampler kernels side by side: both are booked to their iteration);
+    returns the per-kernel totals and the list of per-iteration sums of the TIMED iterations."""
+    for db in dbs(d):
+        con, suf = kernel_rows(db)
+        if con is None:
+            continue
+        q = """select s.kernel_name, d.start, d.end, sum(e.value) from rocpd_pmc_event%s e
+               join rocpd_kernel_dispatch%s d on e.event_id = d.event_id
+               join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id
+               where s.kernel_name like '%%k_nuts%%' group by d.id order by d.start""" % (suf, suf, suf)
+        rows = con.execute(q).fetchall()
+        if not rows:
+            continue
+        names = [r[0] for r in rows]
+        main = max(set(names), key=names.count)
+        starts = [r[1] for r in rows if r[0] == main]
+        per_iter = [0.0] * len(starts)
+        dur = [0.0] * len(starts)
+        kern = {}
+        for name, t0, t1, val in rows:
+            it = min(range(len(starts)), key=lambda i: abs(starts[i] - t0))
+            per_iter[it] += val
+            dur[it] = max(dur[it], (t1 - t0) / 1e6)
+            k = kern.setdefault(name, {'dispatches': 0, 'sum_KiB': 0.0, 'timed_dispatches': 0})
+            k['dispatches'] += 1; k['sum_KiB'] += val
+            k['timed_dispatches'] += int(it >= warmup)
+        return kern, per_iter[warmup:], dur[warmup:]
+    return {}, [], []
+
+
+for name in ('c2', 'c3', 'stream'):
+    if not os.path.exists(os.path.join(SRC, name + '_bench.json')):
+        continue
+    line = [l for l in open(os.path.join(SRC, name + '_bench.json')) if l.startswith('{')]
+    if line:
+        open(os.path.join(ROOT, 'profiles', '%s_%s_bench.json' % (tag, name)), 'w').write(line[-1])
+    for db in dbs(name + '_trace'):
+        if kernel_rows(db)[0] is not None:
+            subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
+                                   os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.csv' % (tag, name))])
+    warmup, key = {'c2': (1, [64, 16, 200, 'm4b', 4, 200]), 'c3': (3, [512, 32, 500, 'm4b', 4, 200]),
+                   'stream': (1, [512, 128, 2000, 'm4b', 4, 200])}[name]
+    f, f_it, f_ms = pmc_sums(name + '_fetch', warmup)
+    w, w_it, w_ms = pmc_sums(name + '_write', warmup)
+    for kind in ('fetch', 'write'):
+        for db in dbs(name + '_' + kind):
+            if kernel_rows(db)[0] is not None:
+                subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
+                                       os.path.join(ROOT, 'profiles', '%s_%s_pmc_%s_size.csv' % (tag, name, kind))])
+    bench = json.loads(line[-1]) if line else {}
+    mean = lambda v: sum(v) / len(v) if v else None
+    fk, wk = mean(f_it), mean(w_it)
+    summary = {
+        'commands': 'scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py <workload>, '
+                    'and separately --pmc WRITE_SIZE; kernel-trace summary of the same command in %s_%s_kernel_stats.csv' % (tag, name),
+        'workload_key': key,
+        'sampler_kernels_fetch_pass': f, 'sampler_kernels_write_pass': w,
+        'timed_launches': len(f_it),
+        'FETCH_SIZE_KiB_per_timed_launch': fk, 'WRITE_SIZE_KiB_per_timed_launch': wk,
+        'hbm_bytes_per_launch_corrected': (2 * fk + wk) * 1024 if fk is not None and wk is not None else None,
+        'launch_ms_pmc_passes': [mean(f_ms), mean(w_ms)],
+        'note': 'per EP iteration of the timed region (warm-up iterations dropped), all sampler kernels of the '
+                'iteration summed (a split launch runs k_nuts and k_nuts_spec side by side). Units: rocprofv3 '
+                'reports KiB; gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per '
+                '128-B request for wide coalesced reads -> x2; WRITE_SIZE as reported.',
+    }
+    if bench:
+        summary['workload'] = bench['config']['workload']
+        summary['bench_launch_ms'] = bench['roofline'].get('launch_ms')
+        summary['algorithmic_bytes_per_launch'] = bench['roofline'].get('hbm_algorithmic_bytes')
+    json.dump(summary, open(os.path.join(ROOT, 'profiles', '%s_%s_pmc_hbm.json' % (tag, name)), 'w'), indent=1)
+    print(name, json.dumps({k: summary.get(k) for k in ('timed_launches', 'hbm_bytes_per_launch_corrected', 'bench_launch_ms', 'launch_ms_pmc_passes', 'algorithmic_bytes_per_launch')}))

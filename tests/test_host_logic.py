@@ -393,3 +393,32 @@ def test_site_schedule_puts_the_slow_sites_first():
     # every site about equally slow (first iteration): nothing to single out
     order, n_lead = Master._site_schedule(np.full(40, 4e5), np.full((40, 4), 1e5))
     assert n_lead == 0 and sorted(order) == list(range(40))
+
+
+def test_master_hands_the_schedule_of_the_next_launch_to_the_engine():
+    """After every sampling launch `run` passes a dispatch order (a permutation of the local sites)
+    and a lead-site count to the engine (engine.set_site_order / set_site_split)."""
+    mod = models.MODELS['m1b'](4, 2, 12)
+    data = mod.simulate_data(Sigma_x='rand', rng=3)
+    _, _, Q0, r0 = mod.get_prior()
+    calls = []
+
+    def spying(model, X, y, k_lim, **groups):
+        eng = OracleEngine(model, X, y, k_lim, **groups)
+        eng.set_site_order = lambda order=None: calls.append(('order', None if order is None else list(order)))
+        eng.set_site_split = lambda n: calls.append(('split', n))
+        return eng
+
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+               chains=2, iter=30, _engine_factory=spying)
+    assert M.run(2, verbose=False, seed=5)[0] == 0
+    orders = [c[1] for c in calls if c[0] == 'order']
+    splits = [c[1] for c in calls if c[0] == 'split']
+    assert len(orders) == 2 and len(splits) == 2
+    assert all(sorted(o) == [0, 1, 2, 3] for o in orders)
+    assert all(isinstance(n, int) and 0 <= n <= 1 for n in splits)
+    M2 = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+                chains=2, iter=30, balance_sites=False, _engine_factory=spying)
+    n0 = len(calls)
+    assert M2.run(1, verbose=False, seed=5)[0] == 0
+    assert len(calls) == n0
