@@ -399,7 +399,15 @@ k_nuts_spec(NutsArgs a) {
                    zg.v[i] = c[(2 * NV + i) * 64 + lane]; inv_e.v[i] = c[(3 * NV + i) * 64 + lane]; }
             eps_l = c[4 * NV * 64];
         }
+        const int lane0 = lane;
         for (int s = 0;; ++s) {
+            // NV > 1: `lane` is re-derived through an opaque move every leapfrog, otherwise the
+            // per-element index arithmetic of the gradient is hoisted out of the loop and, next to
+            // the bookkeeping wave's register needs, spilled (25 scratch reloads per leapfrog at
+            // NV = 2, DP = 32)
+            int lane_v = lane0;
+            if (NV > 1) asm volatile("" : "+v"(lane_v));
+            const int lane = lane_v;
             STAMP(6);
             // BK's word of interval s-1 is complete once barrier s has passed: fetch stamp and
             // command right there, their latency hides behind the chain rule

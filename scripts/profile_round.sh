@@ -6,7 +6,8 @@
 set -u
 REPO=$PWD
 OUT=$REPO/gpurun_out/round
-rm -rf $OUT; mkdir -p $OUT
+WHICH=${ONLY:-c2 c3 stream}      # ONLY="stream" re-profiles one workload (outputs of the others are kept locally)
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() {   # name, bench args...
   local name=$1; shift
@@ -14,12 +15,18 @@ prof() {   # name, bench args...
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${name}_fetch -o run -- python3 $REPO/bench.py "$@" --cpu-sites 0 > $OUT/${name}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${name}_write -o run -- python3 $REPO/bench.py "$@" --cpu-sites 0 > $OUT/${name}_write.log 2>&1
 }
-python3 $REPO/bench.py > $OUT/c2_bench.json 2> $OUT/c2_bench.err
-prof c2 --steps 3 --warmup 1
-python3 $REPO/bench.py --sites 512 --D 32 --n 500 --steps 6 --warmup 3 --cpu-sites 0 > $OUT/c3_bench.json 2> $OUT/c3_bench.err
-prof c3 --sites 512 --D 32 --n 500 --steps 3 --warmup 3
-if [ "${SKIP_STREAM:-0}" != "1" ]; then
-  python3 $REPO/bench.py --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1 --cpu-sites 0 > $OUT/stream_bench.json 2> $OUT/stream_bench.err
-  prof stream --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1
-fi
+for w in $WHICH; do
+  rm -rf $OUT/${w}_*
+  case $w in
+  c2)
+    python3 $REPO/bench.py > $OUT/c2_bench.json 2> $OUT/c2_bench.err
+    prof c2 --steps 3 --warmup 1 ;;
+  c3)
+    python3 $REPO/bench.py --sites 512 --D 32 --n 500 --steps 6 --warmup 3 --cpu-sites 0 > $OUT/c3_bench.json 2> $OUT/c3_bench.err
+    prof c3 --sites 512 --D 32 --n 500 --steps 3 --warmup 3 ;;
+  stream)
+    python3 $REPO/bench.py --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1 --cpu-sites 0 > $OUT/stream_bench.json 2> $OUT/stream_bench.err
+    prof stream --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1 ;;
+  esac
+done
 ls -R $OUT | head -60

@@ -92,8 +92,16 @@ for name in ('c2', 'c3', 'stream'):
                 '128-B request for wide coalesced reads -> x2; WRITE_SIZE as reported.',
     }
     if bench:
+        roof = bench['roofline']
         summary['workload'] = bench['config']['workload']
-        summary['bench_launch_ms'] = bench['roofline'].get('launch_ms')
-        summary['algorithmic_bytes_per_launch'] = bench['roofline'].get('hbm_algorithmic_bytes')
+        summary['bench_launch_ms'] = roof.get('launch_ms')
+        summary['algorithmic_bytes_per_launch'] = roof.get('hbm_algorithmic_bytes')
+        if roof.get('bound') == 'hbm':
+            summary['algorithmic_bytes_per_launch'] = roof['achieved'] * 1e9 * roof['launch_ms'] * 1e-3
+        if summary['hbm_bytes_per_launch_corrected'] and summary['algorithmic_bytes_per_launch']:
+            summary['traffic_over_algorithmic'] = summary['hbm_bytes_per_launch_corrected'] / summary['algorithmic_bytes_per_launch']
+        # the bench line was printed before these passes ran: its traffic field is (re)filled from them
+        roof['traffic'] = summary['hbm_bytes_per_launch_corrected']
+        open(os.path.join(ROOT, 'profiles', '%s_%s_bench.json' % (tag, name)), 'w').write(json.dumps(bench) + '\n')
     json.dump(summary, open(os.path.join(ROOT, 'profiles', '%s_%s_pmc_hbm.json' % (tag, name)), 'w'), indent=1)
     print(name, json.dumps({k: summary.get(k) for k in ('timed_launches', 'hbm_bytes_per_launch_corrected', 'bench_launch_ms', 'launch_ms_pmc_passes', 'algorithmic_bytes_per_launch')}))
