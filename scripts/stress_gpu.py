@@ -1,7 +1,8 @@
 """Randomised cross-checks of the sampler kernels on the GPU (not part of the test suite):
   * layout 2 with / without the bookkeeping wave: bit-identical draws and statistics,
   * layouts 3 and 4 against layout 1 (same algorithm, other summation order): first draws,
-  * multi-group gradients (layouts 3, 4) against the C oracle.
+  * multi-group gradients (layouts 3, 4) against the C oracle,
+  * split launches (random site order and lead count) against whole-batch layouts 1 and 2.
 Usage: python scripts/stress_gpu.py [seconds]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(os.environ.get('STRESS_SEED', '0')))
 MODELS = ['m1b', 'm2b', 'm3b', 'm4b', 'm5b']
 t0 = time.time()
-nspec = nlay = ngrp = 0
+nspec = nlay = ngrp = nsplit = 0
 
 
 def cavities(eng, rng, tight):
@@ -96,5 +97,29 @@ while time.time() - t0 < budget:
                     assert abs(lp - lpo) <= 1e-9 * max(1.0, abs(lpo)), ('mg lp', layout, model, D, groups)
                     assert np.allclose(g[:Pk], go, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go).max())), ('mg grad', layout, model, D, groups)
             ngrp += 1
-print('stress ok: %d spec comparisons, %d layout comparisons, %d multi-group gradient sets in %.0f s'
-      % (nspec, nlay, ngrp, time.time() - t0))
+    # ---- split launch: lead sites == layout 2, the others == layout 1, bit for bit
+    if rng.rand() < 0.15:
+        Ks = 192 + int(rng.randint(0, 40))
+        ns = int(rng.choice([8, 30, 70]))
+        Ds = int(rng.choice([2, 5, 16, 32]))
+        ms = MODELS[rng.randint(5)]
+        Xs = rng.randn(Ks * ns, Ds); ysx = (rng.rand(Ks * ns) < 0.5).astype(int)
+        es = HipEngine(ms + '_sg', Xs, ysx, np.arange(Ks + 1) * ns)
+        cavities(es, rng, 30.0)
+        sd = rng.randint(1, 2**31 - 1, size=Ks).astype(np.int64)
+        ref = {}
+        for layout in (1, 2):
+            es.sample_batch(sd, HipEngine.sampler_opts(chains=4, iter=10, init='random', layout=layout, max_depth=5))
+            ref[layout] = np.stack([es.get_draws(k, True) for k in range(Ks)])
+        order = rng.permutation(Ks)
+        es.set_site_order(order)
+        es.set_site_split(int(rng.randint(1, 40)))
+        es.sample_batch(sd, HipEngine.sampler_opts(chains=4, iter=10, init='random', max_depth=5))
+        m = es.last_split()
+        dr = np.stack([es.get_draws(k, True) for k in range(Ks)])
+        assert m >= 1
+        assert np.array_equal(dr[order[:m]], ref[2][order[:m]], equal_nan=True), ('split lead', ms, Ds, ns, Ks, m)
+        assert np.array_equal(dr[order[m:]], ref[1][order[m:]], equal_nan=True), ('split rest', ms, Ds, ns, Ks, m)
+        nsplit += 1
+print('stress ok: %d spec comparisons, %d layout comparisons, %d multi-group gradient sets, %d split launches in %.0f s'
+      % (nspec, nlay, ngrp, nsplit, time.time() - t0))
