@@ -142,7 +142,7 @@ def main():
     sites_local = args.sites
     # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup: one
     # workgroup per (site, chain) in layout 2, per site in layout 1), draws and last states out
-    wg_per_site = 1 if sites_local >= 192 or args.layout == 1 else args.chains
+    wg_per_site = 1 if M.engine.last_layout() == 1 else args.chains
     P = M.engine.P
     hbm_alg = sites_local * wg_per_site * (n_rows * args.D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
         + sites_local * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)

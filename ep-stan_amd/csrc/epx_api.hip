@@ -492,7 +492,17 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // resident layouts: enough sites to fill the 256 CUs -> one block per site, else one block
     // per (site, chain) with 4 cooperating waves
     int layout = o.layout;
-    const bool many = count >= 192;
+    // one workgroup per (site, chain) schedules chain by chain (no waiting for the slowest of a site's
+    // chains) and has the shorter leapfrog; one workgroup per site packs 4 chains on a CU.  Measured
+    // cross-over at the C2 site size, where two layout-2 workgroups share a CU (scripts/tick_occupancy.py:
+    // layout 2 ahead by 24 % at 192 sites, 5 % at 256, behind by 4 % at 512); 192 when only one fits.
+    bool many = count >= 192;
+    if (layout == 0 && !c->multi && dp > 0 && nv <= 2) {
+        NutsArgs t = a;
+        t.cpb = 1;
+        const size_t lds2 = nuts_lds_layout(t, 4, dp, c->n_max);
+        if (2 * lds2 <= LDS_CAP) many = count >= 320;
+    }
     // layout 4: one block per site, chains in lock step, rows resident in LDS, MFMA products: the
     // home of multi-group sites with small D (measured 1.05-1.4x faster than streaming them);
     // for single-group sites layout 1 is still faster at the C3 site size (132 vs 157 ms per

@@ -339,6 +339,7 @@ k_nuts_spec(NutsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool is_bk = wave == WPC;
     const int team = 0, wt = is_bk ? 0 : wave;
+    (void)team;
     const int sb = a.order ? a.order[blockIdx.x / a.chains] : (int)(blockIdx.x / a.chains);
     const int chain = blockIdx.x % a.chains;
     const int k = a.k0 + sb;

@@ -422,11 +422,11 @@ def test_site_order_hint_does_not_change_results(model, D, n, layout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('model,D,n', [('m1b_sg', 4, 30), ('m4b_sg', 32, 300)])
-def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n):
+@pytest.mark.parametrize('model,D,n,K', [('m1b_sg', 4, 30, 330), ('m4b_sg', 32, 300, 200)])
+def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n, K):
     """epx_set_site_split: the leading sites of the order give exactly the draws of layout 2, the
-    others those of layout 1, whatever the split (the two launches share every buffer)."""
-    K = 200
+    others those of layout 1, whatever the split (the two launches share every buffer).  K: enough
+    sites for the library to pick layout 1 by itself (320 when two layout-2 workgroups fit a CU)."""
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 5, K=K, tight=30.0)
     eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     seeds = np.arange(K, dtype=np.int64) + 11
