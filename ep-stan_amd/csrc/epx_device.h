@@ -282,6 +282,29 @@ __device__ inline void logistic_terms(double f, double y, double &ll, double &g)
     g = y - s;
 }
 
+// log(x) for finite x >= 1 (a product of (1 + e) factors): x = 2^k m with m in [1/sqrt2, sqrt2),
+// log m by the same atanh series as log1p_unit_d
+__device__ inline double log_ge1_d(double x) {
+    int k = 0;
+    double m = frexp(x, &k);                          // m in [0.5, 1)
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? 2.0 * m : m; k = lo ? k - 1 : k;         // m in [1/sqrt2, sqrt2)
+    const double s = (m - 1.0) * rcp_d(m + 1.0);
+    const double z = s * s;                           // |s| <= 0.1716
+    double p = 4.7619047619047616e-02;                // 1/21
+    p = fma(p, z, 5.2631578947368418e-02);
+    p = fma(p, z, 5.8823529411764705e-02);
+    p = fma(p, z, 6.6666666666666666e-02);
+    p = fma(p, z, 7.6923076923076927e-02);
+    p = fma(p, z, 9.0909090909090912e-02);
+    p = fma(p, z, 1.1111111111111110e-01);
+    p = fma(p, z, 1.4285714285714285e-01);
+    p = fma(p, z, 0.2);
+    p = fma(p, z, 3.3333333333333331e-01);
+    p = fma(p, z, 1.0);
+    return fma((double)k, 6.931471805599453094e-01, 2.0 * s * p);
+}
+
 // The same terms with the logarithm left to the caller: log-likelihood term = lin - log(w),
 // w = 1 + exp(-|f|) in [1, 2].  A caller that sums many terms multiplies the w's and takes ONE
 // logarithm per few hundred of them (the streaming sampler's logistic wave: the ~35 dependent
