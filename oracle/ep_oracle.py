@@ -428,7 +428,11 @@ MODELS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4}
 
 
 def model_dims(model, D):
-    """(dphi, P) of the single-group logistic models."""
+    """(dphi, P) of the single-group models; the Gaussian-likelihood family m*a_sg.stan has one
+    more shared parameter in front, log sigma."""
+    if model[2] == 'a':
+        d, P = model_dims(model.replace('a', 'b', 1), D)
+        return d + 1, P + 1
     if model == 'm1b_sg':
         return D + 1, D + 2               # m1b_sg.stan:19-22
     if model == 'm2b_sg':
@@ -444,6 +448,11 @@ def site_logdensity(model, theta, X, y, mu, Omega):
     """lp(theta) and its gradient, NumPy, for cross-checking nuts_oracle.c."""
     theta = np.asarray(theta, dtype=np.float64)
     n, D = X.shape
+    if model[2] == 'a':
+        # experiment/models/m*a_sg.stan: theta = [log sigma | theta of the b-model], y ~ normal(f, sigma).
+        # Written on its own (value by the Stan program's formula, gradient by hand) so that the
+        # shared code below stays the b-family's.
+        return _site_logdensity_gauss(model, theta, X, y, mu, Omega)
     d, P = model_dims(model, D)
     phi = theta[:d]
     eta = theta[d]
@@ -488,6 +497,55 @@ def site_logdensity(model, theta, X, y, mu, Omega):
             g[d] = da * sa - np.sign(eta); g[d + 1:] = db * sb - np.sign(etb)
         else:
             g[d] = da * sa - eta; g[d + 1:] = db * sb - etb
+    return lp, g
+
+
+def _site_logdensity_gauss(model, theta, X, y, mu, Omega):
+    n, D = X.shape
+    d, P = model_dims(model, D)
+    base = model[:2]
+    ls = theta[0]
+    phi = theta[1:d]                                    # the b-model's phi
+    eta = theta[d]
+    etb = theta[d + 1:] if P > d + 1 else None
+    if base == 'm1':
+        sa = np.exp(phi[0]); alpha = eta * sa; beta = phi[1:]
+    elif base == 'm2':
+        sa = np.exp(phi[0]); sb = np.exp(phi[1]); alpha = eta * sa; beta = etb * sb
+    elif base == 'm3':
+        sa = np.exp(phi[0]); sb = np.exp(phi[1:]); alpha = eta * sa; beta = etb * sb
+    else:
+        sa = np.exp(phi[1]); sb = np.exp(phi[2 + D:]); alpha = phi[0] + eta * sa
+        beta = phi[2:2 + D] + etb * sb
+    res = np.asarray(y, dtype=np.float64) - (alpha + X.dot(beta))
+    s2 = np.exp(2 * ls)
+    v = theta[:d] - mu
+    Ov = Omega.dot(v)
+    lp = -0.5 * v.dot(Ov) - n * ls - 0.5 * res.dot(res) / s2
+    laplace = base == 'm5'
+    if laplace:
+        lp += -abs(eta) - np.sum(np.abs(etb))
+    else:
+        lp += -0.5 * eta**2 - (0.5 * np.sum(etb**2) if etb is not None else 0.0)
+    gf = res / s2
+    da, db = gf.sum(), X.T.dot(gf)
+    g = np.zeros(P)
+    g[:d] = -Ov
+    g[0] += res.dot(res) / s2 - n
+    gp = g[1:d]                                         # view: the b-model's phi block
+    pr = (lambda t: np.sign(t)) if laplace else (lambda t: t)
+    if base == 'm1':
+        gp[0] += da * eta * sa; gp[1:] += db; g[d] = da * sa - eta
+    elif base == 'm2':
+        gp[0] += da * eta * sa; gp[1] += db.dot(etb) * sb
+        g[d] = da * sa - eta; g[d + 1:] = db * sb - etb
+    elif base == 'm3':
+        gp[0] += da * eta * sa; gp[1:] += db * etb * sb
+        g[d] = da * sa - eta; g[d + 1:] = db * sb - etb
+    else:
+        gp[0] += da; gp[1] += da * eta * sa
+        gp[2:2 + D] += db; gp[2 + D:] += db * etb * sb
+        g[d] = da * sa - pr(eta); g[d + 1:] = db * sb - pr(etb)
     return lp, g
 
 

@@ -9,6 +9,9 @@
  *   (1) the site log-densities of the reference's own Stan programs
  *       /root/reference/experiment/models/m{1,2,3,4,5}b_sg.stan (model block,
  *       transformed parameters) and their analytic gradients,
+ *       and of the Gaussian-likelihood family m{1..5}a_sg.stan (model ids 5..9:
+ *       phi = [log sigma | the b-model's phi], y ~ normal(alpha + X beta, sigma);
+ *       for these ids the `y` argument of every entry point points to DOUBLES),
  *   (2) Stan 2.17's published sampler: multinomial NUTS with the generalised
  *       U-turn criterion (stan/mcmc/hmc/nuts/base_nuts.hpp @ v2.17), diagonal
  *       Euclidean metric, step-size heuristic (base_hmc::init_stepsize),
@@ -44,7 +47,9 @@
 
 #define EPO_MAX_DEPTH_CAP 16
 
-enum { M1B = 0, M2B = 1, M3B = 2, M4B = 3, M5B = 4 };
+enum { M1B = 0, M2B = 1, M3B = 2, M4B = 3, M5B = 4, M1A = 5, M2A = 6, M3A = 7, M4A = 8, M5A = 9 };
+static inline int is_gauss(int model) { return model >= M1A && model <= M5A; }
+static inline int base_model(int model) { return is_gauss(model) ? model - M1A : model; }
 enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
 
 /* per-chain statistics written to `stats` (doubles) */
@@ -62,20 +67,22 @@ enum {
 
 /* ------------------------------------------------------------------ dims */
 int epo_dphi(int model, int D) {
-    switch (model) {
-    case M1B: return D + 1;
-    case M2B: return 2;
-    case M3B: return D + 1;
-    case M4B: case M5B: return 2 * D + 2;
+    const int o = is_gauss(model);          /* m*a_sg.stan: one more shared parameter, log sigma, in front */
+    switch (base_model(model)) {
+    case M1B: return D + 1 + o;
+    case M2B: return 2 + o;
+    case M3B: return D + 1 + o;
+    case M4B: case M5B: return 2 * D + 2 + o;
     }
     return -1;
 }
 int epo_npar(int model, int D) {
-    switch (model) {
-    case M1B: return D + 2;
-    case M2B: return D + 3;
-    case M3B: return 2 * D + 2;
-    case M4B: case M5B: return 3 * D + 3;
+    const int o = is_gauss(model);
+    switch (base_model(model)) {
+    case M1B: return D + 2 + o;
+    case M2B: return D + 3 + o;
+    case M3B: return 2 * D + 2 + o;
+    case M4B: case M5B: return 3 * D + 3 + o;
     }
     return -1;
 }
@@ -132,6 +139,7 @@ typedef struct {
     int model, n, D, d, P;
     const double *X;   /* n x D row-major (C-order view, method.py:829) */
     const int32_t *y;  /* n, 0/1 */
+    const double *yd;  /* n, real responses of the Gaussian family (m*a_sg.stan `real y[N]`), else NULL */
     const double *mu;  /* d cavity mean   (Worker.vec, method.py:221) */
     const double *Om;  /* d x d cavity precision, symmetric (Worker.Mat, :222) */
     /* groups of the site (K < J, experiment/models/m*b.stan `j_ind`): ng contiguous row blocks,
@@ -148,7 +156,7 @@ typedef struct {
 int epo_npar_groups(int model, int D, int ng) {
     const int d = epo_dphi(model, D);
     if (d < 0 || ng < 1) return -1;
-    return d + ng * (model == M1B ? 1 : 1 + D);
+    return d + ng * (base_model(model) == M1B ? 1 : 1 + D);
 }
 static size_t site_scratch(int D, int d, int ng) { return (size_t)2 * ng * D + ng + d; }
 static void site_bind_scratch(site_t *s, double *w) {
@@ -167,11 +175,15 @@ static inline void logistic_terms(double f, double y, double *ll, double *g) {
 /* m*b_sg.stan / m*b.stan model blocks; SURVEY.md Appendix A.  With ng groups every group j has
  * its own eta_j (and etb_j), alpha_j, beta_j (m4b.stan:33-41); the hyper-parameters phi are shared. */
 static double site_lp_grad(const site_t *s, const double *th, double *grad) {
-    const int D = s->D, d = s->d, model = s->model, ng = s->ng;
-    const double *phi = th;
+    const int D = s->D, d = s->d, model = base_model(s->model), ng = s->ng;
+    const int gauss = is_gauss(s->model);
+    const double *phi = th + gauss;                     /* the b-model's phi; th[0] = log sigma for the a-models */
     const double *eta = th + d;
     const double *etb = th + d + ng;                    /* [group][D] */
     const int laplace = (model == M5B);
+    const double inv_s2 = gauss ? exp(-2.0 * th[0]) : 0.0;
+    double rss = 0.0;                                   /* sum of squared residuals / sigma^2 */
+    int64_t nrow = 0;
     const double sa = exp(model >= M4B ? phi[1] : phi[0]);
     const double a0 = model >= M4B ? phi[0] : 0.0;
     double ll = 0.0;
@@ -194,7 +206,10 @@ static double site_lp_grad(const site_t *s, const double *th, double *grad) {
             double f = alpha;
             for (int c = 0; c < D; ++c) f += x[c] * beta[c];
             double l, g;
-            logistic_terms(f, (double)s->y[i], &l, &g);
+            if (gauss) {            /* y ~ normal(f, sigma): -log sigma - (y-f)^2 / (2 sigma^2) */
+                const double r = s->yd[i] - f;
+                g = r * inv_s2; l = -0.5 * r * g; rss += r * g; ++nrow;
+            } else logistic_terms(f, (double)s->y[i], &l, &g);
             ll += l; da += g;
             for (int c = 0; c < D; ++c) db[c] += g * x[c];
         }
@@ -205,20 +220,23 @@ static double site_lp_grad(const site_t *s, const double *th, double *grad) {
     for (int i = 0; i < d; ++i) {
         double acc = 0.0;
         const double *row = s->Om + (size_t)i * d;
-        for (int j = 0; j < d; ++j) acc += row[j] * (phi[j] - s->mu[j]);
+        for (int j = 0; j < d; ++j) acc += row[j] * (th[j] - s->mu[j]);
         s->Ov[i] = acc;
-        quad += (phi[i] - s->mu[i]) * acc;
+        quad += (th[i] - s->mu[i]) * acc;
     }
     double lp = -0.5 * quad + ll;
     for (int i = 0; i < d; ++i) grad[i] = -s->Ov[i];
+    if (gauss) { lp -= (double)nrow * th[0]; grad[0] += rss - (double)nrow; }
+    grad += gauss;                                      /* the b-model's indices below; d, eta, etb shift too */
+    const int db_ = d - gauss;
 #define SGN(v) (((v) > 0) - ((v) < 0))
     /* eta, etb ~ normal(0,1) (double_exponential(0,1) for m5b*.stan:40-41), and the chain rule */
     for (int j = 0; j < ng; ++j) {
         const double *db = s->db + (size_t)j * D, *eb = etb + (size_t)j * D;
         const double da = s->da[j], et = eta[j];
-        double *geb = grad + d + ng + (size_t)j * D;
+        double *geb = grad + db_ + ng + (size_t)j * D;
         lp -= laplace ? fabs(et) : 0.5 * et * et;
-        grad[d + j] = da * sa - (laplace ? (double)SGN(et) : et);
+        grad[db_ + j] = da * sa - (laplace ? (double)SGN(et) : et);
         if (model != M1B)
             for (int c = 0; c < D; ++c) lp -= laplace ? fabs(eb[c]) : 0.5 * eb[c] * eb[c];
         switch (model) {
@@ -266,6 +284,8 @@ int epo_logdensity_grad_groups(int model, int n, int D, int ng, const int64_t *g
     s.P = epo_npar_groups(model, D, ng);
     if (s.d < 0 || s.P < 0) return -1;
     s.X = X; s.y = y; s.mu = mu; s.Om = Omega;
+    s.yd = NULL;
+    if (is_gauss(model)) { s.yd = (const double *)(const void *)y; s.y = NULL; }
     double *w = (double *)malloc(sizeof(double) * site_scratch(D, s.d, ng));
     site_bind_scratch(&s, w);
     *lp = site_lp_grad(&s, theta, grad);
@@ -646,6 +666,8 @@ static void bind_site(site_t *s, int model, int D, int d, int k, const int64_t *
     s->model = model; s->D = D; s->d = d;
     s->n = (int)(k_lim[k + 1] - k_lim[k]);
     s->X = X + (size_t)k_lim[k] * D; s->y = y + k_lim[k];
+    s->yd = NULL;
+    if (is_gauss(model)) { s->yd = (const double *)(const void *)y + k_lim[k]; s->y = NULL; }
     s->mu = mu + (size_t)k * d; s->Om = Omega + (size_t)k * d * d;
     s->beta = s->db = s->da = s->Ov = NULL;
     s->ng = g_cnt ? g_cnt[k] : 1;

@@ -15,7 +15,10 @@ LIB = os.path.join(HERE, 'libepx_oracle.so')
 MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4,
              # the multi-group programs (K < J, experiment/models/m*b.stan): same densities, several
              # (eta, etb) blocks per site
-             'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4}
+             'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4,
+             # Gaussian-likelihood family (experiment/models/m*a_sg.stan): phi = [log sigma | b-model phi],
+             # real-valued responses
+             'm1a_sg': 5, 'm2a_sg': 6, 'm3a_sg': 7, 'm4a_sg': 8, 'm5a_sg': 9}
 STAT_NAMES = ('stepsize_mean', 'stepsize_final', 'nleap', 'ngrad', 'ndiv',
               'accept_mean', 'depth_mean', 'fail')
 _lib = None
@@ -44,6 +47,22 @@ def _p(a, t=ctypes.c_double):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
+def is_gauss(model):
+    return MODEL_IDS[model] >= 5
+
+
+def _y(model, y):
+    """Responses in the type the library expects for the model: int32 0/1, or float64 for the
+    Gaussian family (nuts_oracle.c reads `y` as doubles for model ids 5..9)."""
+    if is_gauss(model):
+        return np.ascontiguousarray(y, dtype=np.float64)
+    return np.ascontiguousarray(y, dtype=np.int32)
+
+
+def _yp(y):
+    return ctypes.cast(y.ctypes.data, ctypes.POINTER(ctypes.c_int32))
+
+
 def dims(model, D, ng=1):
     """(dphi, sampled coordinates) of a site with ng groups."""
     L = lib()
@@ -67,7 +86,7 @@ def logdensity_grad(model, X, y, mu, Omega, theta, gl=None):
     """gl: row limits of the site's groups relative to its first row (ng+1 entries), or None."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
-    y = np.ascontiguousarray(y, dtype=np.int32)
+    y = _y(model, y)
     mu = np.ascontiguousarray(mu, dtype=np.float64)
     Om = np.ascontiguousarray(Omega, dtype=np.float64)
     th = np.ascontiguousarray(theta, dtype=np.float64)
@@ -79,7 +98,7 @@ def logdensity_grad(model, X, y, mu, Omega, theta, gl=None):
     else:
         gl = np.ascontiguousarray(gl, dtype=np.int64)
         ng, glp = gl.shape[0] - 1, _p(gl, ctypes.c_int64)
-    rc = L.epo_logdensity_grad_groups(MODEL_IDS[model], n, D, ng, glp, _p(X), _p(y, ctypes.c_int32),
+    rc = L.epo_logdensity_grad_groups(MODEL_IDS[model], n, D, ng, glp, _p(X), _yp(y),
                                       _p(mu), _p(Om), _p(th), ctypes.byref(lp), _p(g))
     assert rc == 0
     return lp.value, g
@@ -92,7 +111,7 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
     largest coordinate count over the sites and shorter sites are zero padded."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
-    y = np.ascontiguousarray(y, dtype=np.int32)
+    y = _y(model, y)
     k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
     K = k_lim.shape[0] - 1
     D = X.shape[1]
@@ -114,7 +133,7 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
     rc = L.epo_nuts_sites_groups(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
                                  None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
                                  None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
-                                 _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
+                                 _yp(y), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
                                  chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
                                  _p(stats), nthreads)
     if rc != 0:
@@ -128,7 +147,7 @@ def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1,
     with step sizes eps (K,chains) and inverse metrics inv_e (K,chains,P)."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
-    y = np.ascontiguousarray(y, dtype=np.int32)
+    y = _y(model, y)
     k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
     K = k_lim.shape[0] - 1
     D = X.shape[1]
@@ -147,7 +166,7 @@ def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1,
     rc = L.epo_nuts_transitions_groups(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
                                 None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
                                 None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
-                                _p(y, ctypes.c_int32), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
+                                _yp(y), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
                                 chains, nt, t_offset, max_depth, _p(q0), _p(eps), _p(inv_e),
                                 _p(draws), _p(last), _p(stats))
     if rc != 0:

@@ -8,13 +8,16 @@ import pytest
 from oracle import ep_oracle as eo
 from oracle import nuts_oracle as no
 
-MODELS = ['m1b_sg', 'm2b_sg', 'm3b_sg', 'm4b_sg', 'm5b_sg']
+MODELS = ['m1b_sg', 'm2b_sg', 'm3b_sg', 'm4b_sg', 'm5b_sg',
+          'm1a_sg', 'm2a_sg', 'm3a_sg', 'm4a_sg', 'm5a_sg']     # a: Gaussian likelihood, real responses
 
 
 def _problem(model, D, n, seed):
     rng = np.random.RandomState(seed)
     X = rng.randn(n, D)
     y = (rng.rand(n) < 0.5).astype(np.int32)
+    if no.is_gauss(model):
+        y = rng.randn(n) * 1.3 + 0.2
     d, P = no.dims(model, D)
     A = rng.randn(d, d + 3)
     Om = A.dot(A.T) / (d + 3) + 0.5 * np.eye(d)
@@ -36,7 +39,7 @@ def test_logdensity_and_gradient(model):
             fd[i] = (no.logdensity_grad(model, X, y, mu, Om, th + e)[0]
                      - no.logdensity_grad(model, X, y, mu, Om, th - e)[0]) / 2e-6
         mask = np.ones(P, bool)
-        if model == 'm5b_sg':
+        if model in ('m5b_sg', 'm5a_sg'):
             mask = np.abs(th) > 1e-4                                   # |.| is not smooth at 0
         np.testing.assert_allclose(g[mask], fd[mask], rtol=2e-6, atol=2e-6)
 
@@ -56,6 +59,37 @@ def test_sampler_gaussian_known_answer():
     np.testing.assert_allclose(np.cov(x[:, :d].T), S, atol=0.06 * np.abs(S).max())
     np.testing.assert_allclose(x[:, d:].var(0), 1.0, atol=0.08)
     assert 0.75 < stats[0, :, 5].mean() < 0.97 and stats[0, :, 4].sum() == 0
+
+
+def test_sampler_gaussian_family_known_answer():
+    """m1a_sg with log sigma and log sigma_a pinned by the cavity: the tilted distribution of
+    (beta, eta) is Gaussian with a closed-form mean and covariance (the analytic check of the
+    Gaussian-likelihood family)."""
+    rng = np.random.RandomState(12)
+    D, n = 3, 25
+    d, P = no.dims('m1a_sg', D)                 # phi = [log sigma, log sigma_a, beta(3)], eta
+    X = rng.randn(n, D)
+    ls, lsa = np.log(0.7), np.log(1.4)
+    y = 0.3 + X.dot([0.5, -1.0, 0.2]) + 0.7 * rng.randn(n)
+    A = rng.randn(D, D + 2)
+    Ob = A.dot(A.T) / (D + 2) + 0.4 * np.eye(D)
+    Om = np.zeros((d, d)); Om[0, 0] = Om[1, 1] = 1e8; Om[2:, 2:] = Ob
+    mu = np.concatenate(([ls, lsa], rng.randn(D) * 0.3))
+    draws, _, stats = no.nuts_sites('m1a_sg', X, y, [0, n], mu[None], Om[None], [7], chains=4,
+                                    iter=5000, warmup=1000)
+    x = draws[0].reshape(-1, P)
+    assert np.abs(x[:, 0] - ls).max() < 1e-3 and np.abs(x[:, 1] - lsa).max() < 1e-3
+    # exact: z = (beta, eta), f = [X | sigma_a 1] z, prior precision diag(Ob, 1), noise sigma
+    Z = np.hstack((X, np.full((n, 1), np.exp(lsa))))
+    Pz = np.zeros((D + 1, D + 1)); Pz[:D, :D] = Ob; Pz[D, D] = 1.0
+    prec = Pz + Z.T.dot(Z) / np.exp(2 * ls)
+    rhs = np.concatenate((Ob.dot(mu[2:]), [0.0])) + Z.T.dot(y) / np.exp(2 * ls)
+    S = np.linalg.inv(prec); m = S.dot(rhs)
+    z = x[:, 2:]
+    sd = np.sqrt(np.diag(S))
+    assert np.all(np.abs(z.mean(0) - m) < 5 * sd / np.sqrt(4000))
+    np.testing.assert_allclose(np.cov(z.T), S, atol=0.08 * np.abs(S).max())
+    assert stats[0, :, 4].sum() == 0
 
 
 def test_sampler_logistic_against_quadrature():
