@@ -50,6 +50,8 @@ struct epx_ctx {
     double *X;
     uint8_t *y;
     int *y32;
+    double *yd;                     // real responses (Gaussian-likelihood family), else NULL
+    int gauss;
     double *Q0, *r0, *Q, *r, *S, *m;
     double *Qi, *ri, *Qi2, *ri2, *dQi, *dri;
     double *cav_Om, *cav_mu;
@@ -97,15 +99,16 @@ int epx_device_count(int *count) {
 
 int epx_model_dims(int model, int D, int *dphi, int *npar) {
     int d, P;
-    switch (model) {
+    const int o = (model >= EPX_M1A_SG && model <= EPX_M5A_SG) ? 1 : 0;      // log sigma in front
+    switch (model - (o ? EPX_M1A_SG : 0)) {
     case EPX_M1B_SG: d = D + 1; P = D + 2; break;
     case EPX_M2B_SG: d = 2; P = D + 3; break;
     case EPX_M3B_SG: d = D + 1; P = 2 * D + 2; break;
     case EPX_M4B_SG: case EPX_M5B_SG: d = 2 * D + 2; P = 3 * D + 3; break;
     default: return fail("unknown model id %d", model);
     }
-    if (dphi) *dphi = d;
-    if (npar) *npar = P;
+    if (dphi) *dphi = d + o;
+    if (npar) *npar = P + o;
     return 0;
 }
 
@@ -143,6 +146,9 @@ static int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
+static int ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                      const int64_t *g_lim, const double *X, const int32_t *y, const double *yd, epx_ctx **out);
+
 int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
                    const int32_t *y, epx_ctx **out) {
     return epx_ctx_create_groups(device, model, K_local, D, k_lim, nullptr, nullptr, X, y, out);
@@ -150,6 +156,22 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
 
 int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
                           const int64_t *g_lim, const double *X, const int32_t *y, epx_ctx **out) {
+    if (out) *out = nullptr;
+    if (model >= EPX_M1A_SG && model <= EPX_M5A_SG)
+        return fail("model %d has real responses: use epx_ctx_create_real", model);
+    return ctx_create(device, model, K_local, D, k_lim, g_cnt, g_lim, X, y, nullptr, out);
+}
+
+int epx_ctx_create_real(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
+                        const double *y, epx_ctx **out) {
+    if (out) *out = nullptr;
+    if (model < EPX_M1A_SG || model > EPX_M5A_SG)
+        return fail("model %d has 0/1 responses: use epx_ctx_create", model);
+    return ctx_create(device, model, K_local, D, k_lim, nullptr, nullptr, X, nullptr, y, out);
+}
+
+static int ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                      const int64_t *g_lim, const double *X, const int32_t *y, const double *yd, epx_ctx **out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -162,7 +184,10 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
     HIPCHK(hipSetDevice(device));
     epx_ctx *c = new epx_ctx();
     memset((void *)c, 0, sizeof(int) * 6);
-    c->device = device; c->model = model; c->K = K_local; c->D = D; c->d = d; c->P = P;
+    c->device = device; c->K = K_local; c->D = D; c->d = d; c->P = P;
+    c->gauss = yd != nullptr;
+    c->model = c->gauss ? model - EPX_M1A_SG : model;       // the kernels take the b-model id plus the family flag
+    model = c->model;
     c->k_lim.assign(k_lim, k_lim + K_local + 1);
     c->N = k_lim[K_local] - k_lim[0];
     c->n_max = 0;
@@ -258,7 +283,15 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
     HIPCHK(dalloc(&c->partial, (size_t)len * c->nslice));
     HIPCHK(hipMemcpy(c->k_lim_d, k_lim, (K + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->X, X, (size_t)c->N * D * sizeof(double), hipMemcpyHostToDevice));
-    {
+    c->yd = nullptr;
+    if (c->gauss) {
+        for (int64_t i = 0; i < c->N; ++i)
+            if (!std::isfinite(yd[i])) { epx_ctx_destroy(c); return fail("y[%lld] is not finite", (long long)i); }
+        HIPCHK(dalloc(&c->yd, (size_t)c->N));
+        HIPCHK(hipMemcpy(c->yd, yd, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(c->y, 0, (size_t)c->N));
+        HIPCHK(hipMemset(c->y32, 0, (size_t)c->N * sizeof(int)));
+    } else {
         std::vector<uint8_t> yb((size_t)c->N);
         for (int64_t i = 0; i < c->N; ++i) {
             if (y[i] != 0 && y[i] != 1) { epx_ctx_destroy(c); return fail("y[%lld] = %d is not 0/1", (long long)i, y[i]); }
@@ -280,7 +313,7 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -482,6 +515,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
     memset(&a, 0, sizeof a);
     a.model = c->model; a.D = c->D; a.d = c->d; a.P = c->P; a.k0 = k0;
+    a.gauss = c->gauss; a.yd = c->yd;
     a.chains = o.chains; a.iter = o.iter; a.warmup = o.warmup; a.thin = o.thin; a.nkeep = nkeep;
     a.max_depth = o.max_depth; a.init_mode = o.init;
     a.k_lim = c->k_lim_d; a.X = c->X; a.y = c->y; a.y32 = c->y32; a.cav_Om = c->cav_Om; a.cav_mu = c->cav_mu;
@@ -528,6 +562,13 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         else { wpc = 4; a.cpb = 1; }
         const size_t lds = nuts_lds_layout(a, wpc, dp, c->n_max);
         if (lds > LDS_CAP) resident = false;
+    }
+    if (c->gauss) {
+        // Gaussian-likelihood family: built for the everything-in-LDS forms of the resident kernels
+        const bool ok = resident && a.om_in_lds && (wpc == 1 || (a.stack_in_lds && a.off_spec > 0 && !no_spec));
+        if (!ok) return fail("Gaussian-likelihood models need the site's rows, the cavity precision and (one workgroup "
+                             "per chain) the tree stack in LDS; this shape (D = %d, n_max = %d, layout %d) is not supported",
+                             c->D, c->n_max, o.layout);
     }
     if (!resident && !lock) {
         // rows (or parameters) do not fit the resident kernel: stream X through an LDS tile

@@ -102,6 +102,8 @@ enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
 enum { MAX_DEPTH_CAP = 12 };
 
 struct NutsArgs {
+    int gauss;                  // Gaussian-likelihood family (m*a_sg.stan): phi[0] = log sigma, real responses in yd
+    const double *yd;
     int model, D, d, P;
     int k0;                       // first site of the batch
     int chains, iter, warmup, thin, nkeep, max_depth, init_mode;

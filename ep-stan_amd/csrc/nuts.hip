@@ -96,7 +96,7 @@ __device__ inline void butterfly(double *acc, int lane) {
     }
 }
 
-template <int NV, int DP, int WPC, bool OML, bool STL>
+template <int NV, int DP, int WPC, bool OML, bool STL, bool GAUSS>
 __global__ void __launch_bounds__(256)
 k_nuts(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -118,7 +118,10 @@ k_nuts(NutsArgs a) {
     const int n = (int)(a.k_lim[k + 1] - row0);
 
     double *Xs = reinterpret_cast<double *>(smem);
-    uint8_t *ys = smem + a.off_y;
+    uint8_t *ys = smem + a.off_y;                                   // 0/1 responses (logistic family) ...
+    double *ysd = reinterpret_cast<double *>(smem + a.off_y);       // ... or real ones (Gaussian family)
+    auto y_at = [&](int r) -> double { if constexpr (GAUSS) return ysd[r]; else return (double)ys[r]; };
+    (void)ys; (void)ysd;
     double *xch = reinterpret_cast<double *>(smem + a.off_xch);
 
     // ---- stage the site's rows: HBM -> LDS, once per site update
@@ -136,7 +139,8 @@ k_nuts(NutsArgs a) {
             const int sw = (r / RPL) & (SPR - 1);
             *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
         }
-        for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r];
+        if constexpr (GAUSS) { for (int r = tid; r < n; r += blockDim.x) ysd[r] = a.yd[row0 + r]; }
+        else { for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r]; }
     }
     // Omega and the tree stack: LDS-typed pointers when resident (template flags keep
     // the address space static, so the compiler emits ds_read/ds_write, not flat_*)
@@ -321,7 +325,7 @@ k_nuts(NutsArgs a) {
 //                    post record s
 enum { SPEC_NONE = 0, SPEC_RESTART = 1, SPEC_EXIT = 2 };
 
-template <int NV, int DP, bool RES>
+template <int NV, int DP, bool RES, bool GAUSS>
 __global__ void __launch_bounds__(320)
 k_nuts_spec(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -348,7 +352,10 @@ k_nuts_spec(NutsArgs a) {
     const int n = (int)(a.k_lim[k + 1] - row0);
 
     double *Xs = reinterpret_cast<double *>(smem);
-    uint8_t *ys = smem + a.off_y;
+    uint8_t *ys = smem + a.off_y;                                   // 0/1 responses (logistic family) ...
+    double *ysd = reinterpret_cast<double *>(smem + a.off_y);       // ... or real ones (Gaussian family)
+    auto y_at = [&](int r) -> double { if constexpr (GAUSS) return ysd[r]; else return (double)ys[r]; };
+    (void)ys; (void)ysd;
     double *xch = reinterpret_cast<double *>(smem + a.off_xch);
     double *mbox = reinterpret_cast<double *>(smem + a.off_spec);            // 2 x MREC
     double *ctrl = mbox + 2 * MREC;                                         // 2 x CREC
@@ -366,7 +373,8 @@ k_nuts_spec(NutsArgs a) {
             const int sw = (r / RPL) & (SPR - 1);
             *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
         }
-        for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r];
+        if constexpr (GAUSS) { for (int r = tid; r < n; r += blockDim.x) ysd[r] = a.yd[row0 + r]; }
+        else { for (int r = tid; r < n; r += blockDim.x) ys[r] = a.y[row0 + r]; }
     }
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);
@@ -613,7 +621,7 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     const int nv = (a.P + 63) / 64;
     size_t off = (size_t)n_max * dp * 8;
     a.n_max = n_max;
-    a.off_y = (int)off; off += ((size_t)n_max + 15) & ~(size_t)15;
+    a.off_y = (int)off; off += (((size_t)n_max * (a.gauss ? 8 : 1)) + 15) & ~(size_t)15;
     a.off_xch = (int)off;
     if (wpc > 1) off += (size_t)2 * wpc * (64 * (1 + nv) + 2) * 8;
     off = (off + 15) & ~(size_t)15;
@@ -639,9 +647,9 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     return off;
 }
 
-template <int NV, int DP, bool RES>
+template <int NV, int DP, bool RES, bool GAUSS = false>
 static int launch_spec(const NutsArgs &a, int nblocks, hipStream_t stream) {
-    auto kern = k_nuts_spec<NV, DP, RES>;
+    auto kern = k_nuts_spec<NV, DP, RES, GAUSS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return (int)e;
@@ -649,9 +657,9 @@ static int launch_spec(const NutsArgs &a, int nblocks, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-template <int NV, int DP, int WPC, bool OML, bool STL>
+template <int NV, int DP, int WPC, bool OML, bool STL, bool GAUSS = false>
 static int launch_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
-    auto kern = k_nuts<NV, DP, WPC, OML, STL>;
+    auto kern = k_nuts<NV, DP, WPC, OML, STL, GAUSS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return (int)e;
@@ -663,6 +671,13 @@ static int launch_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 template <int NV, int DP>
 static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t stream) {
     // (Omega in LDS, stack in LDS): layout 2 has both or neither; layout 1 may have Omega only
+    if (a.gauss) {
+        // Gaussian-likelihood family: the everything-resident kernels only (the host refuses other shapes)
+        if (wpc == 4 && a.off_spec > 0 && a.om_in_lds && !a.no_spec) return launch_spec<NV, DP, true, true>(a, nblocks, stream);
+        if (wpc == 1 && a.om_in_lds && a.stack_in_lds) return launch_one<NV, DP, 1, true, true, true>(a, nblocks, stream);
+        if (wpc == 1 && a.om_in_lds) return launch_one<NV, DP, 1, true, false, true>(a, nblocks, stream);
+        return -1;
+    }
     if (wpc == 4) {
         if (a.off_spec > 0 && !a.no_spec)
             return a.om_in_lds ? launch_spec<NV, DP, true>(a, nblocks, stream) : launch_spec<NV, DP, false>(a, nblocks, stream);

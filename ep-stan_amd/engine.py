@@ -15,7 +15,14 @@ from ._lib import SamplerOpts, check, dptr
 MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4,
              # the multi-group programs experiment/models/m{1..5}b.stan (K < J): same densities with
              # several (eta, etb) blocks per site; they need the group structure of the sites
-             'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4}
+             'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4,
+             # Gaussian-likelihood family experiment/models/m{1..5}a_sg.stan: phi = [log sigma | the
+             # b-model's phi], real responses
+             'm1a_sg': 5, 'm2a_sg': 6, 'm3a_sg': 7, 'm4a_sg': 8, 'm5a_sg': 9}
+
+
+def is_gauss(model):
+    return MODEL_IDS[model] >= 5
 PREC_ESTIM_IDS = {'sample': 0, 'olse': 1}
 QI, QI2, DQI = 0, 1, 2
 INIT_IDS = {'random': 0, '0': 1, 0: 1, 'prev': 2}
@@ -47,7 +54,11 @@ class HipEngine(object):
         X = np.ascontiguousarray(X, dtype=np.float64)
         if X.ndim != 2:
             raise ValueError('the built-in site models need a two dimensional X')
-        y32 = np.ascontiguousarray(y, dtype=np.int32)
+        gauss = is_gauss(model)
+        if gauss and g_cnt is not None:
+            raise ValueError('the Gaussian-likelihood models are built for one group per site')
+        y32 = None if gauss else np.ascontiguousarray(y, dtype=np.int32)
+        yd = np.ascontiguousarray(y, dtype=np.float64) if gauss else None
         k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
         self.model = model
         self.K = k_lim.shape[0] - 1
@@ -55,7 +66,12 @@ class HipEngine(object):
         self.d, self.P = model_dims(model if model.endswith('_sg') else model + '_sg', self.D)
         self.device = device
         ctx = ctypes.c_void_p()
-        if g_cnt is None:
+        if gauss:
+            self.site_P = np.full(self.K, self.P, dtype=np.int64)
+            check(self.lib.epx_ctx_create_real(
+                device, MODEL_IDS[model], self.K, self.D,
+                k_lim.ctypes.data_as(_lib.c_int64_p), dptr(X), dptr(yd), ctypes.byref(ctx)))
+        elif g_cnt is None:
             if not model.endswith('_sg'):
                 raise ValueError('site model {!r} needs the groups of every site (g_cnt, g_lim)'.format(model))
             check(self.lib.epx_ctx_create(

@@ -33,7 +33,10 @@ typedef struct epx_ctx epx_ctx;
 /* Site log-density families: the reference's single-group Stan programs
  * experiment/models/m{1,2,3,4,5}b_sg.stan (selected by the basename of the
  * `site_model` path given to Master, method.py:647,672). */
-enum epx_model { EPX_M1B_SG = 0, EPX_M2B_SG = 1, EPX_M3B_SG = 2, EPX_M4B_SG = 3, EPX_M5B_SG = 4 };
+enum epx_model { EPX_M1B_SG = 0, EPX_M2B_SG = 1, EPX_M3B_SG = 2, EPX_M4B_SG = 3, EPX_M5B_SG = 4,
+                 /* Gaussian-likelihood family, experiment/models/m{1..5}a_sg.stan: phi = [log sigma | the
+                  * b-model's phi], y ~ normal(alpha + X beta, sigma), real responses (epx_ctx_create_real) */
+                 EPX_M1A_SG = 5, EPX_M2A_SG = 6, EPX_M3A_SG = 7, EPX_M4A_SG = 8, EPX_M5A_SG = 9 };
 
 /* Worker.PREC_ESTIM_OPTIONS, method.py:163 */
 enum epx_prec_estim { EPX_PREC_SAMPLE = 0, EPX_PREC_OLSE = 1 };
@@ -100,6 +103,13 @@ int epx_ctx_create(int device, int model, int K_local, int D, const int64_t *k_l
  * stride of the largest site.  Runs on the streaming sampler layout. */
 int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
                           const int64_t *g_lim, const double *X, const int32_t *y, epx_ctx **out);
+
+/* The same for the Gaussian-likelihood models (EPX_M1A_SG..EPX_M5A_SG; `real y[N]` in
+ * experiment/models/m1a_sg.stan:16, simulated in models/m1a.py:150-176): y holds real responses.
+ * One group per site; the site's rows, cavity precision (and, for one workgroup per chain, the tree
+ * stack) must fit the LDS -- other shapes are refused by the sampling calls. */
+int epx_ctx_create_real(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
+                        const double *y, epx_ctx **out);
 int epx_ctx_destroy(epx_ctx *ctx);
 
 /* prior natural parameters Q0 (d,d) F-order, r0 (d): method.py:772-797 */

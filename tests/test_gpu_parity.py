@@ -228,6 +228,8 @@ def _site_problem(model, D, n, seed, K=2, tight=1.0):
     rng = np.random.RandomState(seed)
     X = rng.randn(K * n, D) * 1.5
     y = (rng.rand(K * n) < 0.6).astype(int)
+    if no.is_gauss(model):                      # m*a_sg: real responses
+        y = 0.4 + X.dot(rng.randn(D) * 0.5) + 0.8 * rng.randn(K * n)
     d, P = no.dims(model, D)
     Oms, mus = [], []
     for k in range(K):
@@ -252,20 +254,35 @@ def _engine_with_cavity(model, X, y, k_lim, Oms, mus):
     return eng, Om_dev, mu_dev
 
 
-@pytest.mark.parametrize('model', ['m1b_sg', 'm2b_sg', 'm3b_sg', 'm4b_sg', 'm5b_sg'])
+@pytest.mark.parametrize('model', ['m1b_sg', 'm2b_sg', 'm3b_sg', 'm4b_sg', 'm5b_sg',
+                                   'm1a_sg', 'm2a_sg', 'm3a_sg', 'm4a_sg', 'm5a_sg'])
 @pytest.mark.parametrize('D,n', [(3, 7), (4, 50), (16, 200), (21, 333), (32, 500)])
 def test_logdensity_gradient_matches_oracle(model, D, n):
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 100 + D)
     eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     rng = np.random.RandomState(5)
+    layouts = (2, 1)
+    if no.is_gauss(model):
+        # the Gaussian-likelihood family is built for sites that are fully LDS resident
+        dp = [c for c in (4, 8, 16, 32) if c >= D][0]
+        lds1 = n * dp * 8 + n * 8 + d * d * 8                       # rows, responses, cavity precision
+        nv = (P + 63) // 64
+        lds2 = lds1 + 2 * 4 * (64 * (1 + nv) + 2) * 8 + 10 * (4 * nv * 64 + 2) * 8 + 2 * (7 * nv * 64 + 72) * 8
+        if lds1 > 160 * 1024:
+            with pytest.raises(_lib.EpxError, match='not supported'):
+                eng.logdensity_grad(0, np.zeros(P), layout=1)
+            return
+        if lds2 > 160 * 1024:
+            layouts = (1,)                      # one workgroup per chain needs exchange, tree stack and mailbox in LDS too
     for k in range(2):
         for trial in range(3):
             theta = rng.randn(P) * (0.2 + 0.4 * trial)
-            lp, g = eng.logdensity_grad(k, theta)
             lo, hi = k_lim[k], k_lim[k + 1]
             lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta)
-            assert abs(lp - lp_o) <= 1e-11 * max(1.0, abs(lp_o))
-            np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
+            for layout in layouts:
+                lp, g = eng.logdensity_grad(k, theta, layout=layout)
+                assert abs(lp - lp_o) <= 1e-11 * max(1.0, abs(lp_o))
+                np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
 
 
 # ------------------------------------------------------------------ sampler vs oracle, draw by draw
@@ -277,6 +294,9 @@ def test_logdensity_gradient_matches_oracle(model, D, n):
     # layout 4: chains in lock step, rows resident, MFMA products
     ('m4b_sg', 4, 50, 4, 60, 100.), ('m1b_sg', 16, 200, 4, 60, 100.), ('m4b_sg', 32, 120, 4, 44, 1000.),
     ('m5b_sg', 9, 77, 4, 60, 100.), ('m3b_sg', 32, 300, 4, 44, 1000.), ('m2b_sg', 21, 333, 4, 44, 1000.),
+    # Gaussian-likelihood family (real responses, phi[0] = log sigma)
+    ('m1a_sg', 4, 50, 2, 60, 100.), ('m4a_sg', 4, 50, 1, 60, 100.), ('m4a_sg', 16, 200, 2, 44, 1000.),
+    ('m5a_sg', 7, 33, 1, 60, 100.), ('m2a_sg', 6, 80, 2, 60, 100.), ('m3a_sg', 16, 120, 1, 44, 1000.),
 ])
 def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
     """Whole site updates (random init, step-size search, dual averaging, metric
@@ -328,6 +348,7 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
     ('m4b_sg', 4, 50, 1), ('m4b_sg', 4, 50, 2), ('m5b_sg', 8, 64, 2), ('m3b_sg', 16, 100, 1),
     ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1), ('m4b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 2),
     ('m1b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 4), ('m4b_sg', 16, 200, 4), ('m1b_sg', 32, 500, 4), ('m3b_sg', 7, 45, 4),
+    ('m4a_sg', 16, 200, 2), ('m4a_sg', 16, 200, 1), ('m1a_sg', 32, 300, 1), ('m3a_sg', 8, 64, 2),
 ])
 def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
     """Generic (wide, funnel-shaped) tilted distributions up to BASELINE config
