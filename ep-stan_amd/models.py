@@ -77,6 +77,23 @@ def calc_input_param_classification(alpha, beta, Sigma_x=None):
     return mu_x, sigma_x
 
 
+R_SQUARED = 0.5            # common.py:16: target coefficient of determination of the regression models
+
+
+def calc_input_param_lin_reg(beta, sigma, Sigma_x=None):
+    """Input scale of the linear-regression simulators (common.py:81-131): sigma_x such that
+    Var(x beta) / (Var(x beta) + sigma^2) = R_SQUARED, per group when beta is (J, D)."""
+    beta = np.asarray(beta, dtype=np.float64)
+    one_dim = beta.ndim == 0 or beta.shape[-1] == 1
+    if Sigma_x is not None and one_dim:
+        raise ValueError("Input dimension has to be greater than 1 if Sigma is provided")
+    if one_dim:
+        b = np.abs(beta.reshape(-1)) if beta.ndim == 2 else np.abs(beta.reshape(-1)[0])
+        return np.sqrt(R_SQUARED/(1 - R_SQUARED))*sigma/b
+    quad = np.sum(np.square(beta), axis=-1) if Sigma_x is None else np.sum(beta.dot(Sigma_x)*beta, axis=-1)
+    return np.sqrt(R_SQUARED/(quad*(1 - R_SQUARED)))*sigma
+
+
 class Data(object):
     """Simulated data set (common.py:320-404, the fields the EP path uses)."""
 
@@ -221,7 +238,97 @@ class m4b(object):
         return S0, m0, Q0, r0
 
 
-MODELS = {'m1b': m1b, 'm4b': m4b}
+class m1a(object):
+    """y ~ N(alpha_j + x beta, sigma), alpha_j ~ N(0, sigma_a), phi = [log sigma, log sigma_a, beta]
+    (models/m1a.py; site density models/m1a_sg.stan)."""
+    SIGMA, SIGMA_A, SIGMA_B = 1, 1, 1                  # m1a.py:38-46
+    V0_S = V0_A = V0_B = 1.5**2                        # m1a.py:49-58 (zero prior means)
+    site_model = 'm1a_sg'
+
+    def __init__(self, J, D, npg):
+        self.J, self.D, self.npg = J, D, npg
+        self.dphi = D + 2
+
+    def simulate_data(self, Sigma_x=None, rng=None):
+        J, D = self.J, self.D
+        if not isinstance(rng, np.random.RandomState):
+            rng = np.random.RandomState(rng)
+        seed_input_cov = rng.randint(2**31 - 1)
+        if isinstance(Sigma_x, str) and Sigma_x == 'rand':
+            Sigma_x = rand_corr_vine(D, seed=seed_input_cov)
+        Nj, j_lim = _sizes(rng, J, self.npg)
+        N = int(np.sum(Nj))
+        sigma, sigma_a = self.SIGMA, self.SIGMA_A
+        beta = rng.randn(D)*self.SIGMA_B
+        beta_sum = np.sum(beta)
+        while np.abs(beta_sum) < B_ABS_MIN_SUM:
+            index = rng.randint(D)
+            beta_sum -= beta[index]
+            beta[index] = rng.randn()*self.SIGMA_B
+            beta_sum += beta[index]
+        alpha_j = rng.randn(J)*sigma_a
+        phi_true = np.concatenate(([np.log(sigma), np.log(sigma_a)], beta))
+        sigma_x = calc_input_param_lin_reg(beta, sigma, Sigma_x)
+        if Sigma_x is None:
+            X = rng.randn(N, D)*sigma_x
+        else:
+            X = rng.randn(N, D).dot(sigma_x*cholesky(Sigma_x))
+        y = alpha_j[np.repeat(np.arange(J), Nj)] + X.dot(beta)
+        y = y + rng.randn(N)*sigma
+        return Data(X, y, Nj, j_lim, phi_true, {'sigma_x': sigma_x, 'Sigma_x': Sigma_x})
+
+    def get_prior(self):
+        v = np.concatenate(([self.V0_S, self.V0_A], np.full(self.D, self.V0_B)))
+        m0 = np.zeros(self.dphi)
+        return np.diag(v).T, m0, np.diag(1/v).T, m0/v
+
+
+class m4a(object):
+    """y ~ N(alpha_j + x beta_j, sigma), alpha_j ~ N(mu_a, sigma_a), beta_jd ~ N(mu_b_d, sigma_b_d),
+    phi = [log sigma, mu_a, log sigma_a, mu_b, log sigma_b] (models/m4a.py; density m4a_sg.stan)."""
+    SIGMA, MU_A, SIGMA_A, SIGMA_MB, SIGMA_SB = 1, 0.1, 1, 1, 1        # m4a.py:45-55
+    V0 = 1.5**2                                                       # m4a.py:57-72, all five blocks
+    site_model = 'm4a_sg'
+
+    def __init__(self, J, D, npg):
+        self.J, self.D, self.npg = J, D, npg
+        self.dphi = 2*D + 3
+
+    def simulate_data(self, Sigma_x=None, rng=None):
+        J, D = self.J, self.D
+        if not isinstance(rng, np.random.RandomState):
+            rng = np.random.RandomState(rng)
+        seed_input_cov = rng.randint(2**31 - 1)
+        if isinstance(Sigma_x, str) and Sigma_x == 'rand':
+            Sigma_x = rand_corr_vine(D, seed=seed_input_cov)
+        Nj, j_lim = _sizes(rng, J, self.npg)
+        sigma, sigma_a, mu_a = self.SIGMA, self.SIGMA_A, self.MU_A
+        sigma_b = np.exp(rng.randn(D)*self.SIGMA_SB)
+        mu_b = rng.randn(D)*self.SIGMA_MB
+        alpha_j = mu_a + rng.randn(J)*sigma_a
+        beta_j = mu_b + rng.randn(J, D)*sigma_b
+        for j in range(J):
+            beta_sum = np.sum(beta_j[j])
+            while np.abs(beta_sum) < B_ABS_MIN_SUM:
+                index = rng.randint(D)
+                beta_sum -= beta_j[j, index]
+                beta_j[j, index] = mu_b[index] + rng.randn()*sigma_b[index]
+                beta_sum += beta_j[j, index]
+        phi_true = np.concatenate(([np.log(sigma), mu_a, np.log(sigma_a)], mu_b, np.log(sigma_b)))
+        sigma_x_j = calc_input_param_lin_reg(beta_j, sigma, Sigma_x)
+        X = _draw_X(rng, Nj, j_lim, D, np.zeros(J), sigma_x_j, Sigma_x)
+        j_ind = np.repeat(np.arange(J), Nj)
+        y = alpha_j[j_ind] + np.einsum('nd,nd->n', X, beta_j[j_ind])
+        y = y + rng.randn(X.shape[0])*sigma
+        return Data(X, y, Nj, j_lim, phi_true, {'sigma_x': sigma_x_j, 'Sigma_x': Sigma_x})
+
+    def get_prior(self):
+        v = np.full(self.dphi, self.V0)
+        m0 = np.zeros(self.dphi)
+        return np.diag(v).T, m0, np.diag(1/v).T, m0/v
+
+
+MODELS = {'m1b': m1b, 'm4b': m4b, 'm1a': m1a, 'm4a': m4a}
 
 
 def default_df0(K):

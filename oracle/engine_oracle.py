@@ -24,7 +24,7 @@ class OracleEngine(object):
         self.g_cnt = None if g_cnt is None else np.ascontiguousarray(g_cnt, dtype=np.int32)
         self.g_lim = None if g_lim is None else np.ascontiguousarray(g_lim, dtype=np.int64)
         self.X = np.ascontiguousarray(X, dtype=np.float64)
-        self.y = np.ascontiguousarray(y, dtype=np.int32)
+        self.y = np.ascontiguousarray(y, dtype=np.float64 if no.is_gauss(model) else np.int32)
         self.k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
         self.K = self.k_lim.shape[0] - 1
         self.D = self.X.shape[1]

@@ -389,10 +389,36 @@ def g10_distribute_groups(util, out):
     out['g10_n'] = np.array(len(cases))
 
 
+def g11_gauss_simulators(out):
+    """Gaussian-likelihood simulators models/m1a.py, m4a.py (real responses; `rng=100` as fit.py:157)."""
+    from models import m1a, m4a
+    for tag, mod_ref, J, D, n, Sx in (('m1a_s', m1a, 5, 4, 20, 'rand'), ('m4a_s', m4a, 5, 4, 20, 'rand'),
+                                      ('m1a_i', m1a, 3, 1, 10, None), ('m4a_i', m4a, 3, 6, 15, None)):
+        mod = mod_ref.model(J, D, n)
+        data = mod.simulate_data(Sigma_x=Sx, rng=100)
+        S0, m0, Q0, r0 = mod.get_prior()
+        out['g11_%s_X' % tag] = data.X
+        out['g11_%s_y' % tag] = data.y
+        out['g11_%s_phi_true' % tag] = data.true_values['phi']
+        out['g11_%s_sigma_x' % tag] = np.asarray(data.X_param['sigma_x'])
+        out['g11_%s_Q0diag' % tag] = np.diag(Q0).copy()
+        out['g11_%s_r0' % tag] = r0
+        out['g11_%s_dphi' % tag] = np.array(mod.dphi)
+
+
 def main():
     util, method, tmp = import_reference()
     from models import m1b, m4b
     models = {'m1b': m1b, 'm4b': m4b}
+    if '--only-gauss' in sys.argv:
+        try:
+            sim = {}
+            g11_gauss_simulators(sim)
+            np.savez_compressed(os.path.join(HERE, 'simulators_gauss.npz'), **sim)
+            print('simulators_gauss.npz', os.path.getsize(os.path.join(HERE, 'simulators_gauss.npz')), 'bytes')
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     try:
         alg = {}
         g1_invert(util, alg)
@@ -412,6 +438,9 @@ def main():
         sim = {}
         g7_simulators(sim, models)
         np.savez_compressed(os.path.join(HERE, 'simulators.npz'), **sim)
+        simg = {}
+        g11_gauss_simulators(simg)
+        np.savez_compressed(os.path.join(HERE, 'simulators_gauss.npz'), **simg)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     for f in ('algebra.npz', 'master_run.npz', 'simulators.npz', 'damp_sweep.npz'):

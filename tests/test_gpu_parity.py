@@ -654,14 +654,15 @@ def test_fit_main_and_kl_on_gpu(tmp_path, monkeypatch):
     assert fit.kl_mvn(res['m_s_ep'][-1], res['S_s_ep'][-1], res['m_s_ep'][0], res['S_s_ep'][0]) > 1.0
 
 
-def test_ep_posterior_matches_cpu_path_within_monte_carlo_error():
+@pytest.mark.parametrize('name', ['m4b', 'm4a', 'm1a'])
+def test_ep_posterior_matches_cpu_path_within_monte_carlo_error(name):
     """north_star's end-to-end bar: the EP posterior mean/covariance from the device path equals
     the CPU (oracle) path's on the same inputs up to Monte-Carlo error.  The tolerance is stated
     relative to the run-to-run spread of the CPU path itself (two seeds): 3x that spread, with
     floors of 0.15 posterior sd for means and 25 % for variances (S = 800 draws per site update,
     8 damped iterations; SURVEY.md 8c: tighter claims are not meaningful)."""
     from oracle.engine_oracle import OracleEngine
-    mod = models.m4b(4, 4, 50)
+    mod = models.MODELS[name](4, 4, 50)         # m4b: the paper's model; m*a: Gaussian-likelihood family
     data = mod.simulate_data(Sigma_x='rand', rng=100)
     _, _, Q0, r0 = mod.get_prior()
 

@@ -422,3 +422,45 @@ def test_master_hands_the_schedule_of_the_next_launch_to_the_engine():
     n0 = len(calls)
     assert M2.run(1, verbose=False, seed=5)[0] == 0
     assert len(calls) == n0
+
+
+# ---------------------------------------------------------------- Gaussian-likelihood family
+@pytest.mark.parametrize('name,tag,J,D,n,Sx', [('m1a', 'm1a_s', 5, 4, 20, 'rand'), ('m4a', 'm4a_s', 5, 4, 20, 'rand'),
+                                              ('m1a', 'm1a_i', 3, 1, 10, None), ('m4a', 'm4a_i', 3, 6, 15, None)])
+def test_gaussian_family_simulators_match_the_reference(golden_dir, name, tag, J, D, n, Sx):
+    """models.m1a / m4a against vectors of the imported reference (models/m1a.py, m4a.py;
+    tests/golden/make_golden.py g11): data, true parameters, input scale, prior."""
+    g = np.load(os.path.join(golden_dir, 'simulators_gauss.npz'))
+    mod = models.MODELS[name](J, D, n)
+    data = mod.simulate_data(Sigma_x=Sx, rng=100)
+    assert mod.dphi == int(g['g11_%s_dphi' % tag]) and mod.site_model == name + '_sg'
+    np.testing.assert_allclose(data.X, g['g11_%s_X' % tag], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(data.y, g['g11_%s_y' % tag], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(data.phi_true, g['g11_%s_phi_true' % tag], rtol=1e-14)
+    np.testing.assert_allclose(data.X_param['sigma_x'], g['g11_%s_sigma_x' % tag], rtol=1e-13)
+    _, _, Q0, r0 = mod.get_prior()
+    np.testing.assert_allclose(np.diag(Q0), g['g11_%s_Q0diag' % tag])
+    np.testing.assert_allclose(r0, g['g11_%s_r0' % tag])
+    assert Q0.flags['F_CONTIGUOUS']
+
+
+def test_master_runs_a_gaussian_family_model_on_the_oracle_engine():
+    """EP with the m1a site model end to end (host logic + oracle sampler): the real-valued
+    responses reach the engine unchanged and the posterior of beta moves to the simulated truth."""
+    mod = models.MODELS['m1a'](4, 2, 30)
+    data = mod.simulate_data(rng=11)
+    _, _, Q0, r0 = mod.get_prior()
+    seen = {}
+
+    def spying(model, X, y, k_lim, **groups):
+        seen['model'], seen['dtype'] = model, np.asarray(y).dtype
+        return OracleEngine(model, X, y, k_lim, **groups)
+
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+               chains=2, iter=120, _engine_factory=spying)
+    info, (m_s, S_s) = M.run(3, verbose=False, seed=2)
+    assert info == 0 and seen['model'] == 'm1a_sg' and seen['dtype'] == np.float64
+    m, S = m_s[-1], S_s[-1]
+    assert m.shape == (4,) and np.all(np.linalg.eigvalsh(S) > 0)
+    # beta (elements 2, 3) within a few posterior standard deviations of the truth
+    assert np.all(np.abs(m[2:] - data.phi_true[2:]) < 5 * np.sqrt(np.diag(S)[2:]) + 0.2)
