@@ -238,6 +238,117 @@ class m4b(object):
         return S0, m0, Q0, r0
 
 
+def _bernoulli(rng, f):
+    return (rng.rand(f.shape[0]) < 1/(1 + np.exp(-f))).astype(int)
+
+
+def _regulate_rows(rng, beta_j, redraw):
+    """Keep |sum(beta_j)| away from zero, group by group (e.g. m4b.py:150-158)."""
+    for j in range(beta_j.shape[0]):
+        beta_sum = np.sum(beta_j[j])
+        while np.abs(beta_sum) < B_ABS_MIN_SUM:
+            index = rng.randint(beta_j.shape[1])
+            beta_sum -= beta_j[j, index]
+            beta_j[j, index] = redraw(index)
+            beta_sum += beta_j[j, index]
+
+
+class _LogisticBase(object):
+    """Shared skeleton of the remaining logistic simulators: the model-specific part draws the
+    parameters (in the reference's order of random draws) and returns (alpha_j, beta or beta_j,
+    phi_true)."""
+
+    def __init__(self, J, D, npg):
+        self.J, self.D, self.npg = J, D, npg
+        self.dphi = self._dphi(D)
+
+    def simulate_data(self, Sigma_x=None, rng=None):
+        J, D = self.J, self.D
+        if not isinstance(rng, np.random.RandomState):
+            rng = np.random.RandomState(rng)
+        seed_input_cov = rng.randint(2**31 - 1)
+        if isinstance(Sigma_x, str) and Sigma_x == 'rand':
+            Sigma_x = rand_corr_vine(D, seed=seed_input_cov)
+        Nj, j_lim = _sizes(rng, J, self.npg)
+        alpha_j, beta, phi_true = self._draw_parameters(rng)
+        mu_x_j, sigma_x_j = calc_input_param_classification(alpha_j, beta, Sigma_x)
+        X = _draw_X(rng, Nj, j_lim, D, mu_x_j, sigma_x_j, Sigma_x)
+        j_ind = np.repeat(np.arange(J), Nj)
+        f = alpha_j[j_ind] + (X.dot(beta) if beta.ndim == 1 else np.einsum('nd,nd->n', X, beta[j_ind]))
+        return Data(X, _bernoulli(rng, f), Nj, j_lim, phi_true,
+                    {'mu_x': mu_x_j, 'sigma_x': sigma_x_j, 'Sigma_x': Sigma_x})
+
+    def get_prior(self):
+        v = self._prior_var()
+        m0 = np.zeros(self.dphi)
+        return np.diag(v).T, m0, np.diag(1/v).T, m0/v
+
+
+class m2b(_LogisticBase):
+    """alpha_j ~ N(0, sigma_a), beta ~ N(0, sigma_b) shared by the groups, phi = [log sigma_a, log sigma_b]
+    (models/m2b.py; density m2b_sg.stan)."""
+    SIGMA_A, SIGMA_B = 1, 1                            # m2b.py:38-42
+    site_model = 'm2b_sg'
+
+    def _dphi(self, D):
+        return 2
+
+    def _prior_var(self):
+        return np.array([1.5**2, 1.5**2])             # m2b.py:46-50
+
+    def _draw_parameters(self, rng):
+        sigma_a, sigma_b = self.SIGMA_A, self.SIGMA_B
+        alpha_j = rng.randn(self.J)*sigma_a
+        beta = rng.randn(self.D)*sigma_b
+        _regulate_rows(rng, beta[None, :], lambda index: rng.randn()*sigma_b)
+        return alpha_j, beta, np.append(np.log(sigma_a), np.log(sigma_b))
+
+
+class m3b(_LogisticBase):
+    """alpha_j ~ N(0, sigma_a), beta_jd ~ N(0, sigma_b_d), phi = [log sigma_a, log sigma_b]
+    (models/m3b.py; density m3b_sg.stan)."""
+    SIGMA_A, SIGMA_BH = 1, 1                           # m3b.py:39-42
+    site_model = 'm3b_sg'
+
+    def _dphi(self, D):
+        return D + 1
+
+    def _prior_var(self):
+        return np.full(self.dphi, 1.5**2)              # m3b.py:45-50
+
+    def _draw_parameters(self, rng):
+        sigma_a = self.SIGMA_A
+        sigma_b = np.exp(rng.randn(self.D)*self.SIGMA_BH)
+        alpha_j = rng.randn(self.J)*sigma_a
+        beta_j = rng.randn(self.J, self.D)*sigma_b
+        _regulate_rows(rng, beta_j, lambda index: rng.randn()*sigma_b[index])
+        return alpha_j, beta_j, np.append(np.log(sigma_a), np.log(sigma_b))
+
+
+class m5b(_LogisticBase):
+    """m4b with Laplace group effects and half-Cauchy scales, phi = [mu_a, log sigma_a, mu_b, log sigma_b]
+    (models/m5b.py; density m5b_sg.stan)."""
+    MU_A, SIGMA_A, SIGMA_MB, SIGMA_SB = 0.1, 1, 0, 1   # m5b.py:43-50
+    site_model = 'm5b_sg'
+
+    def _dphi(self, D):
+        return 2*D + 2
+
+    def _prior_var(self):
+        return np.full(self.dphi, 1.5**2)              # m5b.py:53-64
+
+    def _draw_parameters(self, rng):
+        J, D = self.J, self.D
+        sigma_a, mu_a = self.SIGMA_A, self.MU_A
+        sigma_b = np.abs(rng.standard_cauchy(D)*self.SIGMA_SB)
+        mu_b = rng.laplace(size=D)*self.SIGMA_MB
+        alpha_j = mu_a + rng.laplace(size=J)*sigma_a
+        beta_j = mu_b + rng.laplace(size=(J, D))*sigma_b
+        _regulate_rows(rng, beta_j, lambda index: mu_b[index] + rng.randn()*sigma_b[index])
+        phi_true = np.concatenate(([mu_a, np.log(sigma_a)], mu_b, np.log(sigma_b)))
+        return alpha_j, beta_j, phi_true
+
+
 class m1a(object):
     """y ~ N(alpha_j + x beta, sigma), alpha_j ~ N(0, sigma_a), phi = [log sigma, log sigma_a, beta]
     (models/m1a.py; site density models/m1a_sg.stan)."""
@@ -328,7 +439,7 @@ class m4a(object):
         return np.diag(v).T, m0, np.diag(1/v).T, m0/v
 
 
-MODELS = {'m1b': m1b, 'm4b': m4b, 'm1a': m1a, 'm4a': m4a}
+MODELS = {'m1b': m1b, 'm2b': m2b, 'm3b': m3b, 'm4b': m4b, 'm5b': m5b, 'm1a': m1a, 'm4a': m4a}
 
 
 def default_df0(K):

@@ -404,18 +404,32 @@ def g11_gauss_simulators(out):
         out['g11_%s_Q0diag' % tag] = np.diag(Q0).copy()
         out['g11_%s_r0' % tag] = r0
         out['g11_%s_dphi' % tag] = np.array(mod.dphi)
+    # the remaining logistic simulators models/m2b.py, m3b.py, m5b.py
+    from models import m2b, m3b, m5b
+    for tag, mod_ref, J, D, n, Sx in (('m2b_s', m2b, 5, 4, 20, 'rand'), ('m3b_s', m3b, 5, 4, 20, 'rand'),
+                                      ('m5b_s', m5b, 5, 4, 20, 'rand'), ('m3b_r', m3b, 6, 5, (10, 30), None),
+                                      ('m5b_r', m5b, 6, 5, (10, 30), None)):
+        mod = mod_ref.model(J, D, n)
+        data = mod.simulate_data(Sigma_x=Sx, rng=100)
+        S0, m0, Q0, r0 = mod.get_prior()
+        out['g12_%s_X' % tag] = data.X
+        out['g12_%s_y' % tag] = data.y
+        out['g12_%s_Nj' % tag] = data.Nj
+        out['g12_%s_phi_true' % tag] = data.true_values['phi']
+        out['g12_%s_Q0diag' % tag] = np.diag(Q0).copy()
+        out['g12_%s_r0' % tag] = r0
 
 
 def main():
     util, method, tmp = import_reference()
     from models import m1b, m4b
     models = {'m1b': m1b, 'm4b': m4b}
-    if '--only-gauss' in sys.argv:
+    if '--only-extra' in sys.argv or '--only-gauss' in sys.argv:
         try:
             sim = {}
             g11_gauss_simulators(sim)
-            np.savez_compressed(os.path.join(HERE, 'simulators_gauss.npz'), **sim)
-            print('simulators_gauss.npz', os.path.getsize(os.path.join(HERE, 'simulators_gauss.npz')), 'bytes')
+            np.savez_compressed(os.path.join(HERE, 'simulators_extra.npz'), **sim)
+            print('simulators_extra.npz', os.path.getsize(os.path.join(HERE, 'simulators_extra.npz')), 'bytes')
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
         return
@@ -440,7 +454,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'simulators.npz'), **sim)
         simg = {}
         g11_gauss_simulators(simg)
-        np.savez_compressed(os.path.join(HERE, 'simulators_gauss.npz'), **simg)
+        np.savez_compressed(os.path.join(HERE, 'simulators_extra.npz'), **simg)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     for f in ('algebra.npz', 'master_run.npz', 'simulators.npz', 'damp_sweep.npz'):

@@ -430,7 +430,7 @@ def test_master_hands_the_schedule_of_the_next_launch_to_the_engine():
 def test_gaussian_family_simulators_match_the_reference(golden_dir, name, tag, J, D, n, Sx):
     """models.m1a / m4a against vectors of the imported reference (models/m1a.py, m4a.py;
     tests/golden/make_golden.py g11): data, true parameters, input scale, prior."""
-    g = np.load(os.path.join(golden_dir, 'simulators_gauss.npz'))
+    g = np.load(os.path.join(golden_dir, 'simulators_extra.npz'))
     mod = models.MODELS[name](J, D, n)
     data = mod.simulate_data(Sigma_x=Sx, rng=100)
     assert mod.dphi == int(g['g11_%s_dphi' % tag]) and mod.site_model == name + '_sg'
@@ -442,6 +442,24 @@ def test_gaussian_family_simulators_match_the_reference(golden_dir, name, tag, J
     np.testing.assert_allclose(np.diag(Q0), g['g11_%s_Q0diag' % tag])
     np.testing.assert_allclose(r0, g['g11_%s_r0' % tag])
     assert Q0.flags['F_CONTIGUOUS']
+
+
+@pytest.mark.parametrize('name,tag,J,D,n,Sx', [('m2b', 'm2b_s', 5, 4, 20, 'rand'), ('m3b', 'm3b_s', 5, 4, 20, 'rand'),
+                                              ('m5b', 'm5b_s', 5, 4, 20, 'rand'), ('m3b', 'm3b_r', 6, 5, (10, 30), None),
+                                              ('m5b', 'm5b_r', 6, 5, (10, 30), None)])
+def test_remaining_logistic_simulators_match_the_reference(golden_dir, name, tag, J, D, n, Sx):
+    """models.m2b / m3b / m5b against vectors of the imported reference (make_golden.py g12)."""
+    g = np.load(os.path.join(golden_dir, 'simulators_extra.npz'))
+    mod = models.MODELS[name](J, D, n)
+    data = mod.simulate_data(Sigma_x=Sx, rng=100)
+    np.testing.assert_array_equal(data.Nj, g['g12_%s_Nj' % tag])
+    np.testing.assert_allclose(data.X, g['g12_%s_X' % tag], rtol=1e-13, atol=1e-13)
+    np.testing.assert_array_equal(data.y, g['g12_%s_y' % tag])
+    np.testing.assert_allclose(data.phi_true, g['g12_%s_phi_true' % tag], rtol=1e-14)
+    _, _, Q0, r0 = mod.get_prior()
+    np.testing.assert_allclose(np.diag(Q0), g['g12_%s_Q0diag' % tag])
+    np.testing.assert_allclose(r0, g['g12_%s_r0' % tag])
+    assert mod.site_model == name + '_sg' and Q0.shape == (mod.dphi, mod.dphi)
 
 
 def test_master_runs_a_gaussian_family_model_on_the_oracle_engine():
