@@ -439,7 +439,95 @@ class m4a(object):
         return np.diag(v).T, m0, np.diag(1/v).T, m0/v
 
 
-MODELS = {'m1b': m1b, 'm2b': m2b, 'm3b': m3b, 'm4b': m4b, 'm5b': m5b, 'm1a': m1a, 'm4a': m4a}
+class _GaussBase(object):
+    """Shared skeleton of the remaining linear-regression simulators (noise sigma = 1, all prior
+    variances 1.5^2, zero prior means): the model-specific part draws the parameters in the
+    reference's order of random draws and returns (alpha_j, beta or beta_j, phi_true[1:])."""
+    SIGMA = 1
+
+    def __init__(self, J, D, npg):
+        self.J, self.D, self.npg = J, D, npg
+        self.dphi = self._dphi(D)
+
+    def simulate_data(self, Sigma_x=None, rng=None):
+        J, D = self.J, self.D
+        if not isinstance(rng, np.random.RandomState):
+            rng = np.random.RandomState(rng)
+        seed_input_cov = rng.randint(2**31 - 1)
+        if isinstance(Sigma_x, str) and Sigma_x == 'rand':
+            Sigma_x = rand_corr_vine(D, seed=seed_input_cov)
+        Nj, j_lim = _sizes(rng, J, self.npg)
+        N = int(np.sum(Nj))
+        sigma = self.SIGMA
+        alpha_j, beta, phi_rest = self._draw_parameters(rng)
+        sigma_x = calc_input_param_lin_reg(beta, sigma, Sigma_x)
+        j_ind = np.repeat(np.arange(J), Nj)
+        if beta.ndim == 1:                      # one coefficient vector: one input scale, one draw of X
+            X = rng.randn(N, D)*sigma_x if Sigma_x is None else rng.randn(N, D).dot(sigma_x*cholesky(Sigma_x))
+            y = alpha_j[j_ind] + X.dot(beta)
+        else:
+            X = _draw_X(rng, Nj, j_lim, D, np.zeros(J), sigma_x, Sigma_x)
+            y = alpha_j[j_ind] + np.einsum('nd,nd->n', X, beta[j_ind])
+        y = y + rng.randn(N)*sigma
+        return Data(X, y, Nj, j_lim, np.append(np.log(sigma), phi_rest), {'sigma_x': sigma_x, 'Sigma_x': Sigma_x})
+
+    def get_prior(self):
+        v = np.full(self.dphi, 1.5**2)
+        m0 = np.zeros(self.dphi)
+        return np.diag(v).T, m0, np.diag(1/v).T, m0/v
+
+
+class m2a(_GaussBase):
+    """phi = [log sigma, log sigma_a, log sigma_b], beta ~ N(0, sigma_b) shared (models/m2a.py; density
+    m2a_sg.stan).  The reference's simulator names its generator `rnd_data` but receives it as
+    `rng` (m2a.py:91-174) and raises NameError; this is the evident intent."""
+    site_model = 'm2a_sg'
+
+    def _dphi(self, D):
+        return 3
+
+    def _draw_parameters(self, rng):
+        alpha_j = rng.randn(self.J)
+        beta = rng.randn(self.D)
+        _regulate_rows(rng, beta[None, :], lambda index: rng.randn())
+        return alpha_j, beta, np.zeros(2)
+
+
+class m3a(_GaussBase):
+    """phi = [log sigma, log sigma_a, log sigma_b(D)] (models/m3a.py; density m3a_sg.stan)."""
+    site_model = 'm3a_sg'
+
+    def _dphi(self, D):
+        return D + 2
+
+    def _draw_parameters(self, rng):
+        sigma_b = np.exp(rng.randn(self.D))
+        alpha_j = rng.randn(self.J)
+        beta_j = rng.randn(self.J, self.D)*sigma_b
+        _regulate_rows(rng, beta_j, lambda index: rng.randn()*sigma_b[index])
+        return alpha_j, beta_j, np.append(0.0, np.log(sigma_b))
+
+
+class m5a(_GaussBase):
+    """m4a with Laplace group effects and half-Cauchy scales (models/m5a.py; density m5a_sg.stan)."""
+    MU_A, SIGMA_A, SIGMA_MB, SIGMA_SB = 0.1, 1, 0, 1   # m5a.py:49-55
+    site_model = 'm5a_sg'
+
+    def _dphi(self, D):
+        return 2*D + 3
+
+    def _draw_parameters(self, rng):
+        J, D = self.J, self.D
+        sigma_b = np.abs(rng.standard_cauchy(D)*self.SIGMA_SB)
+        mu_b = rng.laplace(size=D)*self.SIGMA_MB
+        alpha_j = self.MU_A + rng.laplace(size=J)*self.SIGMA_A
+        beta_j = mu_b + rng.laplace(size=(J, D))*sigma_b
+        _regulate_rows(rng, beta_j, lambda index: mu_b[index] + rng.randn()*sigma_b[index])
+        return alpha_j, beta_j, np.concatenate(([self.MU_A, np.log(self.SIGMA_A)], mu_b, np.log(sigma_b)))
+
+
+MODELS = {'m1b': m1b, 'm2b': m2b, 'm3b': m3b, 'm4b': m4b, 'm5b': m5b,
+          'm1a': m1a, 'm2a': m2a, 'm3a': m3a, 'm4a': m4a, 'm5a': m5a}
 
 
 def default_df0(K):

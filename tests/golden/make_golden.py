@@ -392,8 +392,10 @@ def g10_distribute_groups(util, out):
 def g11_gauss_simulators(out):
     """Gaussian-likelihood simulators models/m1a.py, m4a.py (real responses; `rng=100` as fit.py:157)."""
     from models import m1a, m4a
+    from models import m3a, m5a      # (m2a.py's simulator raises NameError in the reference: `rnd_data`)
     for tag, mod_ref, J, D, n, Sx in (('m1a_s', m1a, 5, 4, 20, 'rand'), ('m4a_s', m4a, 5, 4, 20, 'rand'),
-                                      ('m1a_i', m1a, 3, 1, 10, None), ('m4a_i', m4a, 3, 6, 15, None)):
+                                      ('m1a_i', m1a, 3, 1, 10, None), ('m4a_i', m4a, 3, 6, 15, None),
+                                      ('m3a_s', m3a, 5, 4, 20, 'rand'), ('m5a_s', m5a, 6, 5, (10, 30), None)):
         mod = mod_ref.model(J, D, n)
         data = mod.simulate_data(Sigma_x=Sx, rng=100)
         S0, m0, Q0, r0 = mod.get_prior()

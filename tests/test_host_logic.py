@@ -426,7 +426,8 @@ def test_master_hands_the_schedule_of_the_next_launch_to_the_engine():
 
 # ---------------------------------------------------------------- Gaussian-likelihood family
 @pytest.mark.parametrize('name,tag,J,D,n,Sx', [('m1a', 'm1a_s', 5, 4, 20, 'rand'), ('m4a', 'm4a_s', 5, 4, 20, 'rand'),
-                                              ('m1a', 'm1a_i', 3, 1, 10, None), ('m4a', 'm4a_i', 3, 6, 15, None)])
+                                              ('m1a', 'm1a_i', 3, 1, 10, None), ('m4a', 'm4a_i', 3, 6, 15, None),
+                                              ('m3a', 'm3a_s', 5, 4, 20, 'rand'), ('m5a', 'm5a_s', 6, 5, (10, 30), None)])
 def test_gaussian_family_simulators_match_the_reference(golden_dir, name, tag, J, D, n, Sx):
     """models.m1a / m4a against vectors of the imported reference (models/m1a.py, m4a.py;
     tests/golden/make_golden.py g11): data, true parameters, input scale, prior."""
@@ -460,6 +461,16 @@ def test_remaining_logistic_simulators_match_the_reference(golden_dir, name, tag
     np.testing.assert_allclose(np.diag(Q0), g['g12_%s_Q0diag' % tag])
     np.testing.assert_allclose(r0, g['g12_%s_r0' % tag])
     assert mod.site_model == name + '_sg' and Q0.shape == (mod.dphi, mod.dphi)
+
+
+def test_m2a_simulator_runs_where_the_reference_raises():
+    """models/m2a.py names its generator `rnd_data` but receives `rng` (NameError): the mirror
+    follows the evident intent; shape, prior and determinism only."""
+    mod = models.MODELS['m2a'](5, 4, 20)
+    a, b = mod.simulate_data(rng=100), mod.simulate_data(rng=100)
+    np.testing.assert_array_equal(a.y, b.y)
+    assert a.X.shape == (100, 4) and a.y.dtype == np.float64 and mod.dphi == 3
+    np.testing.assert_allclose(np.diag(mod.get_prior()[2]), 1 / 1.5**2)
 
 
 def test_master_runs_a_gaussian_family_model_on_the_oracle_engine():
