@@ -13,8 +13,9 @@ from oracle import nuts_oracle as no
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(os.environ.get('STRESS_SEED', '0')))
 MODELS = ['m1b', 'm2b', 'm3b', 'm4b', 'm5b']
+GAUSS = ['m1a', 'm2a', 'm3a', 'm4a', 'm5a']         # Gaussian-likelihood family: LDS-resident layouts 1 and 2 only
 t0 = time.time()
-nspec = nlay = ngrp = nsplit = 0
+nspec = nlay = ngrp = nsplit = ngauss = 0
 
 
 def cavities(eng, rng, tight):
@@ -27,13 +28,16 @@ def cavities(eng, rng, tight):
 
 
 while time.time() - t0 < budget:
-    model = MODELS[rng.randint(5)]
+    gauss = rng.rand() < 0.3
+    model = (GAUSS if gauss else MODELS)[rng.randint(5)]
     D = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 21, 32]))
     K = int(rng.randint(1, 5))
     sizes = rng.randint(1, 260, size=K)
     N = int(sizes.sum())
     X = rng.randn(N, D) * rng.choice([0.3, 1.0, 2.0])
     y = (rng.rand(N) < rng.uniform(0.2, 0.8)).astype(int)
+    if gauss:
+        y = rng.randn(N) * rng.choice([0.3, 1.0, 3.0]) + X.dot(rng.randn(D)) * 0.5
     k_lim = np.concatenate(([0], np.cumsum(sizes)))
     chains = int(rng.choice([1, 2, 3, 4, 5]))
     it = int(rng.choice([6, 20, 41]))
@@ -44,6 +48,30 @@ while time.time() - t0 < budget:
     eng = HipEngine(model + '_sg', X, y, k_lim)
     cavities(eng, rng, tight)
     P = eng.P
+    if gauss:
+        # everything-in-LDS kernels only: the sequential 4-wave form and layouts 3 / 4 do not exist for
+        # this family; compare layouts 1 and 2 with each other and the gradient with the oracle
+        from epstan_amd._lib import EpxError
+        try:
+            o = HipEngine.sampler_opts(chains=chains, iter=6, init='random', max_depth=depth, layout=1)
+            eng.sample_batch(seeds, o)
+            d1 = np.stack([eng.get_draws(k, True) for k in range(K)])
+            o = HipEngine.sampler_opts(chains=chains, iter=6, init='random', max_depth=depth, layout=2)
+            eng.sample_batch(seeds, o)
+            d2 = np.stack([eng.get_draws(k, True) for k in range(K)])
+        except EpxError as ex:
+            assert 'not supported' in str(ex), ex
+            continue
+        err = np.abs(d1 - d2).reshape(K, chains, -1, P)[:, :, :1].max() / max(1.0, np.abs(d1).max())
+        assert err < 1e-5, ('gauss layouts', model, D, sizes, chains, depth, tight, err)
+        for k in range(K):
+            th = rng.randn(P) * 0.3
+            Om, mu = eng.get_cavity(k)
+            lpo, go = no.logdensity_grad(model + '_sg', X[k_lim[k]:k_lim[k + 1]], y[k_lim[k]:k_lim[k + 1]], mu, Om, th)
+            lp, g = eng.logdensity_grad(k, th, layout=int(rng.choice([1, 2])))
+            assert abs(lp - lpo) <= 1e-9 * max(1.0, abs(lpo)) and np.allclose(g, go, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go).max())), ('gauss grad', model, D, sizes)
+        ngauss += 1
+        continue
     # ---- bookkeeping wave vs sequential kernel
     out = []
     for flags in (1, 0):
@@ -121,5 +149,5 @@ while time.time() - t0 < budget:
         assert np.array_equal(dr[order[:m]], ref[2][order[:m]], equal_nan=True), ('split lead', ms, Ds, ns, Ks, m)
         assert np.array_equal(dr[order[m:]], ref[1][order[m:]], equal_nan=True), ('split rest', ms, Ds, ns, Ks, m)
         nsplit += 1
-print('stress ok: %d spec comparisons, %d layout comparisons, %d multi-group gradient sets, %d split launches in %.0f s'
-      % (nspec, nlay, ngrp, nsplit, time.time() - t0))
+print('stress ok: %d spec comparisons, %d layout comparisons, %d multi-group gradient sets, %d split launches, '
+      '%d Gaussian-family problems in %.0f s' % (nspec, nlay, ngrp, nsplit, ngauss, time.time() - t0))
