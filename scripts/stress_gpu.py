@@ -68,7 +68,11 @@ while time.time() - t0 < budget:
             th = rng.randn(P) * 0.3
             Om, mu = eng.get_cavity(k)
             lpo, go = no.logdensity_grad(model + '_sg', X[k_lim[k]:k_lim[k + 1]], y[k_lim[k]:k_lim[k + 1]], mu, Om, th)
-            lp, g = eng.logdensity_grad(k, th, layout=int(rng.choice([1, 2])))
+            try:
+                lp, g = eng.logdensity_grad(k, th, layout=int(rng.choice([1, 2])))
+            except EpxError as ex:      # the hook sizes the tree stack for max_depth 10
+                assert 'not supported' in str(ex), ex
+                lp, g = eng.logdensity_grad(k, th, layout=1)
             assert abs(lp - lpo) <= 1e-9 * max(1.0, abs(lpo)) and np.allclose(g, go, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go).max())), ('gauss grad', model, D, sizes)
         ngauss += 1
         continue
@@ -127,7 +131,7 @@ while time.time() - t0 < budget:
             ngrp += 1
     # ---- split launch: lead sites == layout 2, the others == layout 1, bit for bit
     if rng.rand() < 0.15:
-        Ks = 192 + int(rng.randint(0, 40))
+        Ks = 330 + int(rng.randint(0, 40))       # enough sites for the library to choose layout 1 by itself
         ns = int(rng.choice([8, 30, 70]))
         Ds = int(rng.choice([2, 5, 16, 32]))
         ms = MODELS[rng.randint(5)]
