@@ -542,6 +542,22 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // for single-group sites layout 1 is still faster at the C3 site size (132 vs 157 ms per
     // launch), so it is chosen on request only
     bool lock = false;
+    // several groups per site with few sites: one workgroup per chain, the four gradient waves share the
+    // site's groups (nuts_gradient_groups.inc); needs rows, Omega, tree stack and mailbox in LDS
+    bool grp = false;
+    if (c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
+        (layout == 2 || (layout == 0 && (long)count * o.chains <= 4L * c->n_cu))) {
+        a.grp = 1; a.cpb = 1;
+        const size_t lds = nuts_lds_layout(a, 4, dp, c->n_max);
+        if (lds <= LDS_CAP && a.om_in_lds && a.stack_in_lds && a.off_spec > 0) grp = true;
+        else a.grp = 0;
+    }
+    if (grp) {
+        *wpc_out = 4; *dp_out = dp; *nv_out = nv; *layout_out = 2;
+        a.no_spec = 0;
+        return 0;
+    }
+    if (layout == 2 && c->multi) layout = 0;
     if ((layout == 4 || (layout == 0 && c->multi)) && c->D <= 32 && nv <= 7) {
         const int dpl = c->D <= 16 ? 16 : 32;
         size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max);
@@ -883,6 +899,7 @@ int epx_logdensity_grad_layout(epx_ctx *c, int k, const double *theta, int layou
     a.dbg = c->dbg;
     int rc = launch_sampler(a, 1, wpc, dp, nv, layout, c->stream);
     if (rc != 0) return fail("NUTS kernel launch failed (%d)", rc);
+    c->last_layout = layout;
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<double> outv(P + 1);
     HIPCHK(hipMemcpy(outv.data(), c->dbg, (P + 1) * 8, hipMemcpyDeviceToHost));

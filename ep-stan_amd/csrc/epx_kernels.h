@@ -138,6 +138,8 @@ struct NutsArgs {
     int om_in_lds;
     int off_spec;                 // > 0: LDS offset of the speculative kernel's mailbox / control records (layout 2)
     int no_spec;                  // 1: keep the bookkeeping on the gradient waves (k_nuts) even when off_spec > 0
+    int grp;                      // 1: sites with several groups on layout 2 (k_nuts_spec<..., GRP>, nuts_gradient_groups.inc)
+    int off_gl;                   // LDS offset of the site's group row limits (grp)
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int

@@ -325,7 +325,7 @@ k_nuts(NutsArgs a) {
 //                    post record s
 enum { SPEC_NONE = 0, SPEC_RESTART = 1, SPEC_EXIT = 2 };
 
-template <int NV, int DP, bool RES, bool GAUSS>
+template <int NV, int DP, bool RES, bool GAUSS, bool GRP>
 __global__ void __launch_bounds__(320)
 k_nuts_spec(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -347,9 +347,20 @@ k_nuts_spec(NutsArgs a) {
     const int sb = a.order ? a.order[blockIdx.x / a.chains] : (int)(blockIdx.x / a.chains);
     const int chain = blockIdx.x % a.chains;
     const int k = a.k0 + sb;
-    const int D = a.D, d = a.d, P = a.P, model = a.model;
+    const int D = a.D, d = a.d, model = a.model;
     const int64_t row0 = a.k_lim[k];
     const int n = (int)(a.k_lim[k + 1] - row0);
+    // several groups per site (GRP): theta = [phi | eta (ng) | etb (ng x D)]; records stay a.P wide
+    constexpr int GREC = 66, WREC = 64 * NV + 2;        // per-group / per-wave exchange records (nuts_gradient_groups.inc)
+    int ng = 1;
+    int *gl_s = reinterpret_cast<int *>(smem + a.off_gl);
+    if constexpr (GRP) {
+        const int g0 = a.site_g0[k];
+        ng = a.site_g0[k + 1] - g0;
+        for (int g = tid; g <= ng; g += blockDim.x) gl_s[g] = (int)(a.g_lim[g0 + g] - row0);
+    }
+    const int P = GRP ? d + ng * (model == 0 ? 1 : 1 + D) : a.P;
+    (void)gl_s; (void)GREC; (void)WREC;
 
     double *Xs = reinterpret_cast<double *>(smem);
     uint8_t *ys = smem + a.off_y;                                   // 0/1 responses (logistic family) ...
@@ -424,10 +435,15 @@ k_nuts_spec(NutsArgs a) {
             double c_stamp = -9.0, c_cmd = 0.0, lp_lane = 0.0, ll_u = 0.0;
 #define EPX_AFTER_EXCHANGE_BARRIER do { c_stamp = c[4 * NV * 64 + 2]; c_cmd = c[4 * NV * 64 + 1]; } while (0)
 #define EPX_DEFER_ENERGY 1
+            if constexpr (GRP) {
+#include "nuts_gradient_groups.inc"
+                (void)kin;
+            } else {
 #include "nuts_gradient.inc"
+                (void)kin;
+            }
 #undef EPX_DEFER_ENERGY
 #undef EPX_AFTER_EXCHANGE_BARRIER
-            (void)kin;
             STAMP(5);
 #ifdef EPX_STAMPS
             ++nticks;
@@ -475,7 +491,7 @@ k_nuts_spec(NutsArgs a) {
         mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
     }
     {
-        const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        const double *lastp = a.last + ((size_t)k * a.chains + chain) * a.P;
         FORV {
             const int e = lane + 64 * i;
             double q0 = 0.0;
@@ -513,7 +529,7 @@ k_nuts_spec(NutsArgs a) {
     if (teacher) {
         eps = a.eps_in[(size_t)sb * a.chains + chain];
         if (a.inv_e_in) {
-            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * P;
+            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * a.P;
             FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
@@ -593,11 +609,11 @@ k_nuts_spec(NutsArgs a) {
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = bk_busy;
 #endif
     {
-        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        double *lastp = a.last + ((size_t)k * a.chains + chain) * a.P;
         FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
         if (failed) {
             for (int kk = 0; kk < a.nkeep; ++kk) {
-                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * P;
+                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * a.P;
                 FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
             }
         }
@@ -623,7 +639,14 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     a.n_max = n_max;
     a.off_y = (int)off; off += (((size_t)n_max * (a.gauss ? 8 : 1)) + 15) & ~(size_t)15;
     a.off_xch = (int)off;
-    if (wpc > 1) off += (size_t)2 * wpc * (64 * (1 + nv) + 2) * 8;
+    a.off_gl = 0;
+    if (a.grp) {
+        // several groups per site: per-wave (Omega partials, ll) and per-group (dbeta, dalpha) records, both parities,
+        // then the group row limits
+        off += (size_t)2 * (wpc * (64 * nv + 2) + (size_t)a.ngmax * 66) * 8;
+        a.off_gl = (int)off;
+        off += ((size_t)(a.ngmax + 1) * 4 + 15) & ~(size_t)15;
+    } else if (wpc > 1) off += (size_t)2 * wpc * (64 * (1 + nv) + 2) * 8;
     off = (off + 15) & ~(size_t)15;
     const size_t cap = 160 * 1024;
     const size_t om = (size_t)a.d * a.d * 8;
@@ -647,9 +670,9 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     return off;
 }
 
-template <int NV, int DP, bool RES, bool GAUSS = false>
+template <int NV, int DP, bool RES, bool GAUSS = false, bool GRP = false>
 static int launch_spec(const NutsArgs &a, int nblocks, hipStream_t stream) {
-    auto kern = k_nuts_spec<NV, DP, RES, GAUSS>;
+    auto kern = k_nuts_spec<NV, DP, RES, GAUSS, GRP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
     if (e != hipSuccess) return (int)e;
@@ -671,6 +694,12 @@ static int launch_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 template <int NV, int DP>
 static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t stream) {
     // (Omega in LDS, stack in LDS): layout 2 has both or neither; layout 1 may have Omega only
+    if (a.grp) {
+        // several groups per site: the everything-resident bookkeeping-wave kernel only (the host checks)
+        if (wpc == 4 && a.off_spec > 0 && a.om_in_lds && a.stack_in_lds && !a.no_spec)
+            return launch_spec<NV, DP, true, false, true>(a, nblocks, stream);
+        return -1;
+    }
     if (a.gauss) {
         // Gaussian-likelihood family: the everything-resident kernels only (the host refuses other shapes)
         if (wpc == 4 && a.off_spec > 0 && a.om_in_lds && !a.no_spec) return launch_spec<NV, DP, true, true>(a, nblocks, stream);

@@ -12,7 +12,7 @@ for J, K, D, npg in ((64, 32, 16, 20), (1024, 256, 16, 50)):
     data = mod.simulate_data(Sigma_x='rand', rng=100)
     _, _, Q0, r0 = mod.get_prior()
     Nk, Nj_k, j_ind_k = distribute_groups(J, K, data.Nj)
-    for layout in (3, 4):
+    for layout in (2, 3, 4):
         M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
                    prior={'Q': Q0, 'r': r0}, chains=4, iter=100, layout=layout)
         opts = HipEngine.sampler_opts(chains=4, iter=100, init='random', layout=layout)
@@ -20,6 +20,8 @@ for J, K, D, npg in ((64, 32, 16, 20), (1024, 256, 16, 50)):
         for rep in range(2):
             stats, ms = M.engine.sample_batch(np.arange(K) + 1, opts)
             best = min(best, ms)
-        ticks = M.engine.row_passes(4)
-        print('J=%d K=%d D=%d npg=%d layout %d: %.1f ms, %.2f us per lock-step leapfrog (slowest site), P=%d'
-              % (J, K, D, npg, M.engine.last_layout(), best, best * 1e3 / ticks.max(), M.engine.P))
+        ll = M.engine.last_layout()
+        # layout 2: one workgroup per chain -> the slowest CHAIN sets the launch; 3 / 4: chains in lock step
+        ticks = M.engine.get_chain_stats(4)[:, :, 3].max() if ll == 2 else M.engine.row_passes(4).max()
+        print('J=%d K=%d D=%d npg=%d layout %d: %.1f ms, %.2f us per leapfrog of the slowest %s, P=%d'
+              % (J, K, D, npg, ll, best, best * 1e3 / ticks, 'chain' if ll == 2 else 'site (4 chains in lock step)', M.engine.P))

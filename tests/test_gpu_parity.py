@@ -877,23 +877,31 @@ def test_multigroup_gradient_matches_oracle(model, D, groups):
         assert eng.P >= Pk and eng.site_P[k] == Pk
         theta = np.zeros(eng.P)
         theta[:Pk] = rng.randn(Pk) * 0.3
-        lp, g = eng.logdensity_grad(k, theta)
         lo, hi = k_lim[k], k_lim[k + 1]
         gl = g_lim[off[k]:off[k + 1] + 1] - lo
         lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta[:Pk], gl=gl)
-        assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o)), (k, lp, lp_o)
-        np.testing.assert_allclose(g[:Pk], g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
-        assert np.all(g[Pk:] == 0.0)
+        # layout 2: one workgroup per chain, the gradient waves share the groups (D <= 32, P <= 128; larger
+        # sites fall through to the lock-step layouts); 3 streaming; 4 lock step with resident rows (D <= 32)
+        for layout in (2, 3, 4):
+            lp, g = eng.logdensity_grad(k, theta, layout=layout)
+            assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o)), (k, layout, lp, lp_o)
+            np.testing.assert_allclose(g[:Pk], g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+            assert np.all(g[Pk:] == 0.0)
+            if layout == 2 and D <= 32 and eng.P <= 128:
+                assert eng.last_layout() == 2
 
 
-@pytest.mark.parametrize('layout', [3, 4])
+@pytest.mark.parametrize('layout', [2, 3, 4])
 @pytest.mark.parametrize('model,D,groups,chains', [('m4b', 4, [[20, 14, 9], [25, 25]], 4), ('m1b', 16, [[30, 30], [18, 18, 18]], 3),
-                                                   ('m3b', 8, [[40], [16, 24]], 4), ('m4b', 32, [[17, 40, 5]], 4)])
+                                                   ('m3b', 8, [[40], [16, 24]], 4), ('m4b', 32, [[17, 40, 5]], 4),
+                                                   ('m4b', 6, [[9, 70, 3, 11, 20], [150]], 4), ('m2b', 16, [[64, 65], [10, 12]], 2)])
 def test_multigroup_site_updates_match_oracle(model, D, groups, chains, layout):
     """Whole short site updates of multi-group sites against the C oracle, chain by chain (same
     random stream; chains are compared until rounding differences make them part)."""
     X, y, k_lim, g_cnt, g_lim, Oms, mus, d = _group_problem(model, D, groups, 70 + D, tight=300.0)
     eng, Om_dev, mu_dev = _group_engine(model, X, y, k_lim, g_cnt, g_lim, Oms, mus)
+    if layout == 2 and eng.P > 128:
+        pytest.skip('one workgroup per chain holds at most 128 coordinates in registers')
     K = len(groups)
     seeds = np.arange(K, dtype=np.int64) + 31
     it = 44
@@ -925,7 +933,11 @@ def test_multigroup_site_updates_match_oracle(model, D, groups, chains, layout):
             assert e.cavity_site(k, Oms[k] + np.eye(d), Oms[k].dot(mus[k]), np.eye(d), np.zeros(d))
         e.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=20, init='random', layout=layout))
     for k in range(K):
-        np.testing.assert_array_equal(e1.get_draws(k, True), e2.get_draws(k, True))
+        if layout == 2:
+            # grouped kernel: a group's rows on ONE wave; `_sg` kernel: rows over four waves -> other summation order
+            np.testing.assert_allclose(e1.get_draws(k, True)[:3], e2.get_draws(k, True)[:3], rtol=1e-6, atol=1e-8)
+        else:
+            np.testing.assert_array_equal(e1.get_draws(k, True), e2.get_draws(k, True))
 
 
 def test_multigroup_ep_posterior_matches_cpu_path_within_monte_carlo_error():
@@ -948,7 +960,7 @@ def test_multigroup_ep_posterior_matches_cpu_path_within_monte_carlo_error():
 
     cpu = lambda m, X, y, kl, **g: OracleEngine(m, X, y, kl, **g)
     m_g, S_g, Mg = run(1)
-    assert Mg.engine.last_layout() == 4 and Mg.engine.P == 8 + 2 * 4
+    assert Mg.engine.last_layout() == 2 and Mg.engine.P == 8 + 2 * 4      # few sites: one workgroup per chain
     m_c1, S_c1, _ = run(1, _engine_factory=cpu)
     m_c2, S_c2, _ = run(2, _engine_factory=cpu)
     sd = np.sqrt(np.diag(S_c1))
