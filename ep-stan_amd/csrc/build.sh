@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 mkdir -p build
 pids=()
 for f in dense nuts nuts_stream epx_api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ epx_kernels.h -nt build/$f.o ] || [ epx_device.h -nt build/$f.o ] || [ nuts_state_machine.inc -nt build/$f.o ] || [ nuts_gradient.inc -nt build/$f.o ] || [ epx_stream_tile.h -nt build/$f.o ] || [ ../../include/epx.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ epx_kernels.h -nt build/$f.o ] || [ epx_device.h -nt build/$f.o ] || [ nuts_state_machine.inc -nt build/$f.o ] || [ nuts_gradient.inc -nt build/$f.o ] || [ nuts_gradient_groups.inc -nt build/$f.o ] || [ epx_stream_tile.h -nt build/$f.o ] || [ ../../include/epx.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
