@@ -124,10 +124,23 @@ while time.time() - t0 < budget:
                 Om, mu = eg.get_cavity(k)
                 gl = g_lim[off[k]:off[k + 1] + 1] - kl[k]
                 lpo, go = no.logdensity_grad(model, Xg[kl[k]:kl[k + 1]], yg[kl[k]:kl[k + 1]], mu, Om, th[:Pk], gl=gl)
-                for layout in (3, 4):
+                for layout in (2, 3, 4):           # 2: one workgroup per chain (falls through to 4 / 3 when P > 128)
                     lp, g = eg.logdensity_grad(k, th, layout=layout)
                     assert abs(lp - lpo) <= 1e-9 * max(1.0, abs(lpo)), ('mg lp', layout, model, D, groups)
                     assert np.allclose(g[:Pk], go, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go).max())), ('mg grad', layout, model, D, groups)
+            # short site updates: one workgroup per chain against lock step (m5b's kinks amplify rounding: skipped)
+            if eg.P <= 128 and model != 'm5b':
+                sdg = rng.randint(1, 2**31 - 1, size=K).astype(np.int64)
+                cavities(eg, rng, 300.0)
+                res = {}
+                for layout in (2, 4):
+                    eg.sample_batch(sdg, HipEngine.sampler_opts(chains=chains, iter=6, init='random', max_depth=5, layout=layout))
+                    assert eg.last_layout() == layout, (layout, eg.last_layout())
+                    res[layout] = np.stack([eg.get_draws(k, True) for k in range(K)])
+                first = res[2].reshape(K, chains, -1, eg.P)[:, :, 0]
+                ref4 = res[4].reshape(K, chains, -1, eg.P)[:, :, 0]
+                errg = np.abs(first - ref4).max() / max(1.0, np.abs(ref4).max())
+                assert errg < 1e-5, ('grouped layout 2 vs 4', model, D, groups, chains, errg)
             ngrp += 1
     # ---- split launch: lead sites == layout 2, the others == layout 1, bit for bit
     if rng.rand() < 0.15:
