@@ -998,3 +998,38 @@ def test_mix_phi_on_gpu_equals_pooled_sample_moments():
     Sref = (allc.T.dot(allc) + n * sum(np.outer(mk - mref, mk - mref) for mk in means)) / (n * M.K - 1)
     np.testing.assert_allclose(m, mref, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(S, Sref, rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_layout_policy_for_the_baseline_shapes():
+    """Which thread layout the library picks by itself (epx_sampler_opts.layout = 0) for the shapes
+    of BASELINE.json and of the reference's default experiment; tiny iteration counts, the point
+    is the decision."""
+    rng = np.random.RandomState(0)
+
+    def picked(model, K, D, n, g=None, chains=4):
+        X = rng.randn(K * n, D)
+        y = (rng.rand(K * n) < 0.5).astype(int)
+        kw = {}
+        if g is not None:                                       # g groups of n // g rows in every site
+            kw = dict(g_cnt=np.full(K, g, dtype=np.int32), g_lim=np.arange(K * g + 1) * (n // g))
+        eng = HipEngine(model, X, y, np.arange(K + 1) * n, **kw)
+        d = eng.d
+        eng.set_prior(np.eye(d), np.zeros(d))
+        eng.set_global(np.eye(d) * 2.0, np.zeros(d))
+        assert np.all(eng.cavity_batch(QI))
+        eng.sample_batch(np.arange(K) + 1, HipEngine.sampler_opts(chains=chains, iter=4, init='random', max_depth=3))
+        lay = eng.last_layout()
+        eng.close()
+        return lay
+
+    assert picked('m4b_sg', 64, 16, 200) == 2          # C2: fewer sites than CUs -> one workgroup per chain
+    assert picked('m4b_sg', 256, 16, 200) == 2         # two such workgroups share a CU: still ahead (measured)
+    assert picked('m4b_sg', 400, 16, 200) == 1         # many small sites -> one workgroup per site
+    assert picked('m4b_sg', 512, 32, 500) == 1         # C3 / C4 per GPU
+    assert picked('m4b_sg', 100, 32, 500) == 2
+    assert picked('m4b_sg', 4, 128, 2000) == 3         # C5 site size: rows beyond the LDS -> streaming
+    assert picked('m1b_sg', 6, 64, 100) == 3           # D > 32
+    assert picked('m4b', 32, 16, 40, g=2) == 2         # the reference's default experiment: 2 groups per site, few sites
+    assert picked('m4b', 300, 16, 40, g=2) == 4        # many multi-group sites -> lock step, rows resident
+    assert picked('m4b', 8, 64, 60, g=3) == 3          # multi-group, D > 32 -> streaming
