@@ -354,6 +354,8 @@ k_nuts_spec(NutsArgs a) {
     constexpr int GREC = 66, WREC = 64 * NV + 2;        // per-group / per-wave exchange records (nuts_gradient_groups.inc)
     int ng = 1;
     int *gl_s = reinterpret_cast<int *>(smem + a.off_gl);
+    double *qcopy = reinterpret_cast<double *>(smem + a.off_gl) + ((a.ngmax + 1 + 3) / 4) * 2;     // behind the row limits, 16-B aligned
+    (void)qcopy;
     if constexpr (GRP) {
         const int g0 = a.site_g0[k];
         ng = a.site_g0[k + 1] - g0;
@@ -646,6 +648,7 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
         off += (size_t)2 * (wpc * (64 * nv + 2) + (size_t)a.ngmax * 66) * 8;
         a.off_gl = (int)off;
         off += ((size_t)(a.ngmax + 1) * 4 + 15) & ~(size_t)15;
+        off += (size_t)wpc * 2 * 64 * nv * 8;              // per-wave copies of q and exp(q)
     } else if (wpc > 1) off += (size_t)2 * wpc * (64 * (1 + nv) + 2) * 8;
     off = (off + 15) & ~(size_t)15;
     const size_t cap = 160 * 1024;
