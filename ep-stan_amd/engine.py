@@ -2,7 +2,7 @@
 
 `HipEngine` is the only engine the package ships.  It raises when libepx.so or
 a HIP device is missing -- there is no CPU path.  (Tests drive `Master`'s host
-logic on CPU with an oracle-backed engine that lives under tests/.)
+logic on CPU with an oracle-backed engine, oracle/engine_oracle.py, which only tests import.)
 """
 
 import ctypes
