@@ -542,11 +542,11 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // for single-group sites layout 1 is still faster at the C3 site size (132 vs 157 ms per
     // launch), so it is chosen on request only
     bool lock = false;
-    // several groups per site with few sites: one workgroup per chain, the four gradient waves share the
+    // several groups per site: one workgroup per chain, the four gradient waves share the
     // site's groups (nuts_gradient_groups.inc); needs rows, Omega, tree stack and mailbox in LDS
     bool grp = false;
     if (c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
-        (layout == 2 || (layout == 0 && (long)count * o.chains <= 4L * c->n_cu))) {
+        (layout == 2 || layout == 0)) {       // measured ahead of the lock-step layouts from 32 to 1024 sites (scripts/ab_kj.py)
         a.grp = 1; a.cpb = 1;
         const size_t lds = nuts_lds_layout(a, 4, dp, c->n_max);
         if (lds <= LDS_CAP && a.om_in_lds && a.stack_in_lds && a.off_spec > 0) grp = true;

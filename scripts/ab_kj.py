@@ -7,12 +7,16 @@ from epstan_amd import models
 from epstan_amd.engine import HipEngine
 from epstan_amd.method import Master
 from epstan_amd.util import distribute_groups
-for J, K, D, npg in ((64, 32, 16, 20), (1024, 256, 16, 50)):
+import sys
+CASES = ((64, 32, 16, 20), (1024, 256, 16, 50))
+if len(sys.argv) > 4:
+    CASES = (tuple(int(v) for v in sys.argv[1:5]),)
+for J, K, D, npg in CASES:
     mod = models.m4b(J, D, npg)
     data = mod.simulate_data(Sigma_x='rand', rng=100)
     _, _, Q0, r0 = mod.get_prior()
     Nk, Nj_k, j_ind_k = distribute_groups(J, K, data.Nj)
-    for layout in (2, 3, 4):
+    for layout in ((2, 4) if len(sys.argv) > 4 else (2, 3, 4)):
         M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
                    prior={'Q': Q0, 'r': r0}, chains=4, iter=100, layout=layout)
         opts = HipEngine.sampler_opts(chains=4, iter=100, init='random', layout=layout)

@@ -1031,5 +1031,6 @@ def test_layout_policy_for_the_baseline_shapes():
     assert picked('m4b_sg', 4, 128, 2000) == 3         # C5 site size: rows beyond the LDS -> streaming
     assert picked('m1b_sg', 6, 64, 100) == 3           # D > 32
     assert picked('m4b', 32, 16, 40, g=2) == 2         # the reference's default experiment: 2 groups per site, few sites
-    assert picked('m4b', 300, 16, 40, g=2) == 4        # many multi-group sites -> lock step, rows resident
+    assert picked('m4b', 300, 16, 40, g=2) == 2        # ... and many of them (ahead of lock step at every count measured)
+    assert picked('m4b', 12, 16, 160, g=8) == 4        # P = 170 > 128 coordinates: chains in lock step, rows resident
     assert picked('m4b', 8, 64, 60, g=3) == 3          # multi-group, D > 32 -> streaming
