@@ -34,6 +34,9 @@ SIGNATURES = {
     'epx_ctx_create_real': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_int64_p, c_double_p, c_double_p,
                                            ctypes.POINTER(ctypes.c_void_p)]),
+    'epx_ctx_create_real_groups': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  c_int64_p, c_int32_p, c_int64_p, c_double_p, c_double_p,
+                                                  ctypes.POINTER(ctypes.c_void_p)]),
     'epx_ctx_create_groups': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              c_int64_p, c_int32_p, c_int64_p, c_double_p, c_int32_p,
                                              ctypes.POINTER(ctypes.c_void_p)]),

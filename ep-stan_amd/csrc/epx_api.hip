@@ -164,10 +164,15 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
 
 int epx_ctx_create_real(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
                         const double *y, epx_ctx **out) {
+    return epx_ctx_create_real_groups(device, model, K_local, D, k_lim, nullptr, nullptr, X, y, out);
+}
+
+int epx_ctx_create_real_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                               const int64_t *g_lim, const double *X, const double *y, epx_ctx **out) {
     if (out) *out = nullptr;
     if (model < EPX_M1A_SG || model > EPX_M5A_SG)
         return fail("model %d has 0/1 responses: use epx_ctx_create", model);
-    return ctx_create(device, model, K_local, D, k_lim, nullptr, nullptr, X, nullptr, y, out);
+    return ctx_create(device, model, K_local, D, k_lim, g_cnt, g_lim, X, nullptr, y, out);
 }
 
 static int ctx_create(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
@@ -545,7 +550,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // several groups per site: one workgroup per chain, the four gradient waves share the
     // site's groups (nuts_gradient_groups.inc); needs rows, Omega, tree stack and mailbox in LDS
     bool grp = false;
-    if (c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
+    if (c->multi && dp > 0 && nv <= 2 && !no_spec &&
         (layout == 2 || layout == 0)) {       // measured ahead of the lock-step layouts from 32 to 1024 sites (scripts/ab_kj.py)
         a.grp = 1; a.cpb = 1;
         const size_t lds = nuts_lds_layout(a, 4, dp, c->n_max);
@@ -557,6 +562,10 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         a.no_spec = 0;
         return 0;
     }
+    if (c->multi && c->gauss)
+        return fail("Gaussian-likelihood models with several groups per site need D <= 32, at most 128 sampled coordinates and "
+                    "the site's rows, cavity precision, tree stack and mailbox in LDS; this shape (D = %d, P = %d, n_max = %d) "
+                    "is not supported", c->D, c->P, c->n_max);
     if (layout == 2 && c->multi) layout = 0;
     if ((layout == 4 || (layout == 0 && c->multi)) && c->D <= 32 && nv <= 7) {
         const int dpl = c->D <= 16 ? 16 : 32;

@@ -700,7 +700,8 @@ static int launch_wpc(const NutsArgs &a, int nblocks, int wpc, hipStream_t strea
     if (a.grp) {
         // several groups per site: the everything-resident bookkeeping-wave kernel only (the host checks)
         if (wpc == 4 && a.off_spec > 0 && a.om_in_lds && a.stack_in_lds && !a.no_spec)
-            return launch_spec<NV, DP, true, false, true>(a, nblocks, stream);
+            return a.gauss ? launch_spec<NV, DP, true, true, true>(a, nblocks, stream)
+                           : launch_spec<NV, DP, true, false, true>(a, nblocks, stream);
         return -1;
     }
     if (a.gauss) {

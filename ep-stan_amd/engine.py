@@ -18,7 +18,8 @@ MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4,
              'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4,
              # Gaussian-likelihood family experiment/models/m{1..5}a_sg.stan: phi = [log sigma | the
              # b-model's phi], real responses
-             'm1a_sg': 5, 'm2a_sg': 6, 'm3a_sg': 7, 'm4a_sg': 8, 'm5a_sg': 9}
+             'm1a_sg': 5, 'm2a_sg': 6, 'm3a_sg': 7, 'm4a_sg': 8, 'm5a_sg': 9,
+             'm1a': 5, 'm2a': 6, 'm3a': 7, 'm4a': 8, 'm5a': 9}
 
 
 def is_gauss(model):
@@ -55,8 +56,6 @@ class HipEngine(object):
         if X.ndim != 2:
             raise ValueError('the built-in site models need a two dimensional X')
         gauss = is_gauss(model)
-        if gauss and g_cnt is not None:
-            raise ValueError('the Gaussian-likelihood models are built for one group per site')
         y32 = None if gauss else np.ascontiguousarray(y, dtype=np.int32)
         yd = np.ascontiguousarray(y, dtype=np.float64) if gauss else None
         k_lim = np.ascontiguousarray(k_lim, dtype=np.int64)
@@ -66,7 +65,9 @@ class HipEngine(object):
         self.d, self.P = model_dims(model if model.endswith('_sg') else model + '_sg', self.D)
         self.device = device
         ctx = ctypes.c_void_p()
-        if gauss:
+        if gauss and g_cnt is None:
+            if not model.endswith('_sg'):
+                raise ValueError('site model {!r} needs the groups of every site (g_cnt, g_lim)'.format(model))
             self.site_P = np.full(self.K, self.P, dtype=np.int64)
             check(self.lib.epx_ctx_create_real(
                 device, MODEL_IDS[model], self.K, self.D,
@@ -83,14 +84,20 @@ class HipEngine(object):
             g_lim = np.ascontiguousarray(g_lim, dtype=np.int64)
             if g_cnt.shape[0] != self.K or g_lim.shape[0] != int(g_cnt.sum()) + 1:
                 raise ValueError('g_cnt needs one entry per site and g_lim sum(g_cnt)+1 entries')
-            pg = 1 if MODEL_IDS[model] == 0 else 1 + self.D
+            pg = 1 if MODEL_IDS[model] % 5 == 0 else 1 + self.D
             self.P = self.d + int(g_cnt.max()) * pg          # record stride: the largest site
             self.site_P = self.d + g_cnt.astype(np.int64) * pg
-            check(self.lib.epx_ctx_create_groups(
-                device, MODEL_IDS[model], self.K, self.D,
-                k_lim.ctypes.data_as(_lib.c_int64_p), g_cnt.ctypes.data_as(_lib.c_int32_p),
-                g_lim.ctypes.data_as(_lib.c_int64_p), dptr(X),
-                y32.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ctx)))
+            if gauss:
+                check(self.lib.epx_ctx_create_real_groups(
+                    device, MODEL_IDS[model], self.K, self.D,
+                    k_lim.ctypes.data_as(_lib.c_int64_p), g_cnt.ctypes.data_as(_lib.c_int32_p),
+                    g_lim.ctypes.data_as(_lib.c_int64_p), dptr(X), dptr(yd), ctypes.byref(ctx)))
+            else:
+                check(self.lib.epx_ctx_create_groups(
+                    device, MODEL_IDS[model], self.K, self.D,
+                    k_lim.ctypes.data_as(_lib.c_int64_p), g_cnt.ctypes.data_as(_lib.c_int32_p),
+                    g_lim.ctypes.data_as(_lib.c_int64_p), dptr(X),
+                    y32.ctypes.data_as(_lib.c_int32_p), ctypes.byref(ctx)))
         self.g_cnt, self.g_lim = g_cnt, g_lim
         self.ctx = ctx
         n = ctypes.c_int()

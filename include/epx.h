@@ -110,6 +110,10 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
  * stack) must fit the LDS -- other shapes are refused by the sampling calls. */
 int epx_ctx_create_real(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
                         const double *y, epx_ctx **out);
+/* ... with several groups per site (experiment/models/m1a.stan:11-45, `j_ind`; g_cnt / g_lim as in
+ * epx_ctx_create_groups): served by the one-workgroup-per-chain layout only (D <= 32, <= 128 coordinates). */
+int epx_ctx_create_real_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                               const int64_t *g_lim, const double *X, const double *y, epx_ctx **out);
 int epx_ctx_destroy(epx_ctx *ctx);
 
 /* prior natural parameters Q0 (d,d) F-order, r0 (d): method.py:772-797 */

@@ -18,7 +18,8 @@ MODEL_IDS = {'m1b_sg': 0, 'm2b_sg': 1, 'm3b_sg': 2, 'm4b_sg': 3, 'm5b_sg': 4,
              'm1b': 0, 'm2b': 1, 'm3b': 2, 'm4b': 3, 'm5b': 4,
              # Gaussian-likelihood family (experiment/models/m*a_sg.stan): phi = [log sigma | b-model phi],
              # real-valued responses
-             'm1a_sg': 5, 'm2a_sg': 6, 'm3a_sg': 7, 'm4a_sg': 8, 'm5a_sg': 9}
+             'm1a_sg': 5, 'm2a_sg': 6, 'm3a_sg': 7, 'm4a_sg': 8, 'm5a_sg': 9,
+             'm1a': 5, 'm2a': 6, 'm3a': 7, 'm4a': 8, 'm5a': 9}
 STAT_NAMES = ('stepsize_mean', 'stepsize_final', 'nleap', 'ngrad', 'ndiv',
               'accept_mean', 'depth_mean', 'fail')
 _lib = None

@@ -842,6 +842,8 @@ def _group_problem(model, D, groups, seed, tight=1.0):
     N = int(np.sum(sizes))
     X = rng.randn(N, D) * 1.2
     y = (rng.rand(N) < 0.55).astype(int)
+    if no.is_gauss(model):
+        y = 0.2 + X.dot(rng.randn(D) * 0.4) + 0.9 * rng.randn(N)
     k_lim = np.concatenate(([0], np.cumsum(sizes)))
     g_cnt = np.array([len(g) for g in groups], dtype=np.int32)
     g_lim = np.concatenate(([0], np.cumsum([n for g in groups for n in g])))
@@ -938,6 +940,51 @@ def test_multigroup_site_updates_match_oracle(model, D, groups, chains, layout):
             np.testing.assert_allclose(e1.get_draws(k, True)[:3], e2.get_draws(k, True)[:3], rtol=1e-6, atol=1e-8)
         else:
             np.testing.assert_array_equal(e1.get_draws(k, True), e2.get_draws(k, True))
+
+
+@pytest.mark.parametrize('model,D,groups', [('m1a', 3, [[5, 1, 9], [4, 4]]), ('m2a', 16, [[20, 20], [13, 30, 7], [40]]),
+                                            ('m3a', 8, [[9, 70, 3, 11, 20], [150]]), ('m4a', 16, [[20, 20], [64, 65]]),
+                                            ('m5a', 6, [[10, 10, 10, 10], [33]])])
+def test_gaussian_family_multigroup_matches_oracle(model, D, groups):
+    """Gaussian likelihood with several groups per site (experiment/models/m1a.stan etc.): served by the
+    one-workgroup-per-chain layout; gradients to 1e-9 and a short site update chain by chain against the oracle."""
+    X, y, k_lim, g_cnt, g_lim, Oms, mus, d = _group_problem(model, D, groups, 5 + D, tight=300.0)
+    eng, Om_dev, mu_dev = _group_engine(model, X, y, k_lim, g_cnt, g_lim, Oms, mus)
+    rng = np.random.RandomState(4)
+    off = np.concatenate(([0], np.cumsum(g_cnt)))
+    K = len(groups)
+    for k in range(K):
+        Pk = no.dims(model, D, g_cnt[k])[1]
+        assert eng.site_P[k] == Pk
+        theta = np.zeros(eng.P); theta[:Pk] = rng.randn(Pk) * 0.3
+        lo, hi = k_lim[k], k_lim[k + 1]
+        gl = g_lim[off[k]:off[k + 1] + 1] - lo
+        lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta[:Pk], gl=gl)
+        lp, g = eng.logdensity_grad(k, theta)
+        assert eng.last_layout() == 2
+        assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o))
+        np.testing.assert_allclose(g[:Pk], g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+        assert np.all(g[Pk:] == 0.0)
+    if model == 'm5a':
+        return                                  # Laplace kinks: whole runs part ways with the oracle early (chaos)
+    seeds = np.arange(K, dtype=np.int64) + 7
+    it = 44
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=2, iter=it, init='random'))
+    assert eng.last_layout() == 2
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=2, iter=it, g_cnt=g_cnt, g_lim=g_lim)
+    cs = eng.get_chain_stats(2)
+    n_full = 0
+    for k in range(K):
+        dev = eng.get_draws(k, True).reshape(2, it // 2, eng.P)
+        err = np.abs(dev - draws_o[k]).max(axis=2) / max(1.0, np.abs(draws_o[k]).max())
+        for c in range(2):
+            assert np.all(err[c, :3] < 1e-3), (k, c, err[c, :3])
+            if np.all(err[c] < 1e-4):
+                n_full += 1
+                assert cs[k, c, 2] == st_o[k, c, 2]
+    assert n_full >= K
+    with pytest.raises(_lib.EpxError, match='not supported'):
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=2, iter=it, init='random', layout=4))
 
 
 def test_multigroup_ep_posterior_matches_cpu_path_within_monte_carlo_error():

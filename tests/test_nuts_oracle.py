@@ -208,3 +208,38 @@ def test_multigroup_sampler_against_importance_sampling():
     d2 = no.nuts_sites('m4b', X, y, k_lim, mu[None], Om[None], np.array([3]), chains=2, iter=60,
                        g_cnt=np.array([1]), g_lim=k_lim)[0]
     assert np.array_equal(d1, d2)
+
+
+@pytest.mark.parametrize('model', ['m1a', 'm2a', 'm3a', 'm4a', 'm5a'])
+def test_gaussian_family_multigroup_density(model):
+    """Several groups per site with the Gaussian likelihood (models/m1a.stan etc.): the oracle's value is the
+    sum of the single-group values minus the cavity term counted once per extra group, and its gradient
+    matches finite differences."""
+    rng = np.random.RandomState(21)
+    D, sizes = 4, [7, 12, 5]
+    n, ng = sum(sizes), len(sizes)
+    X = rng.randn(n, D); y = rng.randn(n) * 1.1 + 0.3
+    d, P = no.dims(model, D, ng)
+    d1, P1 = no.dims(model + '_sg', D)
+    assert d == d1 and P == d + ng * (P1 - d)
+    A = rng.randn(d, d + 2)
+    Om = A.dot(A.T) / (d + 2) + 0.4 * np.eye(d); mu = 0.3 * rng.randn(d)
+    th = rng.randn(P) * 0.4
+    gl = np.concatenate(([0], np.cumsum(sizes)))
+    lp, g = no.logdensity_grad(model, X, y, mu, Om, th, gl=gl)
+    v = th[:d] - mu
+    cav = -0.5 * v.dot(Om).dot(v)
+    pg = P1 - d
+    total = 0.0
+    for j in range(ng):
+        eta = th[d + j:d + j + 1]
+        etb = th[d + ng + j * D:d + ng + (j + 1) * D] if pg > 1 else np.zeros(0)
+        th_j = np.concatenate((th[:d], eta, etb))
+        total += no.logdensity_grad(model + '_sg', X[gl[j]:gl[j + 1]], y[gl[j]:gl[j + 1]], mu, Om, th_j)[0] - cav
+    assert abs(lp - (total + cav)) < 1e-10 * max(1.0, abs(lp))
+    fd = np.zeros(P)
+    for i in range(P):
+        e = np.zeros(P); e[i] = 1e-6
+        fd[i] = (no.logdensity_grad(model, X, y, mu, Om, th + e, gl=gl)[0] - no.logdensity_grad(model, X, y, mu, Om, th - e, gl=gl)[0]) / 2e-6
+    mask = np.abs(th) > 1e-4 if model == 'm5a' else np.ones(P, bool)
+    np.testing.assert_allclose(g[mask], fd[mask], rtol=2e-6, atol=2e-6)
