@@ -11,6 +11,7 @@ from oracle import nuts_oracle as no
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 niter = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+siter = int(sys.argv[3]) if len(sys.argv) > 3 else 200      # NUTS iterations per chain and site update (fit.py default 200)
 J, D, npg = 64, 16, 20
 mod = models.m4b(J, D, npg)
 data = mod.simulate_data(Sigma_x='rand', rng=100)
@@ -24,12 +25,12 @@ m_full, sd_full = x.mean(0), x.std(0)
 rhat = max(no.split_rhat(draws[0, :, :, e]) for e in range(d))
 print('full posterior (oracle NUTS on the joint model, P = %d): %.0f s, %d divergences, max split-Rhat of phi %.3f'
       % (draws.shape[-1], time.time() - t0, st[0, :, 4].sum(), rhat))
-conf = fit.configurations(run_ep=True, iter=niter, save_res=False, K=K)
+conf = fit.configurations(run_ep=True, iter=niter, save_res=False, K=K, siter=siter)
 t0 = time.time()
 res = fit.main('m4b', conf, verbose=False)
 dt = time.time() - t0
 m, S = res['m_s_ep'], res['S_s_ep']
-print('EP on the device: K = %d sites, %d iterations in %.1f s' % (K, niter, dt))
+print('EP on the device: K = %d sites, %d iterations of 4 x %d NUTS iterations per site in %.1f s' % (K, niter, siter, dt))
 for it in sorted(set([0, 1, 2, 5, 10, 20, niter])):
     z = np.abs(m[it] - m_full) / sd_full
     r = np.sqrt(np.diagonal(S[it])) / sd_full
