@@ -1084,29 +1084,33 @@ def test_layout_policy_for_the_baseline_shapes():
 
 
 @pytest.mark.gpu
-def test_ep_converges_to_the_full_posterior_of_the_joint_model():
+@pytest.mark.parametrize('name,K', [('m4b', 8), ('m4b', 16), ('m4a', 8), ('m1b', 16), ('m1a', 16)])
+def test_ep_converges_to_the_full_posterior_of_the_joint_model(name, K):
     """A target that involves neither the reference nor the EP code: the posterior of the whole hierarchical
     model, sampled by the oracle's NUTS as ONE site that holds all J groups with the prior as its cavity.
-    Device EP (K < J: two groups per site, enough draws per site update for the Monte-Carlo error to be small)
-    has to land on it: means within 0.35 posterior sd in every coordinate (measured over four seeds: 0.08-0.14),
-    marginal sd within a factor 0.6-1.25 (measured 0.73-1.05)
-    (scripts/ep_vs_full_posterior.py is the full-size version: J = 64, D = 16)."""
+    Device EP (K = J: one group per site; K < J: two groups per site; logistic and Gaussian likelihood), with
+    enough draws per site update for the Monte-Carlo error to be small, has to land on it: means within 0.35
+    posterior sd in every coordinate (m4b, K = 8 measured over four seeds: 0.08-0.14), marginal sd within a
+    factor 0.6-1.25 (measured 0.73-1.05).  scripts/ep_vs_full_posterior.py is the full-size version."""
     from epstan_amd.util import distribute_groups
-    J, D, npg, K = 16, 4, 30, 8
-    mod = models.m4b(J, D, npg)
+    J, D, npg = 16, 4, 30
+    mod = models.MODELS[name](J, D, npg)
     data = mod.simulate_data(Sigma_x='rand', rng=100)
     S0, m0, Q0, r0 = mod.get_prior()
     d = mod.dphi
-    draws, _, st = no.nuts_sites('m4b', data.X, data.y, np.array([0, data.X.shape[0]]), m0[None], Q0[None], [11],
+    draws, _, st = no.nuts_sites(name, data.X, data.y, np.array([0, data.X.shape[0]]), m0[None], Q0[None], [11],
                                  chains=4, iter=3000, g_cnt=np.array([J], dtype=np.int32),
                                  g_lim=data.j_lim.astype(np.int64), nthreads=4)
     x = draws[0].reshape(-1, draws.shape[-1])[:, :d]
     m_full, sd_full = x.mean(0), x.std(0)
     assert max(no.split_rhat(draws[0, :, :, e]) for e in range(d)) < 1.1
-    Nk, Nj_k, j_ind_k = distribute_groups(J, K, data.Nj)
-    M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
-               prior={'Q': Q0, 'r': r0}, chains=4, iter=1500, df0=0.4)
-    info, (m_s, S_s) = M.run(14, verbose=False, seed=3)
+    if K < J:
+        Nk, Nj_k, j_ind_k = distribute_groups(J, K, data.Nj)
+        M = Master(name, data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
+                   prior={'Q': Q0, 'r': r0}, chains=4, iter=1500, df0=0.4)
+    else:
+        M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=1500, df0=0.3)
+    info, (m_s, S_s) = M.run(14 if K < J else 22, verbose=False, seed=3)
     assert info == 0 and M.engine.last_layout() == 2
     z = np.abs(m_s[-1] - m_full) / sd_full
     ratio = np.sqrt(np.diag(S_s[-1])) / sd_full
