@@ -1090,8 +1090,8 @@ def test_ep_converges_to_the_full_posterior_of_the_joint_model(name, K):
     model, sampled by the oracle's NUTS as ONE site that holds all J groups with the prior as its cavity.
     Device EP (K = J: one group per site; K < J: two groups per site; logistic and Gaussian likelihood), with
     enough draws per site update for the Monte-Carlo error to be small, has to land on it: means within 0.35
-    posterior sd in every coordinate (m4b, K = 8 measured over four seeds: 0.08-0.14), marginal sd within a
-    factor 0.6-1.25 (measured 0.73-1.05).  scripts/ep_vs_full_posterior.py is the full-size version."""
+    posterior sd in every coordinate (measured over three seeds per case: 0.08-0.21), marginal sd within a
+    factor 0.55-1.25 (measured 0.65-1.07; the low end is the skewed log-scale coordinate of the logistic models).  scripts/ep_vs_full_posterior.py is the full-size version."""
     from epstan_amd.util import distribute_groups
     J, D, npg = 16, 4, 30
     mod = models.MODELS[name](J, D, npg)
@@ -1116,5 +1116,5 @@ def test_ep_converges_to_the_full_posterior_of_the_joint_model(name, K):
     ratio = np.sqrt(np.diag(S_s[-1])) / sd_full
     z0 = np.abs(m0 - m_full) / sd_full
     assert z.max() < 0.35, z
-    assert ratio.min() > 0.6 and ratio.max() < 1.25, ratio
+    assert ratio.min() > 0.55 and ratio.max() < 1.25, ratio
     assert z0.max() > 2.0                       # the prior is far from it: EP did the work
