@@ -202,6 +202,12 @@ def main():
         'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
                                                / (sites_local * args.chains * args.siter)),
     }
+    # the launch ends with its slowest chain (one workgroup per chain) / slowest site (chains in lock step):
+    # how far that is from the average, last launch of this rank
+    lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
+    out['launch_tail'] = {'slowest_chain_leapfrogs': float(lf.max()), 'mean_chain_leapfrogs': float(lf.mean()),
+                          'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(M.engine.last_layout()),
+                          'lead_sites_of_a_split_launch': int(M.engine.last_split())}
     if comm is not None:
         tdist.destroy_process_group()
     if args.cpu_sites > 0:
