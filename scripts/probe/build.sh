@@ -5,4 +5,6 @@ cd "$(dirname "$0")/../.."
 mkdir -p variants
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iep-stan_amd/csrc scripts/probe/stream_probe.hip -o variants/stream_probe
 hipcc --offload-arch=gfx950 -O2 scripts/probe/mfma_layout.hip -o variants/mfma_layout
-echo "built variants/stream_probe variants/mfma_layout"
+hipcc --offload-arch=gfx950 -O2 scripts/probe/concurrent.hip -o variants/concurrent
+hipcc --offload-arch=gfx950 -O2 scripts/probe/xcu_latency.hip -o variants/xcu_latency
+echo "built variants/stream_probe variants/mfma_layout variants/concurrent variants/xcu_latency"
