@@ -13,7 +13,7 @@ struct Ctl { unsigned long long seq, ack; int bad, timeout; };
 __device__ inline unsigned long long ld_acq(unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_rel(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ void k(double *ring, Ctl *c, int n, int pingpong, int consumer_block, long long *cycles) {
+__global__ void k(double *ring, Ctl *c, int n, int pingpong, int consumer_block, long long *cycles, int batch) {
     const int lane = threadIdx.x;
     if (blockIdx.x != 0 && blockIdx.x != consumer_block) return;
     const bool prod = blockIdx.x == 0;
@@ -28,7 +28,7 @@ __global__ void k(double *ring, Ctl *c, int n, int pingpong, int consumer_block,
             }
             for (int v = 0; v < NV; ++v) slot[v * 64 + lane] = (double)i + 0.001 * lane + v;
             __syncthreads();                        // all lanes' stores issued (one wave: cheap)
-            if (lane == 0) st_rel(&c->seq, (unsigned long long)i);
+            if (lane == 0 && (pingpong || i % batch == 0 || i == n)) st_rel(&c->seq, (unsigned long long)i);    // one release per `batch` states
             if (pingpong) {
                 int s = 0;
                 while (ld_acq(&c->ack) < (unsigned long long)i && ++s < SPIN) {}
@@ -43,7 +43,7 @@ __global__ void k(double *ring, Ctl *c, int n, int pingpong, int consumer_block,
             const double want = NV * ((double)i + 0.001 * lane) + 3.0;
             if (fabs(chk - want) > 1e-9) atomicAdd(&c->bad, 1);
             __syncthreads();
-            if (lane == 0) st_rel(&c->ack, (unsigned long long)i);
+            if (lane == 0 && (pingpong || i % batch == 0 || i == n)) st_rel(&c->ack, (unsigned long long)i);
         }
     }
     if (lane == 0) cycles[prod ? 0 : 1] = wall_clock64() - t0;
@@ -54,14 +54,15 @@ int main() {
     CK(hipMalloc(&ring, sizeof(double) * RING * NV * 64)); CK(hipMalloc(&c, sizeof(Ctl))); CK(hipMalloc(&cyc, 16));
     const int n = 20000;
     for (int consumer : {1, 8, 9, 255}) {           // workgroups are dealt round-robin to the 8 XCDs: 1 -> another XCD, 8 -> the same one
-        for (int pp : {1, 0}) {
+        for (int mode : {-1, 1, 4, 16}) {            // -1: ping-pong; else streaming with one release per `mode` states
+            const int pp = mode < 0, batch = mode < 0 ? 1 : mode;
             CK(hipMemset(c, 0, sizeof(Ctl))); CK(hipMemset(cyc, 0, 16));
-            hipLaunchKernelGGL(k, dim3(256), dim3(64), 0, 0, ring, c, n, pp, consumer, cyc);
+            hipLaunchKernelGGL(k, dim3(256), dim3(64), 0, 0, ring, c, n, pp, consumer, cyc, batch);
             CK(hipDeviceSynchronize());
             Ctl h; long long hc[2];
             CK(hipMemcpy(&h, c, sizeof h, hipMemcpyDeviceToHost)); CK(hipMemcpy(hc, cyc, 16, hipMemcpyDeviceToHost));
-            printf("consumer workgroup %3d, %s: %.3f us per state (producer), %.3f us (consumer), wrong payloads %d, timeout %d\n",
-                   consumer, pp ? "ping-pong " : "streaming ", hc[0] / 100.0 / n, hc[1] / 100.0 / n, h.bad, h.timeout);
+            printf("consumer workgroup %3d, %s (release every %2d): %.3f us per state (producer), %.3f us (consumer), wrong payloads %d, timeout %d\n",
+                   consumer, pp ? "ping-pong " : "streaming ", batch, hc[0] / 100.0 / n, hc[1] / 100.0 / n, h.bad, h.timeout);
         }
     }
     return 0;
