@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: site-updates/sec (and EP iters/sec) of the EP inner loop on
-synthetic hierarchical logistic regression (BASELINE.json configs[1]:
-J=64 sites, D=16, n_j=200, model m4b, chains=4, iter=200 -> S=400 draws/site).
+"""Headline benchmark: site-updates/sec (and EP iters/sec) of the EP inner loop on synthetic
+hierarchical logistic regression, model m4b, chains=4, iter=200 (S=400 draws per site update).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3|c2|c5shard]
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); a step is one
-outer EP iteration over all sites: batched NUTS site updates -> moment stage ->
-packed site sums -> all-reduce -> damped update + cavities -> moments.  Weak
-scaling: every rank owns `--sites` sites (64), so J = 64 * N.
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 512 sites per
+GPU, D=32, n_j=500 (N=1 is C3; N=8 is exactly C4: J=4096 sharded over 8 GPUs, weak scaling).
+One process per GPU; a step is one outer EP iteration over all sites: batched NUTS site updates ->
+moment stage -> packed site sums -> ONE RCCL all-reduce (inside libepx.so) -> damped update +
+cavities -> moments.  Launched by torchrun (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the
+environment) every rank joins; a plain `python bench.py --gpus N` with N > 1 starts the N ranks
+itself (fresh child processes through torch.distributed.run, before anything touches a GPU).
 Rank 0 prints ONE JSON line (contract in the task statement).
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,8 +27,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP64 matrix peak (AMD spec)
+# MI355X_MICROARCH.md: HBM3E 8 TB/s peak; LDS 160 KiB/CU, ~150 TB/s aggregate for ds_read_b64/b128.
+# FP64 vector = FP64 matrix peak 78.6 TFLOP/s (AMD MI355X datasheet)
+FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0
+LDS_PEAK_TBS = 150.0
+
+CONFIGS = {
+    # name: (sites per GPU, D, n_j, correlated covariates, default steps, default warm-up)
+    'c2': (64, 16, 200, 1, 20, 5),
+    'c3': (512, 32, 500, 1, 8, 5),
+    'c5shard': (512, 128, 2000, 0, 1, 1),
+}
 
 
 def workload(J, D, n, model, cor_input=True):
@@ -40,183 +54,265 @@ def workload(J, D, n, model, cor_input=True):
     return mod, data, Q0, r0
 
 
-def cpu_baseline(mod, data, Q0, r0, nsites, chains, siter, threads):
-    """The oracle (kind 'port') timed on this box's host cores: one EP iteration
-    (cavity -> NUTS -> moment stage -> damped update) over the first `nsites` sites."""
-    from epstan_amd import models
-    from epstan_amd.method import Master
-    from oracle.engine_oracle import OracleEngine
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(M, mod, data, chains, siter, n_all, n_seq, threads):
+    """The CPU port (oracle/, kind 'port') on this box's host cores, from the SAME state as the
+    timed GPU iterations: the cavities and the chains' last draws of the first sites are
+    downloaded after the timed region, and the C restatement of the sampler + the NumPy moment
+    stage run one site update each from there.  Two schedules:
+      all-cores           (site, chain) pairs spread over every host thread;
+      reference-faithful  sites strictly one after the other, the 4 chains of a site on 4 threads
+                          (PyStan n_jobs=-1 inside method.py:1005-1023), plus the reference's own
+                          "limiting sampling time" = max over sites (method.py:1043)."""
+    from oracle import ep_oracle as eo
     from oracle import nuts_oracle as no
     no.build()
-    nrow = int(data.j_lim[nsites])
-    t_threads = threads if threads > 0 else no.lib().epo_num_threads()
-    M = Master(mod.site_model, data.X[:nrow], data.y[:nrow], site_sizes=data.Nj[:nsites],
-               prior={'Q': Q0, 'r': r0}, chains=chains, iter=siter,
-               df0=models.default_df0(max(nsites, 2)),
-               _engine_factory=lambda m, X, y, kl: OracleEngine(m, X, y, kl, nthreads=t_threads))
-    t0 = time.time()
-    info = M.run(1, verbose=False, calc_moments=True, seed=1)[0]
-    dt = time.time() - t0
-    return {'value': nsites / dt, 'unit': 'site-updates/s', 'cores': int(t_threads), 'kind': 'port',
-            'sample': '1 EP iteration over the first %d sites of the same workload '
-                      '(C oracle NUTS + NumPy moment/cavity stages), %.1f s wall' % (nsites, dt),
-            'info': int(info)}
+    eng = M.engine
+    P = eng.P
+    nkeep = siter - siter // 2
+    n_all = min(n_all, M.K_local)
+    n_seq = min(n_seq, n_all)
+    mus = np.stack([eng.get_cavity(k)[1] for k in range(n_all)])
+    Oms = np.stack([eng.get_cavity(k)[0] for k in range(n_all)])
+    last = np.stack([eng.get_draws(k, all_params=True).reshape(chains, nkeep, P)[:, -1, :] for k in range(n_all)])
+    Q, r = eng.get_global()
+    lim = np.asarray(M.k_lim[:n_all + 1], dtype=np.int64)
+    X, y = M.X[:lim[-1]], M.y[:lim[-1]]
+    seeds = np.arange(1, n_all + 1, dtype=np.int64) * 7919
+    nthr = threads if threads > 0 else no.lib().epo_num_threads()
+
+    def site_update(ks, nt):
+        sl = slice(ks[0], ks[-1] + 1)
+        l = lim[ks[0]:ks[-1] + 2]
+        t0 = time.perf_counter()
+        draws, _, stats = no.nuts_sites(M.model_name, X[l[0]:l[-1]], y[l[0]:l[-1]], l - l[0], mus[sl], Oms[sl],
+                                        seeds[sl], chains=chains, iter=siter, init=last[sl], nthreads=nt)
+        for j in range(len(ks)):
+            eo.tilted_moments(np.asfortranarray(draws[j].reshape(-1, P)[:, :eng.d]), Q, r, 'sample')
+        return time.perf_counter() - t0, float(stats[:, :, 3].sum())
+
+    t_all, g_all = site_update(list(range(n_all)), nthr)
+    t_seq = [site_update([k], min(chains, nthr))[0] for k in range(n_seq)]
+    return {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': int(nthr), 'kind': 'port',
+            'cpu': cpu_model_name(), 'host_threads': os.cpu_count(),
+            'sample': 'one site update (C-oracle NUTS + NumPy moment stage) of the first %d sites of this workload, '
+                      'started from the cavities and last draws the GPU held after its timed iterations; '
+                      '(site, chain) pairs over %d threads: %.1f s wall, %.3g gradients'
+                      % (n_all, nthr, t_all, g_all),
+            'reference_schedule': {
+                'what': 'sites one after the other, the %d chains of a site on %d threads (method.py:1005-1023)'
+                        % (chains, min(chains, nthr)),
+                'sites_timed': n_seq, 'site_updates_per_s': n_seq / float(np.sum(t_seq)),
+                'seconds_per_site': [float(t) for t in t_seq],
+                'max_over_sites_s': float(np.max(t_seq)),
+                'note': 'the reference reports max over sites as its per-iteration "sampling time" '
+                        '(method.py:1043), i.e. the time if every site had its own 4 cores'},
+            'extrapolation': 'none: rates are per site update; an EP iteration over J sites costs J / rate'}
+
+
+def spawn_ranks(n, argv):
+    """Parent of a plain `bench.py --gpus N`: start N fresh ranks, relay their output."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--sites', type=int, default=64, help='sites per GPU (J = sites * gpus)')
-    ap.add_argument('--D', type=int, default=16)
-    ap.add_argument('--n', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--sites', type=int, default=None, help='sites per GPU (J = sites * gpus)')
+    ap.add_argument('--D', type=int, default=None)
+    ap.add_argument('--n', type=int, default=None)
     ap.add_argument('--model', default='m4b')
     ap.add_argument('--chains', type=int, default=4)
     ap.add_argument('--siter', type=int, default=200)
     ap.add_argument('--prec-estim', default='sample')
     ap.add_argument('--layout', type=int, default=0)
-    ap.add_argument('--cor-input', type=int, default=1, help='0: uncorrelated covariates (fit.py cor_input=False)')
-    ap.add_argument('--cpu-sites', type=int, default=32, help='0 disables the cpu_baseline leg')
+    ap.add_argument('--cor-input', type=int, default=None, help='0: uncorrelated covariates (fit.py cor_input=False)')
+    ap.add_argument('--cpu-sites', type=int, default=32, help='sites of the all-cores cpu_baseline leg; 0 disables it')
+    ap.add_argument('--cpu-seq-sites', type=int, default=3, help='sites of the reference-faithful schedule')
     ap.add_argument('--cpu-threads', type=int, default=0)
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launch + rendezvous only (no GPU work): checks that --gpus N starts N ranks')
     args = ap.parse_args()
+    sites, D, n, cor, steps, warm = CONFIGS[args.config]
+    sites = args.sites if args.sites is not None else sites
+    D = args.D if args.D is not None else D
+    n = args.n if args.n is not None else n
+    cor = args.cor_input if args.cor_input is not None else cor
+    steps = args.steps if args.steps is not None else steps
+    warm = args.warmup if args.warmup is not None else warm
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+
+    if args.dry_run:
+        # rendezvous of the ranks over gloo, nothing else: what `--gpus N` launches, without a GPU
+        import torch.distributed as tdist
+        if world > 1 or 'MASTER_ADDR' in os.environ:
+            tdist.init_process_group('gloo')
+            tdist.barrier()
+            seen = tdist.get_world_size()
+            tdist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({'metric': 'site-updates/sec', 'value': None, 'unit': 'site-updates/s', 'n_gpus': world,
+                              'ranks_seen': seen, 'dry_run': True, 'steps': steps, 'warmup': warm}))
+        return
+
     import torch
     from epstan_amd import dist as edist, models
     from epstan_amd.method import Master
-    comm = None
-    under_torchrun = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
-    if world > 1 or under_torchrun:
-        # one rank per GPU over RCCL; also taken at world_size 1 under torchrun so that the
-        # collective path (device-resident packed sums, all-reduce) is the one exercised
-        import torch.distributed as tdist
-        torch.cuda.set_device(local_rank)
-        tdist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        comm = edist.TorchComm(device=torch.device('cuda', local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    # every rank, also a single one, goes through the in-library RCCL communicator
+    comm = edist.EpxComm(rank=rank, world=world)
 
-    J = args.sites * world
-    mod, data, Q0, r0 = workload(J, args.D, args.n, args.model, bool(args.cor_input))
+    J = sites * world
+    mod, data, Q0, r0 = workload(J, D, n, args.model, bool(cor))
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
                chains=args.chains, iter=args.siter, prec_estim=args.prec_estim,
                df0=models.default_df0(J), comm=comm, device=local_rank, layout=args.layout,
                sync_sites=False)
+    rccl_rank, rccl_world = comm.size()
 
     def sync():
         torch.cuda.synchronize()
-        if comm is not None:
-            tdist.barrier()
+        comm.barrier()
+        torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        info = M.run(args.warmup, verbose=False, seed=1)[0]
+    if warm > 0:
+        info = M.run(warm, verbose=False, seed=1)[0]
         assert info == 0, 'warm-up EP iterations failed with info %d' % info
     n_launch0 = len(M.sampling_ms)
     sync()
     t0 = time.perf_counter()
-    res = M.run(args.steps, verbose=False, return_analytics=True, seed=2)
+    res = M.run(steps, verbose=False, return_analytics=True, seed=2)
     sync()
     dt = time.perf_counter() - t0
     info = res[0]
-    if comm is not None:
-        tmax = comm.allreduce_max(np.array([dt]))[0]
-        tdist.barrier()
-    else:
-        tmax = dt
+    tmax = float(comm.allreduce_max(np.array([dt]))[0])
     if rank != 0:
-        tdist.destroy_process_group()
+        comm.barrier()          # rank 0's cpu_baseline leg needs nothing from the others
+        comm.close()
         return
     assert info == 0, 'EP failed with info %d' % info
 
-    # dominant kernel: k_nuts, timed with HIP events on the library's stream
+    # dominant kernel: the sampler, timed with HIP events on the library's stream
     ms = np.array(M.sampling_ms[n_launch0:])
     ngrad = np.array(M.ngrad_log[n_launch0:])
-    n_rows = float(args.n)
-    F_g = 4.0 * n_rows * args.D + 12.0 * n_rows             # SURVEY.md §8d flops per gradient
+    n_rows = float(n)
+    F_g = 4.0 * n_rows * D + 12.0 * n_rows             # SURVEY.md §8d flops per gradient
+    B_g = n_rows * D * 8 + n_rows                      # ... and bytes swept per gradient (from LDS when resident)
     flops_per_launch = float(ngrad.mean()) * F_g
     t_kernel = float(ms.mean()) * 1e-3
     achieved_tf = flops_per_launch / t_kernel / 1e12
-    sites_local = args.sites
-    # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup: one
-    # workgroup per (site, chain) in layout 2, per site in layout 1), draws and last states out
-    wg_per_site = 1 if M.engine.last_layout() == 1 else args.chains
+    layout = M.engine.last_layout()
+    wg_per_site = args.chains if layout == 2 else 1
     P = M.engine.P
-    hbm_alg = sites_local * wg_per_site * (n_rows * args.D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
-        + sites_local * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
-    traffic = None
-    for pmc in ('r01_c2_pmc_hbm.json', 'r01_c3_pmc_hbm.json'):
-        # measured separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
-        # (scripts/profile_round.sh, scripts/profile_summarise.py)
-        pmc = os.path.join(ROOT, 'profiles', pmc)
-        if os.path.exists(pmc):
-            pj = json.load(open(pmc))
-            if pj.get('workload_key') == [args.sites, args.D, args.n, args.model, args.chains, args.siter]:
-                traffic = pj['hbm_bytes_per_launch_corrected']
-    roof = {'kernel': 'k_nuts (sampler)', 'bound': 'mfma', 'achieved': achieved_tf,
-            'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / FP64_PEAK_TFLOPS,
-            'traffic': traffic,
-            'note': 'FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
-                    'duration of the sampler launch; X is LDS resident, so HBM is not the bound: '
-                    'hbm_frac below',
-            'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
-            'hbm_algorithmic_bytes': hbm_alg,
-            'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}
-    if M.engine.last_layout() == 3:
+    # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup), draws
+    # and last states out
+    hbm_alg = sites * wg_per_site * (n_rows * D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
+        + sites * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
+    key = [sites, D, n, args.model, args.chains, args.siter]
+
+    def measured_traffic(names):
+        """HBM bytes per launch from a committed rocprofv3 --pmc run of THIS command (FETCH_SIZE x 2 +
+        WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be collected inside the timed run."""
+        for name in names:
+            path = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(path):
+                pj = json.load(open(path))
+                if pj.get('workload_key', pj.get('workload')) == key:
+                    return pj['hbm_bytes_per_launch_corrected'], 'profiles/' + name
+        return None, None
+
+    if layout == 3:
         # streaming sampler: the site rows (and the cavity precision) come from HBM once per
         # leapfrog of a workgroup's chains in lock step -> the HBM roofline is the one that binds
         passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
-        B_pass = n_rows * args.D * 8 + n_rows * 4 + M.dphi**2 * 8     # X, y (int32), Omega
+        B_pass = n_rows * D * 8 + n_rows * 4 + M.dphi**2 * 8     # X, y (int32), Omega
         hbm_alg = float(passes.mean()) * B_pass
         gbs = hbm_alg / t_kernel / 1e9
-        tr = None
-        pmc3 = os.path.join(ROOT, 'profiles', 'r01_stream_pmc_hbm.json')
-        if os.path.exists(pmc3):
-            pj = json.load(open(pmc3))
-            if pj.get('workload_key', pj.get('workload')) == [args.sites, args.D, args.n, args.model, args.chains, args.siter]:
-                tr = pj['hbm_bytes_per_launch_corrected']
+        tr, src = measured_traffic(('r02_stream_pmc_hbm.json', 'r01_stream_pmc_hbm.json'))
         roof = {'kernel': 'k_nuts_stream (sampler)', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr,
+                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'traffic_source': src,
                 'note': 'algorithmic bytes = row passes x (n D 8 + n 4 + d^2 8) over the HIP-event duration '
                         'of the sampler launch; includes the tail where few sites are still sampling',
                 'launch_ms': float(ms.mean()), 'row_passes_per_launch': float(passes.mean()),
                 'gradients_per_launch': float(ngrad.mean()),
                 'passes_max_over_mean_site': float(np.mean([p.max() / p.mean() for p in M.pass_log[n_launch0:]])),
                 'fp64_tflops': achieved_tf}
+    else:
+        tr, src = measured_traffic(('r02_%s_pmc_hbm.json' % args.config, 'r01_%s_pmc_hbm.json' % args.config))
+        lds_tbs = float(ngrad.mean()) * B_g / t_kernel / 1e12
+        roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'fp64-valu',
+                'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_source': src,
+                'note': 'FP64 vector flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
+                        'duration of the sampler launch.  The kernel issues no MFMA (a wave owns one chain: '
+                        'matrix-vector work) and X is LDS resident, so neither the matrix pipes nor HBM '
+                        'bound it: lds_frac / hbm_frac below',
+                'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
+                'lds_swept_TBps': lds_tbs, 'lds_peak_TBps': LDS_PEAK_TBS, 'lds_frac': lds_tbs / LDS_PEAK_TBS,
+                'hbm_algorithmic_bytes': hbm_alg,
+                'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}
     out = {
-        'metric': 'site-updates/sec', 'value': J * args.steps / tmax, 'unit': 'site-updates/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': tmax / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'metric': 'site-updates/sec', 'value': J * steps / tmax, 'unit': 'site-updates/s',
+        'n_gpus': world, 'steps': steps, 'warmup': warm,
+        'ms_per_step': tmax / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'ep_iters_per_sec': args.steps / tmax,
+        'ep_iters_per_sec': steps / tmax,
         'config': {'workload': 'hierarchical logistic regression %s, J=%d sites (=%d/GPU), D=%d, n_j=%d, '
                                'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s'
-                               % (args.model, J, args.sites, args.D, args.n, args.chains, args.siter,
+                               % (args.model, J, sites, D, n, args.chains, args.siter,
                                   args.chains * (args.siter - args.siter // 2), args.prec_estim,
-                                  '' if args.cor_input else ', uncorrelated covariates'),
-                   'parallelism': 'sites sharded over %d GPU(s), 1 all-reduce/iter' % world},
+                                  '' if cor else ', uncorrelated covariates'),
+                   'name': args.config if (args.sites, args.D, args.n) == (None, None, None) else 'custom',
+                   'parallelism': 'sites sharded over %d GPU(s), 1 RCCL all-reduce/iter inside libepx.so' % world,
+                   'rccl_world_size': rccl_world},
         'roofline': roof,
         'sampler_share_of_step': float(ms.sum() * 1e-3 / dt),
+        'update_phase_ms_per_step': float(np.mean(M.othertime_log[-steps:]) * 1e3),
         'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
-                                               / (sites_local * args.chains * args.siter)),
+                                               / (sites * args.chains * args.siter)),
     }
     # the launch ends with its slowest chain (one workgroup per chain) / slowest site (chains in lock step):
     # how far that is from the average, last launch of this rank
     lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
     out['launch_tail'] = {'slowest_chain_leapfrogs': float(lf.max()), 'mean_chain_leapfrogs': float(lf.mean()),
-                          'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(M.engine.last_layout()),
+                          'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(layout),
                           'lead_sites_of_a_split_launch': int(M.engine.last_split())}
-    if comm is not None:
-        tdist.destroy_process_group()
     if args.cpu_sites > 0:
         try:
-            out['cpu_baseline'] = cpu_baseline(mod, data, Q0, r0, min(args.cpu_sites, J), args.chains,
-                                               args.siter, args.cpu_threads)
+            out['cpu_baseline'] = cpu_baseline(M, mod, data, args.chains, args.siter, args.cpu_sites,
+                                               args.cpu_seq_sites, args.cpu_threads)
         except Exception as ex:                      # the baseline must not void the GPU measurement
             out['cpu_baseline'] = {'value': None, 'unit': 'site-updates/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %r' % (ex,)}
+    comm.barrier()
+    comm.close()
     print(json.dumps(out))
 
 

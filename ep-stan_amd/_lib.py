@@ -13,6 +13,8 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
 c_int_p = ctypes.POINTER(ctypes.c_int)
+COMM_ID_BYTES = 128          # EPX_COMM_ID_BYTES
+OP_SUM, OP_MIN, OP_MAX = 0, 1, 2
 
 
 class SamplerOpts(ctypes.Structure):
@@ -81,6 +83,15 @@ SIGNATURES = {
     'epx_damp_sweep': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, ctypes.c_void_p,
                                       c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p, ctypes.c_int,
                                       c_double_p]),
+    'epx_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
+    'epx_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'epx_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'epx_comm_size': (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_int_p]),
+    'epx_comm_allreduce': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int]),
+    'epx_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p]),
+    'epx_update_trial': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                        c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int,
+                                        c_int_p, c_int_p, c_int64_p, c_double_p, c_double_p]),
     'epx_set_site_order': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     'epx_set_site_split': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'epx_last_split': (ctypes.c_int, [ctypes.c_void_p]),

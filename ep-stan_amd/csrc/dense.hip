@@ -421,6 +421,23 @@ __global__ void k_axpy(double *out, const double *x, const double *dx, double df
     for (; i < n; i += stride) out[i] = x[i] + df * dx[i];
 }
 
+// flags of one damping trial as doubles, so that ONE all-reduce(min) makes them global:
+// out = [global_pd, all local cavities pd (0 when the global check failed), first failing site
+// (global index) or 1e18]
+__global__ void k_trial_flags(const uint8_t *flags, int count, int site_base, const int *global_pd, double *out) {
+    __shared__ int first;
+    if (threadIdx.x == 0) first = 0x7fffffff;
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += blockDim.x)
+        if (!flags[i]) atomicMin(&first, i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int g = *global_pd;
+        out[0] = g ? 1.0 : 0.0;
+        out[1] = (g && first == 0x7fffffff) ? 1.0 : 0.0;
+        out[2] = (g && first != 0x7fffffff) ? (double)(site_base + first) : 1e18;
+    }
+}
 __global__ void k_all_flags(const uint8_t *flags, int k0, int count, int *out /* [2]: all, first_bad */) {
     __shared__ int first;
     if (threadIdx.x == 0) first = 0x7fffffff;

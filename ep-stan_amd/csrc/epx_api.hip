@@ -12,12 +12,13 @@
 
 #include "../../include/epx.h"
 #include "epx_kernels.h"
+#include "epx_ctx.h"
 
 using namespace epx;
 
 static thread_local std::string g_err;
 
-static int fail(const char *fmt, ...) {
+int epx_fail(const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -26,66 +27,6 @@ static int fail(const char *fmt, ...) {
     g_err = buf;
     return -1;
 }
-#define HIPCHK(x)                                                                         \
-    do {                                                                                  \
-        hipError_t e_ = (x);                                                              \
-        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-static const size_t LDS_CAP = 160 * 1024;
-
-struct epx_ctx {
-    int device, model, K, D, d, P;
-    int64_t N;
-    hipStream_t stream;
-    std::vector<int64_t> k_lim;
-    // multi-group sites (K < J): groups per site, device copies of the prefix sums / row limits
-    std::vector<int> g_cnt;
-    int *site_g0_d;
-    int64_t *g_lim_d;
-    int multi, ng_max, nt_max, pg;
-    int n_max;
-    // device buffers
-    int64_t *k_lim_d;
-    double *X;
-    uint8_t *y;
-    int *y32;
-    double *yd;                     // real responses (Gaussian-likelihood family), else NULL
-    int gauss;
-    double *Q0, *r0, *Q, *r, *S, *m;
-    double *Qi, *ri, *Qi2, *ri2, *dQi, *dri;
-    double *cav_Om, *cav_mu;
-    double *tilt_mean, *tilt_scatter;
-    uint8_t *flags;
-    int *iflags;              // [4]
-    double *packed, *partial; // sums
-    int nslice;
-    double *dense_ws;         // global workspace for dense kernels (lazily sized)
-    size_t dense_ws_slots;
-    // sampler buffers (lazily sized)
-    int s_chains, s_nkeep;
-    double *draws, *last, *chain_stats, *site_stats, *stack;
-    size_t stack_elems;
-    int64_t *seeds_d;
-    double *dbg;              // [1+P] lp, grad ; [P] theta (test hook)
-    int64_t *dbg_seed;
-    double *inj;              // injected samples (test hook)
-    size_t inj_elems;
-    int has_last;
-    int nsamp;                // draws per site of the last tilted/moments call
-    double last_df;
-    hipEvent_t ev0, ev1;
-    hipStream_t stream2;            // second queue of a split sampling launch (epx_set_site_split)
-    hipEvent_t ev_fork, ev_join;
-    int split_n, last_split, n_cu;
-    unsigned long long *stamps;
-    size_t stamps_n, stamps_last;
-    int last_layout;
-    int *order_d;
-    int order_n;
-    double *sweep_buf;        // damping sweep: target block + ndf x 5 criteria
-    size_t sweep_elems;
-};
 
 const char *epx_last_error(void) { return g_err.c_str(); }
 
@@ -112,12 +53,10 @@ int epx_model_dims(int model, int D, int *dphi, int *npar) {
     return 0;
 }
 
-template <typename T>
-static hipError_t dalloc(T **p, size_t n) {
-    *p = nullptr;
-    if (n == 0) n = 1;
-    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
-}
+// room behind the packed site sums for the statistics that ride on the same all-reduce
+// (epx_update_trial: 8 sums + 8 maxima x up to 120 ranks) and the three trial flags
+enum { STAT_CAP = 8, PACKED_EXTRA = 1024 };
+int epx_comm_allreduce_dev(epx_ctx *c, double *buf, size_t n, int op);      // epx_comm.hip
 
 static inline int ld_of(int d) { return d | 1; }
 static inline size_t dense_slot_doubles(int d) { return 2 * (size_t)d * ld_of(d) + 4 * (size_t)ld_of(d); }
@@ -280,11 +219,14 @@ static int ctx_create(int device, int model, int K_local, int D, const int64_t *
     HIPCHK(dalloc(&c->tilt_mean, K * d)); HIPCHK(dalloc(&c->tilt_scatter, K * d2));
     HIPCHK(dalloc(&c->flags, K));
     HIPCHK(dalloc(&c->iflags, 4));
+    HIPCHK(dalloc(&c->min_eig, K));
+    HIPCHK(dalloc(&c->err_flag, 4));
+    HIPCHK(hipMemset(c->err_flag, 0, 4 * sizeof(int)));
     HIPCHK(dalloc(&c->dbg, 2 * (size_t)c->P + 1));
     HIPCHK(dalloc(&c->dbg_seed, 1));
     const int len = 2 * (int)(d2 + d);
     c->nslice = K_local >= 64 ? 32 : 1;
-    HIPCHK(dalloc(&c->packed, len));
+    HIPCHK(dalloc(&c->packed, (size_t)len + PACKED_EXTRA));
     HIPCHK(dalloc(&c->partial, (size_t)len * c->nslice));
     HIPCHK(hipMemcpy(c->k_lim_d, k_lim, (K + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->X, X, (size_t)c->N * D * sizeof(double), hipMemcpyHostToDevice));
@@ -318,7 +260,8 @@ static int ctx_create(int device, int model, int K_local, int D, const int64_t *
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    if (c->comm) (void)epx_comm_destroy(c);
+    void *ptrs[] = {c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -332,10 +275,6 @@ int epx_ctx_destroy(epx_ctx *c) {
     delete c;
     return 0;
 }
-
-#define CTX(c)                                      \
-    if (!(c)) return fail("null context");          \
-    HIPCHK(hipSetDevice((c)->device));
 
 int epx_set_prior(epx_ctx *c, const double *Q0, const double *r0) {
     CTX(c);
@@ -999,6 +938,60 @@ int epx_damped_trial(epx_ctx *c, double df, const double *packed_host, const dou
     return 0;
 }
 
+int epx_update_trial(epx_ctx *c, double df, int reduce_sums, int site_base, double *stat_sum, int n_sum,
+                     double *stat_max, int n_max, int want_moments, int *global_pd, int *cav_pd,
+                     int64_t *first_bad, double *S, double *m) {
+    CTX(c);
+    if (n_sum < 0 || n_sum > STAT_CAP || n_max < 0 || n_max > STAT_CAP) return fail("at most %d statistics of a kind", STAT_CAP);
+    const int nr = c->comm ? c->comm_size : 1, rank = c->comm ? c->comm_rank : 0;
+    const int len = 2 * (c->d * c->d + c->d);
+    const int next = n_sum + n_max * nr;
+    if (next + 3 > PACKED_EXTRA) return fail("too many ranks (%d) for the statistics block", nr);
+    double *ext_d = c->packed + len, *trial_d = c->packed + len + PACKED_EXTRA - 3;
+    std::vector<double> ext((size_t)next + 1, 0.0);
+    if (reduce_sums) {
+        // statistics of this rank: sums as they are, maxima in the rank's own slots (the others stay 0,
+        // so the sum over ranks is an all-gather and the maximum is taken on the host)
+        for (int i = 0; i < n_sum; ++i) ext[i] = stat_sum[i];
+        for (int i = 0; i < n_max; ++i) ext[n_sum + (size_t)rank * n_max + i] = stat_max[i];
+        if (next) HIPCHK(hipMemcpyAsync(ext_d, ext.data(), (size_t)next * 8, hipMemcpyHostToDevice, c->stream));
+        SumArgs a;
+        a.K = c->K; a.d = c->d; a.len = len; a.nslice = c->nslice;
+        a.Qi = c->Qi; a.ri = c->ri; a.dQi = c->dQi; a.dri = c->dri;
+        a.partial = c->partial; a.out = c->packed;
+        const int nb = (a.len + 255) / 256;
+        hipLaunchKernelGGL(k_site_sums_partial, dim3(nb, a.nslice), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_site_sums_final, dim3(nb), dim3(256), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+        // the ONE reduction of the iteration (method.py:1073-1074; affine in df, so it serves every trial)
+        if (epx_comm_allreduce_dev(c, c->packed, (size_t)len + next, EPX_OP_SUM)) return -1;
+    }
+    c->last_df = df;
+    if (launch_global(c, c->packed, df, want_moments)) return -1;
+    if (launch_cavity(c, c->Qi, c->ri, c->dQi, c->dri, df, 0, c->K)) return -1;
+    hipLaunchKernelGGL(k_trial_flags, dim3(1), dim3(256), 0, c->stream, c->flags, c->K, site_base, c->iflags, trial_d);
+    HIPCHK(hipGetLastError());
+    if (epx_comm_allreduce_dev(c, trial_d, 3, EPX_OP_MIN)) return -1;
+    double tf[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(tf, trial_d, sizeof tf, hipMemcpyDeviceToHost, c->stream));
+    if (reduce_sums && next) HIPCHK(hipMemcpyAsync(ext.data(), ext_d, (size_t)next * 8, hipMemcpyDeviceToHost, c->stream));
+    if (want_moments && S) HIPCHK(hipMemcpyAsync(S, c->S, (size_t)c->d * c->d * 8, hipMemcpyDeviceToHost, c->stream));
+    if (want_moments && m) HIPCHK(hipMemcpyAsync(m, c->m, (size_t)c->d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));           // the one synchronisation of the trial
+    *global_pd = tf[0] != 0.0;
+    *cav_pd = tf[1] != 0.0;
+    if (first_bad) *first_bad = tf[2] >= 1e17 ? -1 : (int64_t)tf[2];
+    if (reduce_sums) {
+        for (int i = 0; i < n_sum; ++i) stat_sum[i] = ext[i];
+        for (int i = 0; i < n_max; ++i) {
+            double v = ext[n_sum + i];
+            for (int r = 1; r < nr; ++r) v = std::fmax(v, ext[n_sum + (size_t)r * n_max + i]);
+            stat_max[i] = v;
+        }
+    }
+    return 0;
+}
+
 int epx_damp_sweep(epx_ctx *c, int ndf, const double *dfs, const double *packed_host, const double *packed_dev,
                    const double *m_target, const double *S_target, double half_logdet_S_target,
                    const double *samp_mean, const double *samp_scatter, int n_samp, double *out) {
@@ -1047,7 +1040,8 @@ int epx_accept(epx_ctx *c, double df) {
     hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, c->stream, c->Qi, c->Qi, c->dQi, df, K * d * d);
     hipLaunchKernelGGL(k_axpy, dim3(64), dim3(256), 0, c->stream, c->ri, c->ri, c->dri, df, K * d);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // no synchronisation: every later use is ordered behind it on the context's stream (the
+    // synchronous copies of the accessors run on the legacy default stream, which waits for it)
     return 0;
 }
 
@@ -1070,7 +1064,7 @@ int epx_force_pd(epx_ctx *c, double df, double thresh, double min_eig_target, ui
     size_t lds;
     if (dense_ws(c, c->d, c->K, &a.ws, &lds)) return -1;
     a.Qi = c->Qi; a.dQi = c->dQi; a.df = df; a.thresh = thresh; a.target = min_eig_target;
-    a.forced = c->flags; a.min_eig = c->tilt_mean;     // tilt_mean reused as scratch (K doubles <= K*d)
+    a.forced = c->flags; a.min_eig = c->min_eig;
     if (set_lds(k_force_pd, lds)) return -1;
     hipLaunchKernelGGL(k_force_pd, dim3(c->K), dim3(256), lds, c->stream, a);
     HIPCHK(hipGetLastError());
@@ -1099,7 +1093,16 @@ static int need_device(int device) {
     return 0;
 }
 
+// the stand-alone entry points run on the device they are given and leave the calling thread's
+// current device as they found it (a rank of a multi-GPU job keeps its own GPU current)
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int epx_invert_normal_params(int device, int d, int nb, double *A, double *b, int cho_form, int32_t *info) {
+    DeviceGuard guard;
     if (need_device(device)) return -1;
     if (d < 1 || nb < 1) return fail("bad sizes");
     InvertArgs a;
@@ -1124,6 +1127,7 @@ int epx_invert_normal_params(int device, int d, int nb, double *A, double *b, in
 }
 
 int epx_olse(int device, int d, int nb, double *S, int n, const double *P, int32_t *info) {
+    DeviceGuard guard;
     if (need_device(device)) return -1;
     if (d < 1 || nb < 1) return fail("bad sizes");
     OlseArgs a;
@@ -1148,6 +1152,7 @@ int epx_olse(int device, int d, int nb, double *S, int n, const double *P, int32
 
 int epx_rng_probe(int device, uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a, uint32_t b,
                   double *out4) {
+    DeviceGuard guard;
     if (need_device(device)) return -1;
     double *od;
     HIPCHK(dalloc(&od, 4));

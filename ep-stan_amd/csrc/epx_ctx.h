@@ -1,0 +1,94 @@
+// Private to libepx.so: the context behind the opaque epx_ctx of include/epx.h, shared by
+// epx_api.hip (entry points) and epx_comm.hip (the in-library RCCL binding).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/epx.h"
+
+// error message kept per thread, returned by epx_last_error(); always returns -1
+int epx_fail(const char *fmt, ...);
+#define fail epx_fail
+
+#define HIPCHK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define CTX(c)                                      \
+    if (!(c)) return fail("null context");          \
+    HIPCHK(hipSetDevice((c)->device));
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+}
+
+static const size_t LDS_CAP = 160 * 1024;
+
+struct epx_ctx {
+    int device, model, K, D, d, P;
+    int64_t N;
+    hipStream_t stream;
+    std::vector<int64_t> k_lim;
+    // multi-group sites (K < J): groups per site, device copies of the prefix sums / row limits
+    std::vector<int> g_cnt;
+    int *site_g0_d;
+    int64_t *g_lim_d;
+    int multi, ng_max, nt_max, pg;
+    int n_max;
+    // device buffers
+    int64_t *k_lim_d;
+    double *X;
+    uint8_t *y;
+    int *y32;
+    double *yd;                     // real responses (Gaussian-likelihood family), else NULL
+    int gauss;
+    double *Q0, *r0, *Q, *r, *S, *m;
+    double *Qi, *ri, *Qi2, *ri2, *dQi, *dri;
+    double *cav_Om, *cav_mu;
+    double *tilt_mean, *tilt_scatter;
+    uint8_t *flags;
+    int *iflags;              // [4]
+    double *packed, *partial; // sums
+    int nslice;
+    double *dense_ws;         // global workspace for dense kernels (lazily sized)
+    size_t dense_ws_slots;
+    // sampler buffers (lazily sized)
+    int s_chains, s_nkeep;
+    double *draws, *last, *chain_stats, *site_stats, *stack;
+    size_t stack_elems;
+    int64_t *seeds_d;
+    double *dbg;              // [1+P] lp, grad ; [P] theta (test hook)
+    int64_t *dbg_seed;
+    double *inj;              // injected samples (test hook)
+    size_t inj_elems;
+    int has_last;
+    int nsamp;                // draws per site of the last tilted/moments call
+    double last_df;
+    hipEvent_t ev0, ev1;
+    hipStream_t stream2;            // second queue of a split sampling launch (epx_set_site_split)
+    hipEvent_t ev_fork, ev_join;
+    int split_n, last_split, n_cu;
+    unsigned long long *stamps;
+    size_t stamps_n, stamps_last;
+    int last_layout;
+    int *order_d;
+    int order_n;
+    double *sweep_buf;        // damping sweep: target block + ndf x 5 criteria
+    size_t sweep_elems;
+    double *min_eig;          // force-pd fallback: smallest eigenvalue per site (K)
+    // in-library RCCL binding (epx_comm.hip); comm == nullptr: single rank
+    void *comm;               // ncclComm_t
+    int comm_rank, comm_size;
+    double *comm_stage;       // device staging of the small host-side collectives
+    size_t comm_stage_n;
+    int *err_flag;            // device word the sampler kernels set when a hand-off spin gives up
+};
+

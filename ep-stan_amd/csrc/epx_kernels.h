@@ -91,6 +91,7 @@ __global__ void k_axpy(double *out, const double *x, const double *dx, double df
 __global__ void k_mix_partial(SumArgs a);
 __global__ void k_sweep_flag(const int *all_flag, double *crit);
 __global__ void k_all_flags(const uint8_t *flags, int k0, int count, int *out);
+__global__ void k_trial_flags(const uint8_t *flags, int count, int site_base, const int *global_pd, double *out);
 __global__ void k_invert(InvertArgs a);
 __global__ void k_olse(OlseArgs a);
 __global__ void k_force_pd(ForceArgs a);

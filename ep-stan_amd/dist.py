@@ -1,9 +1,20 @@
 """Multi-GPU plumbing: contiguous site sharding + the one all-reduce per EP
-iteration.  torch.distributed is used as transport only
-(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+iteration.
+
+`EpxComm` is the product path: RCCL inside libepx.so (epx_comm_init, include/epx.h), the
+reduction of /root/reference/epstan/method.py:1073-1074 running on the engine's own HIP
+stream.  `TorchComm` moves host buffers through an already initialised torch.distributed
+group (gloo in the CPU tests); `LocalComm` is the single-process identity.
 """
 
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+from . import _lib
 
 
 def site_range(K, rank, world):
@@ -15,6 +26,7 @@ class LocalComm(object):
     """Single process: every collective is the identity."""
     rank = 0
     world = 1
+    native = True            # the engine's fused update (epx_update_trial) covers it
 
     def allreduce_sum(self, x):
         return x
@@ -32,8 +44,147 @@ class LocalComm(object):
         pass
 
 
+def _gather_layout(local, K, world):
+    lead = local.shape[:-1]
+    per = int(np.prod(lead)) if lead else 1
+    counts = [site_range(K, r, world) for r in range(world)]
+    kmax = max(hi - lo for lo, hi in counts)
+    buf = np.zeros(per * kmax)
+    flat = np.asarray(local).reshape(-1, order='F')
+    buf[:flat.shape[0]] = flat
+    return lead, per, counts, kmax, buf
+
+
+def _scatter_gathered(parts, lead, per, counts, K):
+    full = np.empty(lead + (K,), order='F')
+    for (lo, hi), part in zip(counts, parts):
+        full[..., lo:hi] = part[:per * (hi - lo)].reshape(lead + (hi - lo,), order='F')
+    return full
+
+
+class EpxComm(object):
+    """RCCL communicator held by libepx.so: one process per GPU, sites sharded over the ranks.
+
+    Rank and world size default to torchrun's environment (RANK / WORLD_SIZE).  The 128-byte
+    RCCL id goes from rank 0 to the others over a plain TCP connection to
+    MASTER_ADDR:(EPX_COMM_PORT or MASTER_PORT + 23) -- no torch.distributed involved.
+    `Master` binds the communicator to its engine (`bind`, collective over all ranks)."""
+    native = True
+
+    def __init__(self, rank=None, world=None, addr=None, port=None):
+        env = os.environ
+        self.rank = int(env.get('RANK', '0')) if rank is None else int(rank)
+        self.world = int(env.get('WORLD_SIZE', '1')) if world is None else int(world)
+        self.addr = addr or env.get('MASTER_ADDR', '127.0.0.1')
+        if port is None:
+            port = int(env['EPX_COMM_PORT']) if 'EPX_COMM_PORT' in env else int(env.get('MASTER_PORT', '29500')) + 23
+        self.port = int(port)
+        self.engine = None
+        if not 0 <= self.rank < self.world:
+            raise ValueError('rank {} outside 0..{}'.format(self.rank, self.world - 1))
+
+    # ---- bootstrap
+    def _exchange_id(self, uid):
+        """Rank 0 serves `uid` to every other rank; the others fetch it (retrying while rank 0
+        is not listening yet)."""
+        n = _lib.COMM_ID_BYTES
+        if self.world == 1:
+            return uid
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((self.addr, self.port))
+            srv.listen(self.world)
+            srv.settimeout(300.0)
+            try:
+                seen = set()
+                while len(seen) < self.world - 1:
+                    conn, _ = srv.accept()
+                    with conn:
+                        conn.settimeout(60.0)
+                        peer = struct.unpack('<i', _recv_exact(conn, 4))[0]
+                        conn.sendall(uid)
+                        seen.add(peer)
+            finally:
+                srv.close()
+            return uid
+        deadline = time.time() + 300.0
+        while True:
+            try:
+                with socket.create_connection((self.addr, self.port), timeout=10.0) as conn:
+                    conn.sendall(struct.pack('<i', self.rank))
+                    return _recv_exact(conn, n)
+            except (ConnectionRefusedError, ConnectionResetError, socket.timeout, OSError):
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.05)
+
+    def bind(self, engine):
+        """Create the RCCL communicator of `engine`'s context (collective)."""
+        import ctypes
+        lib = _lib.load()
+        if not hasattr(engine, 'ctx'):
+            raise TypeError('EpxComm needs the HIP engine (a context of libepx.so)')
+        uid = b''
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(lib.epx_comm_unique_id(buf))
+            uid = buf.raw
+        uid = self._exchange_id(uid)
+        _lib.check(lib.epx_comm_init(engine.ctx, uid, self.rank, self.world))
+        self.engine = engine
+        return self
+
+    def size(self):
+        """(rank, number of ranks) as RCCL reports them for the bound communicator."""
+        return self.engine.comm_size()
+
+    def close(self):
+        if self.engine is not None and getattr(self.engine, 'ctx', None):
+            _lib.load().epx_comm_destroy(self.engine.ctx)
+        self.engine = None
+
+    # ---- host-side collectives (small; the per-iteration reduction itself is inside epx_update_trial)
+    def _reduce(self, arr, op):
+        a = np.ascontiguousarray(arr, dtype=np.float64).copy()
+        if a.size:
+            self.engine.comm_allreduce(a.reshape(-1), op)
+        return a
+
+    def allreduce_sum(self, x):
+        x[...] = self._reduce(x, _lib.OP_SUM).reshape(x.shape)
+        return x
+
+    def allreduce_min_int(self, v):
+        return int(self._reduce(np.array([float(int(v))]), _lib.OP_MIN)[0])
+
+    def allreduce_max(self, arr):
+        return self._reduce(np.asarray(arr, dtype=np.float64), _lib.OP_MAX)
+
+    def allgather_sites(self, local, K):
+        """local: F-ordered (..., K_local) slice; returns the full (..., K) array."""
+        lead, per, counts, kmax, buf = _gather_layout(local, K, self.world)
+        out = self.engine.comm_allgather(buf, self.world)
+        return _scatter_gathered([out[r] for r in range(self.world)], lead, per, counts, K)
+
+    def barrier(self):
+        self._reduce(np.zeros(1), _lib.OP_SUM)
+
+
+def _recv_exact(conn, n):
+    buf = b''
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionResetError('peer closed the id exchange')
+        buf += chunk
+    return buf
+
+
 class TorchComm(object):
-    """torch.distributed process group wrapper (already initialised by the caller)."""
+    """Host buffers through a torch.distributed process group that the caller initialised
+    (gloo in the CPU tests; any backend works, device tensors are not involved)."""
+    native = False
 
     def __init__(self, group=None, device=None):
         import torch
@@ -43,7 +194,7 @@ class TorchComm(object):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.device = device      # torch.device of this rank's GPU (None on CPU/gloo)
+        self.device = device      # staging device of the collectives (None: host tensors, gloo)
 
     def _small(self, arr):
         t = self.torch.as_tensor(np.ascontiguousarray(arr))
@@ -52,13 +203,9 @@ class TorchComm(object):
         return t
 
     def allreduce_sum(self, x):
-        """x: CUDA torch tensor (reduced in place over RCCL) or NumPy array."""
-        if isinstance(x, np.ndarray):
-            t = self._small(x)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            x[...] = t.cpu().numpy()
-            return x
-        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
+        t = self._small(x)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        x[...] = t.cpu().numpy()
         return x
 
     def allreduce_min_int(self, v):
@@ -73,21 +220,11 @@ class TorchComm(object):
 
     def allgather_sites(self, local, K):
         """local: F-ordered (..., K_local) slice; returns the full (..., K) array."""
-        lead = local.shape[:-1]
-        per = int(np.prod(lead)) if lead else 1
-        counts = [site_range(K, r, self.world) for r in range(self.world)]
-        kmax = max(hi - lo for lo, hi in counts)
-        buf = np.zeros(per * kmax)
-        flat = np.asarray(local).reshape(-1, order='F')
-        buf[:flat.shape[0]] = flat
+        lead, per, counts, kmax, buf = _gather_layout(local, K, self.world)
         t = self._small(buf)
         outs = [self.torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t, group=self.group)
-        full = np.empty(lead + (K,), order='F')
-        for r, (lo, hi) in enumerate(counts):
-            part = outs[r].cpu().numpy()[:per * (hi - lo)]
-            full[..., lo:hi] = part.reshape(lead + (hi - lo,), order='F')
-        return full
+        return _scatter_gathered([o.cpu().numpy() for o in outs], lead, per, counts, K)
 
     def barrier(self):
         self.dist.barrier(group=self.group)

@@ -103,7 +103,6 @@ class HipEngine(object):
         n = ctypes.c_int()
         check(self.lib.epx_packed_len(self.ctx, ctypes.byref(n)))
         self.packed_len = n.value
-        self._packed = None
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -308,38 +307,64 @@ class HipEngine(object):
         """util.invert_normal_params on this engine's device (new arrays)."""
         from . import util
         return util.invert_normal_params(np.asfortranarray(A, dtype=np.float64),
-                                         np.asarray(b, dtype=np.float64))
+                                         np.asarray(b, dtype=np.float64), device=self.device)
 
     # ---- global update
-    def site_sums(self, out_tensor=None):
-        """Packed [sum Qi, sum ri, sum dQi, sum dri] of the local sites.
-
-        With a CUDA/HIP torch tensor the sums are written in place on the
-        device (for the RCCL all-reduce); otherwise a NumPy array is returned."""
-        if out_tensor is not None:
-            assert out_tensor.is_cuda and out_tensor.numel() == self.packed_len
-            check(self.lib.epx_site_sums(self.ctx, None, ctypes.c_void_p(out_tensor.data_ptr())))
-            return out_tensor
+    def site_sums(self):
+        """Packed [sum Qi, sum ri, sum dQi, sum dri] of the local sites (NumPy array)."""
         out = np.zeros(self.packed_len)
         check(self.lib.epx_site_sums(self.ctx, dptr(out), None))
         return out
 
-    def damped_trial(self, df, packed):
-        """packed: NumPy array (host) or CUDA torch tensor (device)."""
+    def damped_trial(self, df, packed=None):
+        """One damping trial from host-side packed sums (None: the sums the device holds)."""
         g, c, fb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        if isinstance(packed, np.ndarray):
+        if packed is not None:
             packed = np.ascontiguousarray(packed, dtype=np.float64)
-            check(self.lib.epx_damped_trial(self.ctx, float(df), dptr(packed), None,
-                                            ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb)))
-        else:
-            check(self.lib.epx_damped_trial(self.ctx, float(df), None,
-                                            ctypes.c_void_p(packed.data_ptr()),
-                                            ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb)))
+        check(self.lib.epx_damped_trial(self.ctx, float(df), dptr(packed), None,
+                                        ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb)))
         return bool(g.value), bool(c.value), fb.value
+
+    def update_trial(self, df, reduce_sums, site_base=0, stat_sum=(), stat_max=(), want_moments=False):
+        """One damping trial as one stream-ordered batch (epx_update_trial, include/epx.h): site
+        sums + all-reduce over the engine's communicator (with `reduce_sums`), global check,
+        cavities, flags reduced over the ranks, one synchronisation.  Returns
+        (global_pd, cav_pd, first_bad, stat_sum, stat_max, S, m); S, m are None without
+        `want_moments`."""
+        ss = np.array(stat_sum, dtype=np.float64).reshape(-1)
+        sm = np.array(stat_max, dtype=np.float64).reshape(-1)
+        g, c, fb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        S = m = None
+        if want_moments:
+            S = np.empty((self.d, self.d), order='F')
+            m = np.empty(self.d)
+        check(self.lib.epx_update_trial(
+            self.ctx, float(df), 1 if reduce_sums else 0, int(site_base),
+            dptr(ss) if ss.size else None, int(ss.size), dptr(sm) if sm.size else None, int(sm.size),
+            1 if want_moments else 0, ctypes.byref(g), ctypes.byref(c), ctypes.byref(fb), dptr(S), dptr(m)))
+        return bool(g.value), bool(c.value), int(fb.value), ss, sm, S, m
+
+    # ---- the engine's communicator (dist.EpxComm binds it)
+    def comm_size(self):
+        r, n = ctypes.c_int(), ctypes.c_int()
+        check(self.lib.epx_comm_size(self.ctx, ctypes.byref(r), ctypes.byref(n)))
+        return r.value, n.value
+
+    def comm_allreduce(self, buf, op):
+        assert buf.dtype == np.float64 and buf.flags['C_CONTIGUOUS']
+        check(self.lib.epx_comm_allreduce(self.ctx, dptr(buf), int(buf.size), int(op)))
+        return buf
+
+    def comm_allgather(self, buf, world):
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        out = np.empty((world, buf.size))
+        check(self.lib.epx_comm_allgather(self.ctx, dptr(buf), int(buf.size), dptr(out)))
+        return out
 
     def damp_sweep(self, damps, packed, m_target, S_target, samp_target=None):
         """Score every damping factor of `damps` (find_damp.py:146-173) -> (ndf, 5) array
-        [global_pd, cav_pd (this rank's sites), mse, kl, ll]; criteria NaN unless both flags hold."""
+        [global_pd, cav_pd (this rank's sites), mse, kl, ll]; criteria NaN unless both flags hold.
+        packed: the all-reduced site sums (host array), or None for the ones the device holds."""
         damps = np.ascontiguousarray(damps, dtype=np.float64)
         m_t = np.ascontiguousarray(m_target, dtype=np.float64)
         S_t = np.asfortranarray(S_target, dtype=np.float64)
@@ -353,12 +378,8 @@ class HipEngine(object):
             c = samp - xm
             xs = np.asfortranarray(c.T.dot(c))
         out = np.zeros((damps.shape[0], 5))
-        host = dev = None
-        if isinstance(packed, np.ndarray):
-            host = dptr(np.ascontiguousarray(packed, dtype=np.float64))
-        elif packed is not None:
-            dev = ctypes.c_void_p(packed.data_ptr())
-        check(self.lib.epx_damp_sweep(self.ctx, int(damps.shape[0]), dptr(damps), host, dev, dptr(m_t), dptr(S_t),
+        host = None if packed is None else dptr(np.ascontiguousarray(packed, dtype=np.float64))
+        check(self.lib.epx_damp_sweep(self.ctx, int(damps.shape[0]), dptr(damps), host, None, dptr(m_t), dptr(S_t),
                                       half_logdet, dptr(xm) if xm is not None else None,
                                       dptr(xs) if xs is not None else None, int(ns), dptr(out)))
         return out

@@ -11,13 +11,13 @@ every numerical step runs on the GPU through libepx.so:
   for k: Worker.tilted -> Stan subprocess (:1005)   ONE batched NUTS kernel over all sites
   mean / dgeqrf / potri per site (:413-437)         batched scatter(MFMA f64)+Cholesky kernel
   Qi2 = Qi + df dQi ; Q = sum_k Qi2 + Q0 (:1071)    site sums once per iteration (affine in df)
-                                                    + one all-reduce across GPUs
-  cho_factor(Q) (:1080), for k: Worker.cavity       one small kernel + one batched cavity kernel
-  invert_normal_params(cho_Q, r) (:1215)            one small kernel
+                                                    + one RCCL all-reduce across GPUs
+  cho_factor(Q) (:1080), for k: Worker.cavity       one small kernel + one batched cavity kernel,
+  invert_normal_params(cho_Q, r) (:1215)            queued behind the all-reduce, one host sync
 
 The host mirrors (`master.Qi` ...) are refreshed when `run` returns; inside `run`
 the device copies are authoritative.  Sites are sharded contiguously over the
-ranks of an optional torch.distributed group (`comm=`).
+ranks of an optional communicator (`comm=dist.EpxComm()`: RCCL inside libepx.so).
 """
 
 __all__ = ['Worker', 'Master']
@@ -31,6 +31,7 @@ from numpy.linalg import LinAlgError
 
 from . import dist as _dist
 from . import engine as _engine
+from . import site_params as _site_params
 from .seeds import MAX_UINT, run_seeds, stan_seed, stan_seeds
 from .util import invert_normal_params
 
@@ -48,6 +49,21 @@ def _model_name(site_model):
     return base
 
 
+def _sort_keywords(given, tables, unknown):
+    """Distribute keyword arguments over option tables.
+
+    `tables` is a sequence of dicts of defaults; returns one dict per table holding the
+    table's keys with the given value or the default.  A keyword that no table knows raises
+    TypeError with the message `unknown` (formatted with the keyword)."""
+    known = set()
+    for table in tables:
+        known.update(table)
+    for kw in given:
+        if kw not in known:
+            raise TypeError(unknown.format(kw))
+    return [dict((kw, given.get(kw, default)) for kw, default in table.items()) for table in tables]
+
+
 class Worker(object):
     """Per-site state and the per-site entry points `cavity` / `tilted`.
 
@@ -55,6 +71,11 @@ class Worker(object):
     (method.py:121-265).  `Mat`/`vec` hold the cavity precision / MEAN after
     `cavity` (phase 1) and the unnormalised scatter matrix / tilted mean after
     `tilted` (phase 2); they are fetched from the device on access.
+
+    `last_time` is the device time of the sampling launch the site took part in: inside
+    `Master.run` all sites of a rank are sampled by ONE launch, so every worker of the rank
+    reports the same value (the reference reports each site's own Stan time; their maximum,
+    which is what `run` records in `stimes`, has the same meaning in both).
     """
 
     DEFAULT_OPTIONS = {
@@ -77,52 +98,37 @@ class Worker(object):
     RESERVED_STAN_PARAMETER_NAMES = ['X', 'y', 'N', 'D', 'mu_phi', 'Omega_phi']
 
     def __init__(self, index, stan_model, dphi, X, y, A=None, _master=None, **options):
-        for (kw, default) in self.DEFAULT_OPTIONS.items():
-            if kw not in options:
-                options[kw] = default
-        for (kw, default) in self.DEFAULT_STAN_PARAMS.items():
-            if kw not in options:
-                options[kw] = default
-        self.stan_params = {}
-        for (kw, val) in options.items():
-            if kw in self.DEFAULT_STAN_PARAMS:
-                self.stan_params[kw] = val
-            elif kw not in self.DEFAULT_OPTIONS:
-                raise TypeError("Unexpected option '{}'".format(kw))
-        if A is None:
-            A = {}
-        self._Mat = np.zeros((dphi, dphi), order='F')
-        self._vec = np.zeros(dphi)
-        self._stale = False
-        self.phase = 0
-        self.nsamp = None
-        self.Q = None
-        self.r = None
-        self.data = dict(N=X.shape[0], X=X, y=y, **A)
-        if len(X.shape) == 2:
-            self.data['D'] = X.shape[1]
-        self.index = index
-        self.stan_model = stan_model
-        self.dphi = dphi
-        self.iteration = 0
-        self.last_time = None
-        self.last_msteps = None
-        self.last_mrhat = None
-        self.saved_samples = None
-        self.init_prev = options['init_prev']
+        opt, sampler = _sort_keywords(options, (self.DEFAULT_OPTIONS, self.DEFAULT_STAN_PARAMS),
+                                      "Unexpected option '{}'")
+        # sampler settings first: `init_prev` constrains `init`
+        self.stan_params = sampler
+        self.init_prev = opt['init_prev']
         if self.init_prev:
-            self.init_orig = self.stan_params['init']
+            self.init_orig = sampler['init']
             if not isinstance(self.init_orig, str):
                 raise ValueError("Arg. `init` has to be a string if "
                                  "`init_prev` is True")
-        self.prec_estim = options['prec_estim']
+        self.prec_estim = opt['prec_estim']
         if self.prec_estim not in self.PREC_ESTIM_OPTIONS:
             raise ValueError("Invalid value for option `prec_estim`")
-        if self.prec_estim != 'sample':
-            self.prec_estim_skip = options['prec_estim_skip']
-        else:
-            self.prec_estim_skip = 0
-        self.verbose = options['verbose']
+        self.prec_estim_skip = opt['prec_estim_skip'] if self.prec_estim != 'sample' else 0
+        self.verbose = opt['verbose']
+
+        self.index = index
+        self.stan_model = stan_model
+        self.dphi = dphi
+        self.data = dict(N=X.shape[0], X=X, y=y, **(A or {}))
+        if X.ndim == 2:
+            self.data['D'] = X.shape[1]
+        self.phase = 0
+        self.iteration = 0
+        self.nsamp = None
+        self.Q = self.r = None
+        self.last_time = self.last_msteps = self.last_mrhat = None
+        self.saved_samples = None
+        self._Mat = np.zeros((dphi, dphi), order='F')
+        self._vec = np.zeros(dphi)
+        self._stale = False
         # binding to the device engine (a stand-alone Worker owns a 1-site engine)
         self._master = _master
         self._eng = None
@@ -194,10 +200,22 @@ class Worker(object):
             self._stale = False
         return ok
 
+    def _save_named(self, names):
+        """`saved_samp = {name: draws}` for the requested parameter names (method.py:387-392)."""
+        eng = self._eng
+        theta = eng.get_draws(self._k, all_params=True)
+        ng = 1 if eng.g_cnt is None else int(eng.g_cnt[self._k])
+        mid = _engine.MODEL_IDS[eng.model] % 5
+        self.saved_samp = _site_params.named_draws(
+            mid, eng.D, ng, _engine.is_gauss(eng.model), eng.model.endswith('_sg'), theta, list(names))
+
     def tilted(self, dQi, dri, save_samples=None, seed=None):
         """Estimate the tilted distribution and write the site parameter update
         into `dQi`, `dri` (method.py:305-475).  Returns False if the precision
-        estimate is not positive definite (then dQi, dri are zero)."""
+        estimate is not positive definite (then dQi, dri are zero).
+
+        `save_samples`: parameter names of the site model whose draws are kept in
+        `self.saved_samp` (chain-major, not permuted)."""
         if self.phase != 1:
             raise RuntimeError('Cavity has to be calculated before tilted.')
         if self._eng is None:
@@ -219,13 +237,15 @@ class Worker(object):
                 np.array([self.stan_params['seed']]), self._sampler_opts(), self._cur_estim(),
                 k0=self._k, count=1)
             ok = bool(flags[0])
+            if stats[0, 7] > 0:
+                ok = self._void_update()
             self.last_time = ms * 1e-3
             self.last_msteps = stats[0, 0]
             self.last_mrhat = stats[0, 1]
             lastsamp = 'prev'
             self._has_sampled = True
             if save_samples:
-                self.saved_samp = {'phi': self._eng.get_draws(self._k)}
+                self._save_named(save_samples)
         if self.verbose:
             print('\n   sampling runtime: {:.4}'.format(self.last_time))
             print('    mean stepsize: {:.4}'.format(self.last_msteps))
@@ -237,6 +257,13 @@ class Worker(object):
         dQi[...] = dQ
         dri[...] = dr
         return ok
+
+    def _void_update(self):
+        """A chain of this site started at a non-finite density (its draws are its initial point):
+        the site update is dropped like a failed precision estimate (method.py:462-475)."""
+        d = self.dphi
+        self._eng.set_site(_engine.DQI, self._k, np.zeros((d, d), order='F'), np.zeros(d))
+        return False
 
     def _refresh_for_injection(self):
         """Expose the device cavity as the Stan data of method.py:221-222."""
@@ -258,6 +285,106 @@ class Worker(object):
         self.iteration += 1
 
 
+# ---------------------------------------------------------------------------------------------
+# constructor helpers of Master: every check of method.py:674-814, one concern per function
+
+def _partition(N, site_sizes, site_ind_ord, site_ind):
+    """Rows -> sites.  Returns (Nk, k_lim, k_ind, order): rows per site, row limits, site of
+    every (sorted) row, and the permutation that sorts the rows by site (None: already sorted).
+    Precedence of the three descriptions as in the reference (method.py:696-722)."""
+    order = None
+    if site_sizes is not None:
+        Nk = site_sizes
+        k_ind = np.repeat(np.arange(len(Nk), dtype=np.int64), np.asarray(Nk, dtype=np.int64))
+    elif site_ind_ord is not None:
+        k_ind = site_ind_ord
+        Nk = np.bincount(k_ind)
+    elif site_ind is not None:
+        order = np.argsort(site_ind, kind='mergesort')           # stable: rows keep their order inside a site
+        k_ind = site_ind[order]
+        Nk = np.bincount(k_ind)
+    else:
+        raise NotImplementedError("Auto clustering not yet implemented")
+    k_lim = np.concatenate(([0], np.cumsum(Nk)))
+    if k_lim[-1] != N:
+        raise ValueError("Site definition does not match with `X`")
+    empty = np.nonzero(np.asarray(Nk) == 0)[0]
+    if empty.size:
+        raise ValueError("Empty sites: {}. Index the sites from 1 to K-1".format(empty))
+    if len(Nk) < 2:
+        raise ValueError("Distributed EP should be run with at least "
+                         "two sites.")
+    return Nk, k_lim, k_ind, order
+
+
+def _additional_data(A, A_n, A_k, N, K):
+    """The three dictionaries of extra Stan data (shared, per row, per site; method.py:736-769):
+    lengths must fit and no name may be used twice or shadow the built-in data names."""
+    taken = list(Worker.RESERVED_STAN_PARAMETER_NAMES)
+
+    def claim(name):
+        if name in taken:
+            raise ValueError("Additional data name {} clashes.".format(name))
+        taken.append(name)
+
+    for name in A:
+        claim(name)
+    rows = {}
+    for name, val in A_n.items():
+        if val.shape[0] != N:
+            raise ValueError("The shapes of `A_n[{}]` and `X` does not "
+                             "match".format(repr(name)))
+        claim(name)
+        rows[name] = val if val.flags['CARRAY'] else np.ascontiguousarray(val)
+    for name, val in A_k.items():
+        if len(val) != K:
+            raise ValueError("Array-like length mismatch in `A_k` "
+                             "(should be: {}, found: {})"
+                             .format(K, len(val)))
+        claim(name)
+    return A, rows, A_k
+
+
+def _prior_natural(prior, dphi, device):
+    """(Q0, r0, dphi) from the `prior` argument: natural parameters, moment parameters or
+    None = unit Gaussian of the given size (method.py:772-797)."""
+    if prior is None:
+        if dphi is None:
+            raise ValueError("If arg. `prior` is not provided, "
+                             "arg. `dphi` has to be given")
+        return np.asfortranarray(np.eye(dphi)), np.zeros(dphi), dphi
+    if not isinstance(prior, dict):
+        raise TypeError("Argument `prior` is of wrong type")
+    if 'Q' in prior and 'r' in prior:
+        Q0 = np.asfortranarray(prior['Q'], dtype=np.float64)
+        r0 = np.asarray(prior['r'], dtype=np.float64)
+    elif 'S' in prior and 'm' in prior:
+        try:
+            Q0, r0 = invert_normal_params(np.asarray(prior['S'], dtype=np.float64),
+                                          np.asarray(prior['m'], dtype=np.float64), device=device)
+        except LinAlgError as ex:
+            raise ValueError("Argument `prior` is not appropriate") from ex
+    else:
+        raise ValueError("Argument `prior` is not appropriate")
+    if dphi is None:
+        dphi = Q0.shape[0]
+    if Q0.shape[0] != dphi or r0.shape[0] != dphi:
+        raise ValueError("Arg. `dphi` does not match with `prior`")
+    return Q0, r0, dphi
+
+
+def _damping_schedule(df0, K):
+    """Initial damping factor of iteration i as a function (method.py:800-814)."""
+    if df0 is None:
+        return lambda i, _v=1 / K: _v
+    if isinstance(df0, (float, int)):
+        if not 0 < df0 <= 1:
+            raise ValueError("Constant initial damping factor has to be "
+                             "in (0,1]")
+        return lambda i, _v=df0: _v
+    return df0
+
+
 class Master(object):
     """Manages the distributed EP algorithm (method.py:478-1247).
 
@@ -269,7 +396,7 @@ class Master(object):
     (`m1b_sg` ... `m5b_sg`).
 
     GPU-only keyword arguments: `device` (HIP device index, default: rank's
-    LOCAL_RANK or 0), `comm` (a `dist.TorchComm` to shard the sites over several
+    LOCAL_RANK or 0), `comm` (a `dist.EpxComm` to shard the sites over several
     GPUs), `max_treedepth` (default 10), `layout` (0 auto, 1 block per site,
     2 block per (site, chain), 3 streaming), `sync_sites` (gather the site arrays
     of all ranks into the host mirrors when `run` returns, default True),
@@ -313,26 +440,12 @@ class Master(object):
     )
 
     def __init__(self, site_model, X, y, **kwargs):
-        self.worker_options = {}
-        gpu = dict(self.GPU_KWARGS)
-        for (kw, val) in list(kwargs.items()):
-            if kw in Worker.DEFAULT_OPTIONS or kw in Worker.DEFAULT_STAN_PARAMS:
-                self.worker_options[kw] = val
-            elif kw in self.GPU_KWARGS:
-                gpu[kw] = kwargs.pop(kw)
-            elif kw not in self.DEFAULT_KWARGS:
-                raise TypeError("Unexpected keyword argument '{}'".format(kw))
-        for (kw, default) in self.DEFAULT_KWARGS.items():
-            if kw not in kwargs:
-                kwargs[kw] = default
-        for (kw, default) in Worker.DEFAULT_OPTIONS.items():
-            if kw not in self.worker_options:
-                self.worker_options[kw] = default
-        for (kw, default) in Worker.DEFAULT_STAN_PARAMS.items():
-            if kw not in self.worker_options:
-                self.worker_options[kw] = default
-
+        own, gpu, w_opt, w_stan = _sort_keywords(
+            kwargs, (self.DEFAULT_KWARGS, self.GPU_KWARGS, Worker.DEFAULT_OPTIONS, Worker.DEFAULT_STAN_PARAMS),
+            "Unexpected keyword argument '{}'")
+        self.worker_options = dict(w_opt, **w_stan)
         self.site_model = site_model
+        self.model_name = _model_name(site_model)
         self.max_treedepth = gpu['max_treedepth']
         self.layout = gpu['layout']
         self.sync_sites = gpu['sync_sites']
@@ -345,136 +458,40 @@ class Master(object):
         self.pass_log = []                  # passes over the site rows of every sampling launch (per site)
         self.sweep_log = []                 # results of `run(..., sweep=...)`, one dict per iteration
         self.df_log = []                    # damping factor accepted in every iteration
+        self.othertime_log = []             # host time of every update phase (this rank)
+        device = gpu['device']
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0')) if self.comm.world > 1 else 0
 
-        # ---- validate X, y (method.py:674-689)
-        self.N = X.shape[0]
-        if len(X.shape) == 2:
-            self.D = X.shape[1]
-        elif len(X.shape) == 1:
-            self.D = None
-        else:
+        # ---- the data and its partition into sites
+        if X.ndim not in (1, 2):
             raise ValueError("Argument `X` should be one or two dimensional")
-        self.X = X
-        if len(y.shape) != 1:
+        if y.ndim != 1:
             raise ValueError("Argument `y` should be one dimensional")
-        if y.shape[0] != self.N:
+        if y.shape[0] != X.shape[0]:
             raise ValueError("The shapes of `y` and `X` does not match")
-        self.y = y
-
-        # ---- site partition (method.py:696-730)
-        if kwargs['site_sizes'] is not None:
-            self.Nk = kwargs['site_sizes']
-            self.K = len(self.Nk)
-            self.k_lim = np.concatenate(([0], np.cumsum(self.Nk)))
-            self.k_ind = np.empty(self.N, dtype=np.int64)
-            for k in range(self.K):
-                self.k_ind[self.k_lim[k]:self.k_lim[k+1]] = k
-        elif kwargs['site_ind_ord'] is not None:
-            self.k_ind = kwargs['site_ind_ord']
-            self.Nk = np.bincount(self.k_ind)
-            self.K = len(self.Nk)
-            self.k_lim = np.concatenate(([0], np.cumsum(self.Nk)))
-        elif kwargs['site_ind'] is not None:
-            k_ind = kwargs['site_ind']
-            k_sort = k_ind.argsort(kind='mergesort')
-            self.k_ind = k_ind[k_sort]
-            self.Nk = np.bincount(self.k_ind)
-            self.K = len(self.Nk)
-            self.k_lim = np.concatenate(([0], np.cumsum(self.Nk)))
-            self.X = self.X[k_sort]
-            self.y = self.y[k_sort]
-        else:
-            raise NotImplementedError("Auto clustering not yet implemented")
-        if self.k_lim[-1] != self.N:
-            raise ValueError("Site definition does not match with `X`")
-        if np.any(np.asarray(self.Nk) == 0):
-            raise ValueError("Empty sites: {}. Index the sites from 1 to K-1"
-                             .format(np.nonzero(np.asarray(self.Nk) == 0)[0]))
-        if self.K < 2:
-            raise ValueError("Distributed EP should be run with at least "
-                             "two sites.")
-        self.X = np.ascontiguousarray(self.X)
-        self.y = np.ascontiguousarray(self.y)
-
-        # ---- additional data (method.py:736-769); kept for API parity
-        self.A = kwargs['A']
-        for key in self.A.keys():
-            if key in Worker.RESERVED_STAN_PARAMETER_NAMES:
-                raise ValueError("Additional data name {} clashes.".format(key))
-        self.A_n = kwargs['A_n'].copy()
-        for (key, val) in kwargs['A_n'].items():
-            if val.shape[0] != self.N:
-                raise ValueError("The shapes of `A_n[{}]` and `X` does not "
-                                 "match".format(repr(key)))
-            if key in Worker.RESERVED_STAN_PARAMETER_NAMES or key in self.A:
-                raise ValueError("Additional data name {} clashes.".format(key))
-            if not val.flags['CARRAY']:
-                self.A_n[key] = np.ascontiguousarray(val)
-        self.A_k = kwargs['A_k']
-        for (key, val) in self.A_k.items():
-            if len(val) != self.K:
-                raise ValueError("Array-like length mismatch in `A_k` "
-                                 "(should be: {}, found: {})"
-                                 .format(self.K, len(val)))
-            if (key in Worker.RESERVED_STAN_PARAMETER_NAMES or key in self.A
-                    or key in self.A_n):
-                raise ValueError("Additional data name {} clashes.".format(key))
-
-        # ---- prior (method.py:772-797)
-        prior = kwargs['prior']
-        self.dphi = kwargs['dphi']
-        if prior is None:
-            if self.dphi is None:
-                raise ValueError("If arg. `prior` is not provided, "
-                                 "arg. `dphi` has to be given")
-            self.Q0 = np.eye(self.dphi).T
-            self.r0 = np.zeros(self.dphi)
-        else:
-            if not isinstance(prior, dict):
-                raise TypeError("Argument `prior` is of wrong type")
-            if 'Q' in prior and 'r' in prior:
-                self.Q0 = np.asfortranarray(prior['Q'], dtype=np.float64)
-                self.r0 = np.asarray(prior['r'], dtype=np.float64)
-            elif 'S' in prior and 'm' in prior:
-                try:
-                    self.Q0, self.r0 = invert_normal_params(
-                        np.asarray(prior['S'], dtype=np.float64),
-                        np.asarray(prior['m'], dtype=np.float64))
-                except LinAlgError as ex:
-                    raise ValueError("Argument `prior` is not appropriate") from ex
-            else:
-                raise ValueError("Argument `prior` is not appropriate")
-            if self.dphi is None:
-                self.dphi = self.Q0.shape[0]
-            if self.Q0.shape[0] != self.dphi or self.r0.shape[0] != self.dphi:
-                raise ValueError("Arg. `dphi` does not match with `prior`")
-
-        # ---- damping (method.py:800-814)
-        self.df_decay = kwargs['df_decay']
-        self.df_treshold = kwargs['df_treshold']
-        if kwargs['df0'] is None:
-            default_df = 1/self.K
-            self.df0 = lambda i: default_df
-        elif isinstance(kwargs['df0'], (float, int)):
-            if kwargs['df0'] <= 0 or kwargs['df0'] > 1:
-                raise ValueError("Constant initial damping factor has to be "
-                                 "in (0,1]")
-            self.df0 = lambda i: kwargs['df0']
-        else:
-            self.df0 = kwargs['df0']
+        self.N = X.shape[0]
+        self.D = X.shape[1] if X.ndim == 2 else None
+        self.Nk, self.k_lim, self.k_ind, order = _partition(
+            self.N, own['site_sizes'], own['site_ind_ord'], own['site_ind'])
+        self.K = len(self.Nk)
+        # sorted, C-contiguous copies for the device; the Workers below still receive slices of the
+        # caller's arrays, as in the reference (method.py:829-830)
+        self.X = np.ascontiguousarray(X if order is None else X[order])
+        self.y = np.ascontiguousarray(y if order is None else y[order])
+        self.A, self.A_n, self.A_k = _additional_data(own['A'], own['A_n'], own['A_k'], self.N, self.K)
+        self.Q0, self.r0, self.dphi = _prior_natural(own['prior'], own['dphi'], device)
+        self.df_decay = own['df_decay']
+        self.df_treshold = own['df_treshold']
+        self.df0 = _damping_schedule(own['df0'], self.K)
 
         # ---- this rank's contiguous block of sites + its device engine
-        self.model_name = _model_name(site_model)
         self.k_lo, self.k_hi = _dist.site_range(self.K, self.comm.rank, self.comm.world)
         self.K_local = self.k_hi - self.k_lo
         if self.K_local < 1:
             raise ValueError("more ranks ({}) than sites ({})".format(self.comm.world, self.K))
         r0w, r1w = int(self.k_lim[self.k_lo]), int(self.k_lim[self.k_hi])
         k_lim_local = np.asarray(self.k_lim[self.k_lo:self.k_hi + 1], dtype=np.int64) - r0w
-        factory = gpu['_engine_factory']
-        device = gpu['device']
-        if device is None:
-            device = int(os.environ.get('LOCAL_RANK', '0')) if self.comm.world > 1 else 0
         groups = {}
         if not self.model_name.endswith('_sg'):
             # several groups per site (K < J, fit.py:310-324): the multi-group programs take the
@@ -483,6 +500,7 @@ class Master(object):
             glo = int(np.sum(g_cnt[:self.k_lo]))
             ghi = glo + int(np.sum(g_cnt[self.k_lo:self.k_hi]))
             groups = dict(g_cnt=g_cnt[self.k_lo:self.k_hi], g_lim=g_lim[glo:ghi + 1] - r0w)
+        factory = gpu['_engine_factory']
         if factory is None:
             self.engine = _engine.HipEngine(self.model_name, self.X[r0w:r1w], self.y[r0w:r1w],
                                             k_lim_local, device=device, **groups)
@@ -491,19 +509,20 @@ class Master(object):
         if self.engine.d != self.dphi:
             raise ValueError("Arg. `dphi`/`prior` ({}) does not match site model {} (dphi {})"
                              .format(self.dphi, self.model_name, self.engine.d))
+        if hasattr(self.comm, 'bind'):
+            self.comm.bind(self.engine)                   # RCCL communicator of the engine's context (collective)
+        # the fused update (epx_update_trial) needs the engine's own communicator (or one rank)
+        self._fused = bool(getattr(self.comm, 'native', False)) and hasattr(self.engine, 'update_trial')
+        self._host_sums = None
 
         # ---- workers (method.py:817-834); slices of the ORIGINAL X, y like the reference
         self.workers = []
         for k in range(self.K):
-            A = dict((key, val[self.k_lim[k]:self.k_lim[k+1]])
-                     for (key, val) in self.A_n.items())
+            rows = slice(self.k_lim[k], self.k_lim[k + 1])
+            A = dict((key, val[rows]) for (key, val) in self.A_n.items())
             A.update(self.A)
-            for (key, val) in self.A_k.items():
-                A[key] = val[k]
-            w = Worker(k, self.site_model, self.dphi,
-                       X[self.k_lim[k]:self.k_lim[k+1]],
-                       y[self.k_lim[k]:self.k_lim[k+1]],
-                       A=A, _master=self, **self.worker_options)
+            A.update((key, val[k]) for (key, val) in self.A_k.items())
+            w = Worker(k, self.site_model, self.dphi, X[rows], y[rows], A=A, _master=self, **self.worker_options)
             if self.k_lo <= k < self.k_hi:
                 w._eng = self.engine
                 w._k = k - self.k_lo
@@ -515,48 +534,56 @@ class Master(object):
         self.m = np.empty(d)
         self.Q = self.Q0.copy(order='F')
         self.r = self.r0.copy()
-        self.Qi = np.zeros((d, d, K), order='F')
-        self.ri = np.zeros((d, K), order='F')
-        self.Qi2 = np.zeros((d, d, K), order='F')
-        self.ri2 = np.zeros((d, K), order='F')
-        self.dQi = np.zeros((d, d, K), order='F')
-        self.dri = np.zeros((d, K), order='F')
-        if kwargs['init_site'] is not None:
-            if isinstance(kwargs['init_site'], np.ndarray):
-                for k in range(K):
-                    np.copyto(self.Qi[:, :, k], kwargs['init_site'])
-            else:
-                diag_elem = K / (kwargs['init_site']**2)
-                for k in range(K):
-                    self.Qi[:, :, k].flat[::d+1] = diag_elem
+        self.Qi, self.Qi2, self.dQi = (np.zeros((d, d, K), order='F') for _ in range(3))
+        self.ri, self.ri2, self.dri = (np.zeros((d, K), order='F') for _ in range(3))
+        init_site = own['init_site']
+        if isinstance(init_site, np.ndarray):
+            self.Qi[...] = init_site[:, :, None]
+        elif init_site is not None:
+            self.Qi[np.arange(d), np.arange(d), :] = K / (init_site**2)
         self.iter = 0
 
         # ---- initial global approximation and cavities on the device (method.py:867-882)
         self.engine.set_prior(self.Q0, self.r0)
         self._upload_sites()
-        self._packed = self._new_packed()
-        packed = self.comm.allreduce_sum(self.engine.site_sums(self._packed))
-        g_pd, c_pd, first_bad = self.engine.damped_trial(0.0, packed)
+        g_pd, c_pd = self._trial(0.0, True)[:2]
         if not g_pd:
             raise ValueError("Initial approximation is not pos.def.")
-        if not self.comm.allreduce_min_int(1 if c_pd else 0):
+        if not c_pd:
             raise ValueError("Initial cavity is not pos.def.")
         self.Q[...], self.r[...] = self.engine.get_global()
-        for k in range(self.k_lo, self.k_hi):
-            w = self.workers[k]
+        for w in self.workers[self.k_lo:self.k_hi]:
             w.Q, w.r = self.Q, self.r
             w.phase = 1
             w._stale = True
 
     # ------------------------------------------------------------------
-    def _new_packed(self):
-        """Buffer of the packed site sums: a CUDA tensor when the all-reduce runs
-        over RCCL, otherwise None (the engine returns a NumPy array)."""
-        dev = getattr(self.comm, 'device', None)
-        if dev is None:
-            return None
-        import torch
-        return torch.zeros(self.engine.packed_len, dtype=torch.float64, device=dev)
+    def _trial(self, df, reduce_sums, stat_sum=(), stat_max=(), want_moments=False):
+        """One damping trial over all ranks: (global_pd, cav_pd, first_bad (global site or -1),
+        stat_sum, stat_max, S, m).  The device engine runs it as one stream-ordered batch with the
+        all-reduce inside (epx_update_trial); other engines / transports compose it from the
+        engine's primitives and the communicator's host collectives."""
+        eng, comm = self.engine, self.comm
+        if self._fused:
+            return eng.update_trial(df, reduce_sums, self.k_lo, stat_sum, stat_max, want_moments)
+        ss = np.array(stat_sum, dtype=np.float64)
+        sm = np.array(stat_max, dtype=np.float64)
+        if reduce_sums:
+            self._host_sums = comm.allreduce_sum(np.array(eng.site_sums(), dtype=np.float64))
+            if ss.size:
+                ss = comm.allreduce_sum(ss)
+            if sm.size:
+                sm = comm.allreduce_max(sm)
+        g_pd, c_pd, first_bad = eng.damped_trial(df, self._host_sums)
+        c_pd = bool(g_pd and c_pd)
+        first = self.k_lo + first_bad if (g_pd and first_bad >= 0) else self.K + 1
+        if comm.world > 1:
+            c_pd = bool(comm.allreduce_min_int(1 if c_pd else 0))
+            first = comm.allreduce_min_int(first)
+        S = m = None
+        if want_moments and g_pd and c_pd:
+            S, m = eng.global_moments()
+        return g_pd, c_pd, (first if first <= self.K else -1), ss, sm, S, m
 
     def _upload_sites(self):
         lo, hi = self.k_lo, self.k_hi
@@ -651,23 +678,29 @@ class Master(object):
             lims.append(int(self.k_lim[k + 1]))
         return g_cnt, np.asarray(lims, dtype=np.int64)
 
-    def damp_sweep(self, damps, m_target, S_target, samp_target=None, packed=None):
-        """Score damping factors for the pending site updates `dQi, dri` against a target
-        posterior N(m_target, S_target): the loop `for di, df in enumerate(damps)` of
-        experiment/find_damp.py:146-173 as ONE batched device call (the proposal is affine in
-        `df`, so the site sums are reduced once).  Returns a dict with `mses`, `lls`, `kls`
-        (NaN where the proposal or a cavity is not positive definite, as in the reference) and
-        the flags `global_pd`, `cav_pd`.  Does not change the site parameters."""
+    def _score_damps(self, damps, m_target, S_target, samp_target):
+        """The sweep itself, on the site sums the device / `_host_sums` hold."""
         eng, comm = self.engine, self.comm
-        if packed is None:
-            packed = comm.allreduce_sum(eng.site_sums(self._packed))
-        res = eng.damp_sweep(damps, packed, m_target, S_target, samp_target)
+        res = eng.damp_sweep(damps, None if self._fused else self._host_sums, m_target, S_target, samp_target)
         if comm.world > 1:
             res[:, 1] = -comm.allreduce_max(-res[:, 1])
         bad = res[:, 1] == 0.0
         res[bad, 2:] = np.nan
         return dict(damps=np.asarray(damps, dtype=np.float64), global_pd=res[:, 0] > 0, cav_pd=res[:, 1] > 0,
                     mses=res[:, 2], kls=res[:, 3], lls=res[:, 4])
+
+    def damp_sweep(self, damps, m_target, S_target, samp_target=None):
+        """Score damping factors for the pending site updates `dQi, dri` against a target
+        posterior N(m_target, S_target): the loop `for di, df in enumerate(damps)` of
+        experiment/find_damp.py:146-173 as ONE batched device call (the proposal is affine in
+        `df`, so the site sums are reduced once).  Returns a dict with `mses`, `lls`, `kls`
+        (NaN where the proposal or a cavity is not positive definite, as in the reference) and
+        the flags `global_pd`, `cav_pd`.  Site parameters, the global approximation and the
+        cavities are those of the accepted state again when it returns."""
+        self._trial(0.0, True)                  # reduce the sums of the current (Qi, dQi)
+        out = self._score_damps(damps, m_target, S_target, samp_target)
+        self._trial(0.0, False)                 # the sweep left the last factor's Q, r and cavities behind
+        return out
 
     def cur_approx(self):
         """Current posterior approximation moments (S, m) (method.py:884-896)."""
@@ -691,9 +724,12 @@ class Master(object):
         `(stimes, msteps, mrhats, othertimes)` exactly like the reference
         (a list on the early-exit paths, a tuple on the normal path).
 
+        `save_last_param`: parameter names whose draws of the LAST iteration every worker keeps
+        in `saved_samp` (method.py:1011-1016).
+
         `sweep` (not in the reference's `run`; it is the body of experiment/find_damp.py): a dict
         `damps, m_target, S_target[, samp_target]`; every iteration scores these damping factors
-        with `damp_sweep` before its own damped update and appends the result to `self.sweep_log`."""
+        before its own damped update and appends the result to `self.sweep_log`."""
         if niter < 1:
             if verbose:
                 print("Nothing to do here as provided arg. `niter` is {}".format(niter))
@@ -701,7 +737,7 @@ class Master(object):
                              (None, None), (None, None, None))
 
         seeds = run_seeds(seed, niter, self.K)                    # :956-960
-        eng, comm = self.engine, self.comm
+        eng = self.engine
         lo, hi, K = self.k_lo, self.k_hi, self.K
         local_workers = self.workers[lo:hi]
 
@@ -737,6 +773,8 @@ class Master(object):
             else:
                 opts = w0._sampler_opts()
                 posdefs_l, stats, ms = eng.tilted_batch(sseeds, opts, estim)
+                for j in np.nonzero(stats[:, 7] > 0)[0]:
+                    posdefs_l[j] = local_workers[j]._void_update()
                 self.last_site_stats = stats        # (K_local, 8): see epx_site_stat in include/epx.h
                 self.sampling_ms.append(ms)
                 self.ngrad_log.append(float(stats[:, 3].sum()))
@@ -750,13 +788,14 @@ class Master(object):
                     eng.set_site_split(n_lead)
                 tl = np.full(self.K_local, ms * 1e-3)
                 ml, rl = stats[:, 0], stats[:, 1]
+            nsamp = eng.get_tilted(0)[2]
             for j, w in enumerate(local_workers):
                 w.stan_params['seed'] = int(sseeds[j])
                 w.last_time, w.last_msteps, w.last_mrhat = tl[j], ml[j], rl[j]
                 if w.init_prev:
                     w.stan_params['init'] = 'prev' if self._sample_injector is None \
                         else [{}] * w.stan_params['chains']
-                w.nsamp = eng.get_tilted(0)[2] if j == 0 else local_workers[0].nsamp
+                w.nsamp = nsamp
                 if w.prec_estim_skip > 0:
                     w.prec_estim_skip -= 1
                 w.phase = 2 if posdefs_l[j] else 0
@@ -764,51 +803,42 @@ class Master(object):
                     w.init = w.init_orig                            # sic (:468)
                 w._stale = True
                 w.iteration += 1
+                if save_last_param and cur_iter == niter - 1 and self._sample_injector is None:
+                    w._save_named(save_last_param)
             n_ok = int(np.sum(posdefs_l))
-            red = comm.allreduce_max(np.array([1.0 if n_ok > 0 else 0.0,
-                                               0.0 if n_ok == self.K_local else 1.0,
-                                               np.max(tl), np.max(ml), np.max(rl)]))
+            start_othertime = time.time()
+
+            # ---- the one reduction per iteration (:1073-1074, affine in df) and the first damping
+            # trial behind it; the site counts and the analytics of :1043-1045 ride on the same buffer
+            df = self.df0(self.iter)                                # :1060
+            g_pd, c_pd, first_bad, ssum, smax, S, m = self._trial(
+                df, True, stat_sum=(n_ok, self.K_local - n_ok),
+                stat_max=(np.max(tl), np.max(ml), np.max(rl)), want_moments=calc_moments)
             if verbose:
-                if red[1] == 0.0:
+                if ssum[1] == 0.0:
                     print("\rAll sites ok")
-                elif red[0] > 0:
+                elif ssum[0] > 0:
                     print("\rSome sites failed and are not updated")
                 else:
                     print("\rEvery site failed")
-            if red[0] == 0.0:                                       # :1033-1040
+            if ssum[0] == 0.0:                                      # :1033-1040
                 self._download_sites()
                 return self._ret(self.INFO_ALL_SITES_FAIL, calc_moments, return_analytics,
                                  moments, analytics)
-            stimes[cur_iter], msteps[cur_iter], mrhats[cur_iter] = red[2], red[3], red[4]   # :1043-1045
+            stimes[cur_iter], msteps[cur_iter], mrhats[cur_iter] = smax[0], smax[1], smax[2]   # :1043-1045
             if verbose:
                 print("Sampling done, max sampling time {}".format(stimes[cur_iter]))
-            start_othertime = time.time()
-
-            # ---- the one reduction per iteration (:1073-1074, affine in df)
-            packed = comm.allreduce_sum(eng.site_sums(self._packed))
 
             if sweep is not None:                                   # find_damp.py:146-173
-                self.sweep_log.append(self.damp_sweep(sweep['damps'], sweep['m_target'], sweep['S_target'],
-                                                      sweep.get('samp_target'), packed=packed))
+                self.sweep_log.append(self._score_damps(sweep['damps'], sweep['m_target'], sweep['S_target'],
+                                                        sweep.get('samp_target')))
+                g_pd, c_pd, first_bad, _, _, S, m = self._trial(df, False, want_moments=calc_moments)
 
-            df = self.df0(self.iter)                                # :1060
             if verbose:
                 print("Iter {}, starting df {:.3g}".format(self.iter, df))
             fail_printline = False
             failed_force_pos_def = False
-            while True:                                             # :1067
-                g_pd, c_pd, first_bad = eng.damped_trial(df, packed)
-                if g_pd:
-                    if comm.world > 1:
-                        c_pd = bool(comm.allreduce_min_int(1 if c_pd else 0))
-                    if c_pd:                                        # :1145-1158 accept
-                        eng.accept(df)
-                        self.df_log.append(df)
-                        for w in local_workers:
-                            w.Q, w.r = self.Q, self.r
-                            w.phase = 1
-                            w._stale = True
-                        break
+            while not (g_pd and c_pd):                              # :1067
                 df *= self.df_decay                                 # :1083 / :1163
                 if verbose:
                     fail_printline = True
@@ -817,7 +847,7 @@ class Master(object):
                                          "reducing df to {:.3}".format(df) + " "*5 + "\b"*5)
                     else:
                         sys.stdout.write("\rNon pos. def. cavity, " +
-                                         "(first encountered in site {}), ".format(first_bad + lo) +
+                                         "(first encountered in site {}), ".format(first_bad) +
                                          "reducing df to {:.3}".format(df) + " "*5 + "\b"*5)
                     sys.stdout.flush()
                 if not g_pd and self.iter == 1:                     # :1092-1101
@@ -826,6 +856,7 @@ class Master(object):
                     self._download_sites()
                     return self._ret(self.INFO_INVALID_PRIOR, calc_moments, return_analytics,
                                      moments, analytics)
+                refresh = False
                 if df < self.df_treshold:                           # :1102-1132 / :1177-1207
                     if verbose:
                         print("\nDamping factor reached minimum.")
@@ -840,13 +871,19 @@ class Master(object):
                     forced = eng.force_pd(df, self.MIN_EIG_TRESHOLD, self.MIN_EIG)
                     if verbose:
                         print("Force sites {} pos_def.".format(np.nonzero(forced)[0] + lo))
-                    # the shift changed Qi: refresh the sums
-                    packed = comm.allreduce_sum(eng.site_sums(self._packed))
+                    refresh = True                                  # the shift changed Qi: reduce the sums again
+                g_pd, c_pd, first_bad, _, _, S, m = self._trial(df, refresh, want_moments=calc_moments)
             if verbose and fail_printline:
                 print()
 
+            eng.accept(df)                                          # :1145-1158
+            self.df_log.append(df)
+            for w in local_workers:
+                w.Q, w.r = self.Q, self.r
+                w.phase = 1
+                w._stale = True
+
             if calc_moments:                                        # :1211-1219
-                S, m = eng.global_moments()
                 self.S[...] = S
                 self.m[...] = m
                 np.copyto(m_phi_s[cur_iter], m)
@@ -855,12 +892,10 @@ class Master(object):
                     print("Mean and std of phi[0]: {:.3}, {:.3}".format(
                         m_phi_s[cur_iter, 0], np.sqrt(cov_phi_s[cur_iter, 0, 0])))
             othertimes[cur_iter] = time.time() - start_othertime   # :1230
+            self.othertime_log.append(othertimes[cur_iter])
             if verbose:
                 print("Iter {} done.".format(self.iter))
 
-        if save_last_param:
-            for w in local_workers:
-                w.saved_samp = {'phi': eng.get_draws(w._k)}
         self._download_sites()
         if verbose:
             print("{} iterations done\nTotal limiting sampling time: {}"

@@ -14,82 +14,81 @@ from numpy.linalg import LinAlgError
 from . import _lib
 from ._lib import check, dptr
 
-DEVICE = 0
+DEVICE = 0          # device of the stand-alone calls when none is given
 
 
-def invert_normal_params(A, b=None, out_A=None, out_b=None, cho_form=False):
+def _destination(src, out, what):
+    """Array the kernel works in: `out` may be None (a new F-ordered copy of `src`), the string
+    'in-place' (`src` itself) or an ndarray (receives a copy of `src`) -- the three spellings of
+    the reference's `out_*` arguments."""
+    if isinstance(out, str):
+        if out != 'in-place':
+            raise ValueError("{} has to be None, an ndarray or 'in-place'".format(what))
+        return src
+    if out is None:
+        return src.copy(order='F')
+    np.copyto(out, src)
+    return out
+
+
+def _column_major(M, message):
+    """A view of the square matrix that the kernels can address column by column.  A C-ordered
+    SYMMETRIC matrix is its own transpose, so its transposed view serves."""
+    if M.flags['FARRAY']:
+        return M
+    Mt = M.T
+    if not Mt.flags['FARRAY'] and M.shape[0] > 1:
+        raise ValueError(message)
+    return Mt
+
+
+def _device(device):
+    return DEVICE if device is None else int(device)
+
+
+def invert_normal_params(A, b=None, out_A=None, out_b=None, cho_form=False, device=None):
     """Invert moment parameters into natural parameters or vice versa.
 
     (S, m) -> (Q, r) and back: returns (A^-1, A^-1 b).  `out_A`/`out_b` may be
     None (new arrays), an ndarray, or the string 'in-place'.  With
-    `cho_form=True`, `A` holds the UPPER Cholesky factor of the real matrix.
-    Raises LinAlgError if A is not positive definite (util.py:82-86).
+    `cho_form=True`, `A` holds the UPPER Cholesky factor of the real matrix
+    (whatever sits below the diagonal is ignored).  Raises LinAlgError if A is
+    not positive definite (util.py:82-86).  `device`: HIP device the kernel runs
+    on (not in the reference; default `util.DEVICE`).
     """
     lib = _lib.load()
-    if not isinstance(out_A, np.ndarray) and out_A == 'in-place':
-        out_A = A
-    elif out_A is None:
-        out_A = A.copy(order='F')
-    else:
-        np.copyto(out_A, A)
-    if not out_A.flags['FARRAY']:
-        # C-order -> F-order by transposing (symmetric; util.py:95-99)
-        out_A = out_A.T
-        if not out_A.flags['FARRAY'] and out_A.shape[0] > 1:
-            raise ValueError('Provided array A is inappropriate')
-    if out_A.dtype != np.float64:
+    work = _column_major(_destination(A, out_A, 'out_A'), 'Provided array A is inappropriate')
+    if work.dtype != np.float64:
         raise ValueError('Provided array A has to be float64')
-    if b is not None:
-        if not isinstance(out_b, np.ndarray) and out_b == 'in-place':
-            out_b = b
-        elif out_b is None:
-            out_b = b.copy()
-        else:
-            np.copyto(out_b, b)
-    else:
-        out_b = None
-    d = out_A.shape[0]
+    vec = None if b is None else _destination(b, out_b, 'out_b')
+    staged = vec
+    if vec is not None and not (vec.flags['C_CONTIGUOUS'] and vec.dtype == np.float64):
+        staged = np.ascontiguousarray(vec, dtype=np.float64)
     info = np.zeros(1, dtype=np.int32)
-    if cho_form and not out_A.flags['C_CONTIGUOUS'] and d > 1:
-        # the kernel reads the upper factor; a lower triangle of junk is ignored
-        pass
-    bb = None
-    if out_b is not None:
-        bb = out_b if (out_b.flags['C_CONTIGUOUS'] and out_b.dtype == np.float64) \
-            else np.ascontiguousarray(out_b, dtype=np.float64)
-    check(lib.epx_invert_normal_params(DEVICE, d, 1, dptr(out_A), dptr(bb), 1 if cho_form else 0,
-                                       info.ctypes.data_as(_lib.c_int32_p)))
+    check(lib.epx_invert_normal_params(_device(device), work.shape[0], 1, dptr(work), dptr(staged),
+                                       1 if cho_form else 0, info.ctypes.data_as(_lib.c_int32_p)))
     if info[0]:
         raise LinAlgError('matrix is not positive definite')
-    if out_b is not None and bb is not out_b:
-        np.copyto(out_b, bb)
-    return out_A, out_b
+    if staged is not vec:
+        np.copyto(vec, staged)
+    return work, vec
 
 
-def olse(S, n, P=None, out=None):
+def olse(S, n, P=None, out=None, device=None):
     """Optimal linear shrinkage estimator of the precision matrix (Bodnar,
     Gupta, Parolya, arXiv:1308.0931) from a sample covariance `S` of `n`
     draws, shrinking towards `P` (None: the naive I/d prior)."""
     lib = _lib.load()
-    if not isinstance(out, np.ndarray) and out == 'in-place':
-        out = S
-    elif out is None:
-        out = S.copy(order='F')
-    else:
-        np.copyto(out, S)
-    if not out.flags['FARRAY']:
-        out = out.T
-        if not out.flags['FARRAY']:
-            raise ValueError('Provided array should be in F-order')
-    d = out.shape[0]
-    Pa = None
-    if P is not None:
-        Pa = np.require(P, dtype=np.float64, requirements=['F', 'A'])
+    work = _column_major(_destination(S, out, 'out'), 'Provided array should be in F-order')
+    if not work.flags['FARRAY']:
+        raise ValueError('Provided array should be in F-order')
+    prior = None if P is None else np.require(P, dtype=np.float64, requirements=['F', 'A'])
     info = np.zeros(1, dtype=np.int32)
-    check(lib.epx_olse(DEVICE, d, 1, dptr(out), int(n), dptr(Pa), info.ctypes.data_as(_lib.c_int32_p)))
+    check(lib.epx_olse(_device(device), work.shape[0], 1, dptr(work), int(n), dptr(prior),
+                       info.ctypes.data_as(_lib.c_int32_p)))
     if info[0]:
         raise LinAlgError('matrix is not positive definite')
-    return out
+    return work
 
 
 def distribute_groups(J, K, Nj):

@@ -15,9 +15,11 @@
  *   - all reals are float64; matrices are column-major ("F order") exactly as
  *     the reference lays them out: site arrays (d,d,K) / (d,K) with the site
  *     index slowest (method.py:838-851), so site k is one contiguous d*d block;
- *   - pointers named *_dev are DEVICE addresses (e.g. torch tensor.data_ptr()),
- *     used for the RCCL all-reduce that torch.distributed performs between
- *     epx_site_sums() and epx_damped_trial().
+ *   - pointers named *_dev are DEVICE addresses (a caller that runs the reduction between
+ *     epx_site_sums() and epx_damped_trial() itself, on device memory of its own);
+ *   - several GPUs: one context per rank, bound to the others by epx_comm_init() (RCCL inside
+ *     the library); epx_update_trial() then performs the iteration's one all-reduce in stream
+ *     order.
  */
 #ifndef EPX_H
 #define EPX_H
@@ -227,6 +229,44 @@ int epx_nuts_transitions(epx_ctx *ctx, int k0, int count, const int64_t *seeds, 
  * samples): out = [sum_k scatter_k (d*d, column-major), sum_k mean_k (d), sum_k mean_k mean_k' (d*d)] over this
  * context's sites, from the tilted moments of the last epx_tilted_batch / epx_moments_batch. */
 int epx_mix_sums(epx_ctx *ctx, double *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Several GPUs: sites are sharded over the ranks (one context each); the only exchange of an EP
+ * iteration is the reduction of method.py:1073-1074 (Q = sum_k Qi2 + Q0 over ALL sites) and the logical
+ * AND of the cavity flags (:1145).  The library runs both as RCCL all-reduces on the context's stream.
+ *   rank 0:      epx_comm_unique_id(id)           -> hand the EPX_COMM_ID_BYTES bytes to every rank
+ *   every rank:  epx_comm_init(ctx, id, rank, nranks)      (collective: returns when all ranks called)
+ * The reference runs in one process and has no counterpart. */
+#define EPX_COMM_ID_BYTES 128
+enum epx_op { EPX_OP_SUM = 0, EPX_OP_MIN = 1, EPX_OP_MAX = 2 };
+int epx_comm_unique_id(void *id_out);
+int epx_comm_init(epx_ctx *ctx, const void *id, int rank, int nranks);
+int epx_comm_destroy(epx_ctx *ctx);
+/* rank and number of ranks of the context's communicator as RCCL reports them (0 of 1 without one) */
+int epx_comm_size(epx_ctx *ctx, int *rank, int *nranks);
+/* small host-side collectives over the communicator (staged through device memory, synchronous):
+ * buf[n] reduced in place with op; in[n] of every rank gathered into out[n * nranks] in rank order.
+ * Without a communicator both are the identity. */
+int epx_comm_allreduce(epx_ctx *ctx, double *buf, int n, int op);
+int epx_comm_allgather(epx_ctx *ctx, const double *in, int n, double *out);
+
+/*
+ * One damping trial of the update phase (method.py:1067-1143) as ONE stream-ordered batch with ONE host
+ * synchronisation:  [reduce_sums: packed site sums of this rank -> all-reduce(sum) over the communicator,
+ * the caller's statistics riding on the same buffer] -> Q, r for df -> Cholesky check (:1077-1080)
+ * [-> S = Q^-1, m = S r with want_moments (:1211-1216)] -> cavities of all local sites against Qi + df*dQi
+ * (:1138-1143) -> flags -> all-reduce(min) of the flags.
+ *   reduce_sums  1 on the first trial of an iteration (or after epx_force_pd), 0 on the following ones: the
+ *                proposal is affine in df, the reduced sums are kept;
+ *   stat_sum[n_sum], stat_max[n_max]  in/out, only with reduce_sums, at most 8 each: summed / maximised over
+ *                the ranks (the any-site-ok / all-sites-ok counts and the analytics of method.py:1043-1045);
+ *   site_base    global index of the context's first site;
+ *   global_pd, cav_pd  the two checks over ALL ranks; first_bad: first failing site (global index) or -1;
+ *   S (d,d), m (d)  moments of the proposal (valid when both checks hold), may be NULL.
+ */
+int epx_update_trial(epx_ctx *ctx, double df, int reduce_sums, int site_base, double *stat_sum, int n_sum,
+                     double *stat_max, int n_max, int want_moments, int *global_pd, int *cav_pd,
+                     int64_t *first_bad, double *S, double *m);
 
 /* Damping sweep (experiment/find_damp.py:146-173, the loop `for di, df in enumerate(damps)`): for every
  * dfs[i] form the proposal Q = Q0 + sum(Qi + df dQi), r likewise, factorise, S = Q^-1, m = S r, all cavities,

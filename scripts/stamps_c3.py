@@ -1,0 +1,41 @@
+"""Diagnostic: cycle shares of one leapfrog at the C3 site size (D=32, n_j=500, m4b) in the
+steady state of EP (tight cavities, deep trees).  Needs the stamped build:
+EPX_LIB=variants/libepx_stamps.so python3 scripts/stamps_c3.py [sites] [ep_iters] [layout]"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from epstan_amd import models, _lib
+from epstan_amd.method import Master
+
+NAMES = ['prep(beta)', 'row loop', 'butterfly', 'Omega matvec', 'exchange', 'chain rule', 'state machine']
+
+def main():
+    J = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    nit = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    layout = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    mod = models.m4b(J, 32, 500)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+               chains=4, iter=200, df0=models.default_df0(J), layout=layout, sync_sites=False)
+    info = M.run(nit, verbose=False, seed=1)[0]
+    eng = M.engine
+    lib = _lib.load()
+    buf = np.zeros((8192, 8), dtype=np.uint64)
+    lib.epx_dbg_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    nb = lib.epx_dbg_get_stamps(eng.ctx, buf.ctypes.data, 8192)
+    st = buf[:nb].astype(np.float64)
+    per = st[:, :7] / st[:, 7:8]
+    med = np.median(per, axis=0)
+    lf = eng.get_chain_stats(4)[:, :, 3]
+    print('C3 site size, J=%d, layout %d, info %d, EP iteration %d: sampling launches (ms) %s'
+          % (J, eng.last_layout(), info, nit, np.round(M.sampling_ms, 1)))
+    print('leapfrogs per chain: mean %.0f max %.0f; per transition %.0f' % (lf.mean(), lf.max(), lf.mean() / 200))
+    print('cycles per leapfrog (median over %d blocks), total %.0f' % (nb, med.sum()))
+    for nm, v in zip(NAMES, med):
+        print('    %-14s %8.0f  %5.1f%%' % (nm, v, 100 * v / med.sum()))
+    wg = lf.max(axis=1)
+    print('us per leapfrog of the slowest chain of a workgroup ~ %.2f' % (M.sampling_ms[-1] * 1e3 / wg.max()))
+
+if __name__ == '__main__':
+    main()

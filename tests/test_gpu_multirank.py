@@ -1,0 +1,189 @@
+"""The N>1 path on the device: the in-library RCCL communicator (dist.EpxComm, epx_comm_init)
+and the host-buffer transport (dist.TorchComm over gloo) in front of the HIP engine.
+
+  * world size 1 over RCCL runs on any GPU box: the all-reduces of epx_update_trial execute in
+    stream order and must leave every result bit-equal to the single-process path;
+  * two ranks SHARING device 0 over gloo drive HipEngine's host-buffer branch (RCCL itself
+    refuses two ranks on one device);
+  * two ranks over RCCL need two devices: skipped on a 1-GPU box.
+References: /root/reference/epstan/method.py:1073-1074 (the reduction), :1145 (the flags)."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope='module')
+def runs():
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'master_run.npz'))
+
+
+def _g6_master(runs, scenario, df0, nsites, comm=None, **kw):
+    import injectors
+    from epstan_amd.method import Master
+    Nj = runs['g6_Nj'][:nsites]
+    nrow = int(Nj.sum())
+    M = Master('m1b_sg', runs['g6_X'][:nrow], runs['g6_y'][:nrow], site_sizes=Nj,
+               prior={'Q': runs['g6_Q0'], 'r': runs['g6_r0']}, A_k={'site_id': np.arange(nsites)},
+               chains=4, iter=200, df0=df0, comm=comm, **kw)
+    M._sample_injector = injectors.GaussianTilted(scenario)
+    return M
+
+
+@pytest.mark.parametrize('tag,scenario,niter,df0,nsites', [('smooth', 'smooth', 12, 0.5, 4),
+                                                           ('decay', 'wide_first', 4, 1.0, 3)])
+def test_rccl_world_of_one_equals_the_local_path_and_the_goldens(runs, tag, scenario, niter, df0, nsites):
+    from epstan_amd import dist
+    comm = dist.EpxComm(rank=0, world=1)
+    M = _g6_master(runs, scenario, df0, nsites, comm=comm)
+    assert comm.size() == (0, 1)                       # RCCL's own view of the communicator
+    info, (m_s, S_s) = M.run(niter, verbose=False, seed=1)
+    L = _g6_master(runs, scenario, df0, nsites)
+    info_l, (m_l, S_l) = L.run(niter, verbose=False, seed=1)
+    assert info == info_l == int(runs['g6_%s_info' % tag])
+    for a, b in ((m_s, m_l), (S_s, S_l), (M.Qi, L.Qi), (M.ri, L.ri), (M.Q, L.Q), (M.r, L.r)):
+        np.testing.assert_array_equal(a, b)            # a one-rank all-reduce must not change a bit
+    np.testing.assert_allclose(m_s, runs['g6_%s_m' % tag], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(S_s, runs['g6_%s_S' % tag], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(M.Qi, runs['g6_%s_Qi' % tag], rtol=1e-8, atol=1e-9)
+    assert M.df_log == L.df_log
+    comm.close()
+
+
+def test_rccl_world_of_one_with_the_real_sampler():
+    from epstan_amd import dist, models
+    from epstan_amd.method import Master
+    mod = models.m4b(6, 3, 60)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    kw = dict(site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=120, df0=0.4)
+    comm = dist.EpxComm(rank=0, world=1)
+    M = Master('m4b_sg', data.X, data.y, comm=comm, **kw)
+    L = Master('m4b_sg', data.X, data.y, **kw)
+    out = [m.run(2, verbose=False, return_analytics=True, seed=3) for m in (M, L)]
+    assert out[0][0] == out[1][0] == 0
+    np.testing.assert_array_equal(out[0][1][0], out[1][1][0])
+    np.testing.assert_array_equal(out[0][1][1], out[1][1][1])
+    np.testing.assert_array_equal(M.Qi, L.Qi)
+    for a, b in zip(out[0][2][:3], out[1][2][:3]):     # stimes differ (clock), msteps / mrhats must not
+        if a is not out[0][2][0]:
+            np.testing.assert_array_equal(a, b)
+    # the small host-side collectives of the communicator
+    assert comm.allreduce_min_int(1) == 1
+    np.testing.assert_array_equal(comm.allreduce_max(np.array([1.5, -2.0])), [1.5, -2.0])
+    np.testing.assert_array_equal(comm.allgather_sites(M.Qi, M.K), M.Qi)
+    comm.close()
+
+
+# ------------------------------------------------------------------ two processes
+def _worker(rank, world, port, mode, outdir, transport):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'] = str(rank)
+    os.environ['WORLD_SIZE'] = str(world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from epstan_amd import dist, models
+    from epstan_amd.method import Master
+    if transport == 'gloo':
+        import torch.distributed as tdist
+        tdist.init_process_group('gloo', rank=rank, world_size=world)
+        comm = dist.TorchComm()
+        device = 0                                     # both ranks share the one GPU
+    else:
+        comm = dist.EpxComm(rank=rank, world=world, port=port)
+        device = rank
+    runs = np.load(os.path.join(ROOT, 'tests', 'golden', 'master_run.npz'))
+    if mode == 'injected':
+        M = _g6_master(runs, 'smooth', 0.5, 4, comm=comm, device=device)
+        info, (m_s, S_s) = M.run(12, verbose=False, seed=1)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
+                 klo=M.k_lo, khi=M.k_hi)
+    elif mode == 'decay':
+        M = _g6_master(runs, 'wide_first', 1.0, 3, comm=comm, device=device)
+        info, (m_s, S_s) = M.run(4, verbose=False, seed=1)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
+                 klo=M.k_lo, khi=M.k_hi)
+    else:
+        mod = models.m4b(6, 3, 60)
+        data = mod.simulate_data(Sigma_x='rand', rng=100)
+        _, _, Q0, r0 = mod.get_prior()
+        M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+                   chains=4, iter=120, df0=0.4, comm=comm, device=device)
+        info, (m_s, S_s), an = M.run(1, verbose=False, return_analytics=True, seed=3)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
+                 klo=M.k_lo, khi=M.k_hi, msteps=an[1], mrhats=an[2])
+    comm.barrier()
+    if transport == 'gloo':
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
+    else:
+        comm.close()
+
+
+def _spawn(mode, tmp_path, transport, world=2):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path), transport), nprocs=world, join=True)
+    return [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+
+
+def _transports():
+    from epstan_amd import _lib
+    out = [pytest.param('gloo', id='gloo-shared-gpu')]
+    two = _lib.device_count() >= 2
+    out.append(pytest.param('rccl', id='rccl-2gpu',
+                            marks=pytest.mark.skipif(not two, reason='RCCL needs one device per rank')))
+    return out
+
+
+@pytest.mark.parametrize('transport', _transports())
+@pytest.mark.parametrize('mode,tag', [('injected', 'smooth'), ('decay', 'decay')])
+def test_two_ranks_reproduce_reference_trajectory_on_gpu(runs, tmp_path, mode, tag, transport):
+    res = _spawn(mode, tmp_path, transport)
+    K = runs['g6_%s_Qi' % tag].shape[2]
+    assert [(int(r['klo']), int(r['khi'])) for r in res] == [(0, K // 2), (K // 2, K)]
+    for r in res:
+        assert int(r['info']) == int(runs['g6_%s_info' % tag])
+        np.testing.assert_allclose(r['m'], runs['g6_%s_m' % tag], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['S'], runs['g6_%s_S' % tag], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['Qi'], runs['g6_%s_Qi' % tag], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(r['ri'], runs['g6_%s_ri' % tag], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(r['Q'], runs['g6_%s_Q' % tag], rtol=1e-8, atol=1e-9)
+    np.testing.assert_array_equal(res[0]['Qi'], res[1]['Qi'])      # gathered site arrays agree bit for bit
+
+
+@pytest.mark.parametrize('transport', _transports())
+def test_sharding_does_not_change_the_first_iteration_on_gpu(tmp_path, transport):
+    """Seeds are indexed by GLOBAL site id: one rank and two ranks sample the same draws in the
+    first iteration (identical cavities), so the site updates agree to reduction-order rounding."""
+    from epstan_amd import models
+    from epstan_amd.method import Master
+    res = _spawn('nuts', tmp_path, transport)
+    mod = models.m4b(6, 3, 60)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=120, df0=0.4)
+    info, (m_s, S_s), an = M.run(1, verbose=False, return_analytics=True, seed=3)
+    for r in res:
+        assert int(r['info']) == info == 0
+        np.testing.assert_allclose(r['m'], m_s, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['Qi'], M.Qi, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r['msteps'], an[1], rtol=1e-12)
+        np.testing.assert_allclose(r['mrhats'], an[2], rtol=1e-12)

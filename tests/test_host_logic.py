@@ -6,6 +6,7 @@ the oracle standing in for the device engine.  No GPU needed."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -493,3 +494,75 @@ def test_master_runs_a_gaussian_family_model_on_the_oracle_engine():
     assert m.shape == (4,) and np.all(np.linalg.eigvalsh(S) > 0)
     # beta (elements 2, 3) within a few posterior standard deviations of the truth
     assert np.all(np.abs(m[2:] - data.phi_true[2:]) < 5 * np.sqrt(np.diag(S)[2:]) + 0.2)
+
+
+# ------------------------------------------------------------------ round 2: launch + communicator plumbing
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` outside torchrun spawns two fresh ranks (here without GPUs:
+    --dry-run stops after the rendezvous) and rank 0 reports n_gpus = 2."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['dry_run'] is True
+
+
+def test_epxcomm_hands_the_rccl_id_from_rank_0_to_every_rank():
+    """The 128-byte id exchange of dist.EpxComm (plain TCP, late and early joiners alike)."""
+    import socket
+    import threading
+    import time as _time
+    from epstan_amd import _lib, dist
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    uid = bytes(range(128))
+    got = {}
+
+    def rank(r, delay):
+        _time.sleep(delay)
+        c = dist.EpxComm(rank=r, world=3, addr='127.0.0.1', port=port)
+        got[r] = c._exchange_id(uid if r == 0 else b'')
+
+    th = [threading.Thread(target=rank, args=(r, d)) for r, d in ((1, 0.0), (0, 0.3), (2, 0.6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert got == {0: uid, 1: uid, 2: uid} and len(uid) == _lib.COMM_ID_BYTES
+    with pytest.raises(ValueError):
+        dist.EpxComm(rank=3, world=3)
+
+
+def test_named_draws_restates_the_transformed_parameters():
+    """site_params.named_draws against the transformed-parameters blocks of
+    experiment/models/m4b_sg.stan:24-37, m1b_sg.stan, m4a_sg.stan and the multi-group m4b.stan:29-44."""
+    from epstan_amd import site_params as sp
+    rng = np.random.RandomState(0)
+    D, S = 3, 7
+    th = rng.randn(S, 3 * D + 3)                            # m4b_sg: phi (2D+2), eta, etb (D)
+    out = sp.named_draws(3, D, 1, False, True, th, ['alpha', 'beta', 'sigma_a', 'mu_b', 'phi', 'eta', 'etb'])
+    phi, eta, etb = th[:, :2 * D + 2], th[:, 2 * D + 2], th[:, 2 * D + 3:]
+    np.testing.assert_allclose(out['alpha'], phi[:, 0] + eta * np.exp(phi[:, 1]))
+    np.testing.assert_allclose(out['beta'], phi[:, 2:2 + D] + etb * np.exp(phi[:, 2 + D:]))
+    np.testing.assert_allclose(out['sigma_a'], np.exp(phi[:, 1]))
+    assert out['alpha'].shape == (S,) and out['beta'].shape == (S, D) and out['phi'].shape == (S, 2 * D + 2)
+    th1 = rng.randn(S, D + 2)                               # m1b_sg: phi = [log sigma_a, beta], eta
+    o1 = sp.named_draws(0, D, 1, False, True, th1, ['alpha', 'beta'])
+    np.testing.assert_allclose(o1['alpha'], th1[:, D + 1] * np.exp(th1[:, 0]))
+    np.testing.assert_allclose(o1['beta'], th1[:, 1:D + 1])
+    tha = rng.randn(S, 3 * D + 4)                           # m4a_sg: log sigma in front
+    oa = sp.named_draws(3, D, 1, True, True, tha, ['sigma', 'alpha'])
+    np.testing.assert_allclose(oa['sigma'], np.exp(tha[:, 0]))
+    np.testing.assert_allclose(oa['alpha'], tha[:, 1] + tha[:, 2 * D + 3] * np.exp(tha[:, 2]))
+    ng = 2                                                  # m4b (two groups): eta (2), etb (2 x D)
+    thg = rng.randn(S, 2 * D + 2 + ng + ng * D)
+    og = sp.named_draws(3, D, ng, False, False, thg, ['alpha', 'beta'])
+    assert og['alpha'].shape == (S, ng) and og['beta'].shape == (S, ng, D)
+    np.testing.assert_allclose(og['beta'][:, 1, :], thg[:, 2:2 + D] + thg[:, 2 * D + 2 + ng + D:] * np.exp(thg[:, 2 + D:2 + 2 * D]))
+    with pytest.raises(ValueError):
+        sp.named_draws(0, D, 1, False, True, th1, ['etb'])
