@@ -182,6 +182,12 @@ def main():
                               'ranks_seen': seen, 'dry_run': True, 'steps': steps, 'warmup': warm}))
         return
 
+    # stdout carries exactly ONE line, the JSON record: whatever native libraries print meanwhile
+    # (RCCL writes its version banner to fd 1) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from epstan_amd import dist as edist, models
     from epstan_amd.method import Master
@@ -229,7 +235,7 @@ def main():
     t_kernel = float(ms.mean()) * 1e-3
     achieved_tf = flops_per_launch / t_kernel / 1e12
     layout = M.engine.last_layout()
-    wg_per_site = args.chains if layout == 2 else 1
+    wg_per_site = args.chains if layout in (2, 6) else 1
     P = M.engine.P
     # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup), draws
     # and last states out
@@ -313,7 +319,8 @@ def main():
                                    'sample': 'failed: %r' % (ex,)}
     comm.barrier()
     comm.close()
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
 if __name__ == '__main__':

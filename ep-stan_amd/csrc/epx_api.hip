@@ -518,6 +518,33 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         }
     }
     if (layout == 4 && !lock) layout = 0;
+    // layouts 5 / 6 (nuts_duo.hip): row waves + a state wave per chain, LDS hand-offs.  5 = one workgroup per
+    // site (up to 4 chains), the default for batches that fill the chip; 6 = one workgroup per chain with 4 row waves
+    if (!lock && !c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
+        (layout == 5 || layout == 6 || (layout == 0 && many))) {
+        const int cpb = layout == 6 ? 1 : 4, rw = layout == 6 ? 4 : 1;
+        NutsArgs t = a;
+        const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
+        const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP && (c->n_max + 64 * rw - 1) / (64 * rw) <= 64;
+        if (fits) {
+            a = t;
+            a.err = c->err_flag;
+            layout = layout == 6 ? 6 : 5;
+            if (!a.stack_in_lds) {
+                const size_t need = (size_t)stack_sites * o.chains * o.max_depth * (4 * nv * 64 + 2);
+                if (c->stack_elems < need) {
+                    if (c->stack) (void)hipFree(c->stack);
+                    HIPCHK(dalloc(&c->stack, need));
+                    c->stack_elems = need;
+                }
+                a.stack = c->stack;
+            }
+            a.no_spec = 0;
+            *wpc_out = rw; *dp_out = dp; *nv_out = nv; *layout_out = layout;
+            return 0;
+        }
+        if (layout == 5 || layout == 6) layout = 0;
+    }
     if (layout == 0) layout = many ? 1 : 2;
     int wpc = 1;
     bool resident = !lock && dp > 0 && nv <= 2 && layout != 3 && !c->multi;      // several groups per site: layouts 3 / 4 only
@@ -561,6 +588,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
 }
 
 static int launch_sampler(const NutsArgs &a, int count, int wpc, int dp, int nv, int layout, hipStream_t stream) {
+    if (layout == 5 || layout == 6) return launch_nuts_duo(a, count, a.cpb, a.duo_rw, dp, nv, stream);
     if (layout >= 3) return launch_nuts_stream(a, count, dp, nv, stream);
     return launch_nuts(a, count, wpc, dp, nv, stream);
 }
@@ -583,7 +611,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // The launch ends with its slowest chain; this takes that chain at the faster tick.
     NutsArgs a2;
     int wpc2 = 0, dp2 = 0, nv2 = 0, n_lead = 0;
-    if (o.layout == 0 && layout == 1 && a.order && c->split_n > 0 && !eps_dev) {
+    if (o.layout == 0 && (layout == 1 || layout == 5) && a.order && c->split_n > 0 && !eps_dev) {
         n_lead = c->split_n < count ? c->split_n : count - 1;
         const int cap = c->n_cu / (2 * o.chains);          // at most half of the CUs for the lead sites
         if (n_lead > cap) n_lead = cap;
@@ -638,7 +666,13 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     c->has_last = 1;
     c->last_layout = layout;
     c->nsamp = o.chains * nkeep;
+    int herr = 0;
+    if (layout == 5 || layout == 6) HIPCHK(hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (herr) {
+        HIPCHK(hipMemset(c->err_flag, 0, sizeof(int)));
+        return fail("sampler: a hand-off between the waves of a chain timed out (code %d); the draws of this call are void", herr);
+    }
     if (elapsed_ms) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));

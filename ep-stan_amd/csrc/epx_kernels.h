@@ -141,11 +141,24 @@ struct NutsArgs {
     int no_spec;                  // 1: keep the bookkeeping on the gradient waves (k_nuts) even when off_spec > 0
     int grp;                      // 1: sites with several groups on layout 2 (k_nuts_spec<..., GRP>, nuts_gradient_groups.inc)
     int off_gl;                   // LDS offset of the site's group row limits (grp)
+    // k_nuts_duo (nuts_duo.hip): row waves + state waves with LDS hand-offs
+    int duo_rw;                   // row waves per chain
+    int off_tail;                 // cavity precision rows 64..d-1 (row-major, stride d rounded up to even)
+    int off_slot;                 // per chain: job / result slots
+    int off_flag;                 // per chain: hand-off sequence numbers
+    int slot_doubles;             // doubles of one chain's slots
+    int *err;                     // device word: set when a hand-off spin gives up (never in a healthy run)
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int
 int launch_nuts(const NutsArgs &a, int count, int wpc, int dp, int nv, hipStream_t stream);
 size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
+
+// row-wave / state-wave variant (nuts_duo.hip): cpb chains of a site per workgroup, every chain one
+// state wave + rw row waves that talk through LDS slots (no workgroup barrier in the loop)
+int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream);
+size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max);
+bool nuts_duo_has(int cpb, int rw, int dp, int nv);
 
 // streaming variant (nuts_stream.hip): one workgroup per site, chains in lock step, X through
 // an LDS-DMA ring; dpb in {64, 128}, nv = ceil(P/64) <= 7.  a.stack holds, per (site of the

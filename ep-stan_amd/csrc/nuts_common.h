@@ -1,0 +1,62 @@
+// Pieces shared by the LDS-resident sampler kernels (nuts.hip, nuts_duo.hip): the register layout
+// of a length-P vector (element e in lane e % 64, register e / 64) and the transposing butterfly.
+#pragma once
+#include "epx_device.h"
+#include "epx_kernels.h"
+
+namespace epx {
+
+template <int NV> struct Vec { double v[NV]; };
+
+#define FORV _Pragma("unroll") for (int i = 0; i < NV; ++i)
+
+template <int NV>
+__device__ inline double gatherV(const Vec<NV> &x, int e) {
+    double r = 0.0;
+    FORV {
+        const double t = __shfl(x.v[i], e & 63, 64);
+        if ((e >> 6) == i) r = t;
+    }
+    return r;
+}
+// element e (wave-uniform index) as a scalar
+template <int NV>
+__device__ inline double elemU(const Vec<NV> &x, int e) {
+    double r = 0.0;
+    FORV { if ((e >> 6) == i) r = readlane_d(x.v[i], e & 63); }
+    return r;
+}
+
+template <int DP> struct Log2 { static constexpr int v = 1 + Log2<DP / 2>::v; };
+template <> struct Log2<1> { static constexpr int v = 0; };
+
+enum { MODE_INIT = 0, MODE_SS = 1, MODE_TREE = 2 };
+
+// Transposing reduction of CNT per-lane partial sums over the 64 lanes of a wave:
+// each stage halves the values a lane carries and doubles the lanes summed, so
+// CNT values cost CNT-1 exchanges (not 6*CNT).  Stage with selector bit B keeps
+// the half of the values chosen by the lane's own bit B and receives the same
+// half from a partner lane whose bit B differs.  Fully static indexing.
+template <int CNT, int B>
+__device__ inline void butterfly(double *acc, int lane) {
+    if constexpr (CNT > 1) {
+        if constexpr (B >= 4) {
+#pragma unroll
+            for (int j = 0; j < CNT / 2; ++j) acc[j] = swap_add_d<B>(acc[j], acc[j + CNT / 2]);
+        } else {
+            const bool upper = (lane >> B) & 1;
+#pragma unroll
+            for (int j = 0; j < CNT / 2; ++j) {
+                const double send = upper ? acc[j] : acc[j + CNT / 2];
+                const double keep = upper ? acc[j + CNT / 2] : acc[j];
+                acc[j] = keep + partner_d<B>(send, lane);
+            }
+        }
+        butterfly<CNT / 2, B - 1>(acc, lane);
+    } else if constexpr (B >= 0) {
+        acc[0] += partner_d<B>(acc[0], lane);
+        butterfly<1, B - 1>(acc, lane);
+    }
+}
+
+}  // namespace epx

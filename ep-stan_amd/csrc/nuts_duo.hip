@@ -1,0 +1,554 @@
+// k_nuts_duo: the LDS-resident sampler with the work of a chain split over waves by ROLE.
+//
+// Replaces the Stan subprocess of /root/reference/epstan/method.py:43-118, 349-363 exactly like
+// k_nuts (nuts.hip); same algorithm (nuts_state_machine.inc), same arithmetic in the same order,
+// hence the same draws bit for bit as k_nuts with one wave per chain (tested).
+//
+// Why: with one wave per chain (k_nuts, layout 1) that wave carries the 23 state vectors of the
+// tree bookkeeping AND the 64 + 64 row / accumulator registers of the gradient: 256 VGPRs + 247
+// AGPRs of spill at D = 32, and every part of a leapfrog runs one after the other (measured at
+// the C3 site size: 23 800 cycles per leapfrog, 36 % row loop, 31 % cavity mat-vec, 14 % tree
+// bookkeeping, 10 % chain rule).  Here a chain is
+//   * RW row waves (R): wait for (alpha, beta) -> fused row pass over their rows of the LDS-resident
+//     X -> transposing butterfly -> publish (X'g, sum g, log-lik);
+//   * one state wave (S): owns the NUTS state.  Per leapfrog it takes the half kick + drift,
+//     publishes (alpha, beta) and, WHILE the row waves sweep the rows, computes the cavity term
+//     Omega (phi - mu) and runs the tree bookkeeping of the PREVIOUS leapfrog's state; then the
+//     chain rule and the second half kick.
+// The trajectory is integrated speculatively one leapfrog ahead of the bookkeeping (as in
+// k_nuts_spec): when the bookkeeping decides to continue elsewhere (other tree end, new
+// transition, step-size trial, new metric) the job in flight is dropped -- one wasted gradient per
+// change of direction.  Accepted states are those of the sequential algorithm.
+//
+// Hand-offs go through LDS slots with sequence numbers (ds_write data, s_waitcnt, ds_write flag /
+// poll): the chains of a workgroup are NOT coupled by a barrier, a finished chain's waves leave.
+// Every spin is bounded; a spin that gives up raises NutsArgs::err and ends the chain (the host
+// reports it) instead of hanging the GPU.
+#include "nuts_common.h"
+
+namespace epx {
+
+enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23 };
+
+__device__ inline int duo_wait(const volatile int *flag, int want) {
+    for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+        const int v = __builtin_amdgcn_readfirstlane(*flag);
+        if (v == want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return DUO_TIMEOUT;
+}
+// everything this wave wrote to LDS is visible before the flag that follows
+__device__ inline void duo_publish(volatile int *flag, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *flag = v;
+}
+
+#define STAMP(i) do { } while (0)
+
+template <int NV, int DP, int CPB, int RW, bool STL>
+__global__ void __launch_bounds__(64 * CPB * (1 + RW))
+k_nuts_duo(NutsArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    using V = Vec<NV>;
+    constexpr int LOG = Log2<DP>::v;
+    constexpr int SPR = DP / 2;                       // 16-B slots per row
+    constexpr int RPL = DP >= 32 ? 1 : 32 / DP;       // rows per 256-B bank line
+    constexpr int SREC = 4 * NV * 64 + 2;             // per-level stack record (doubles)
+    constexpr int RES = DP + 2;                       // result of a row wave: X'g (DP), sum g, log-lik
+    constexpr int JOB = RW == 1 ? 0 : DP + 2;         // job (alpha, beta): its own slot, or (RW == 1) the result's
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // waves 0..CPB-1: state wave of chain c; then the row waves.  A workgroup's waves go to the SIMDs
+    // round robin, so wave w and w + 4 share one: the row waves of chain c sit CPB waves behind the
+    // state wave of chain c + 1 -- a chain that is the last one running keeps its two roles on different SIMDs
+    const bool is_state = wave < CPB;
+    const int team = is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB;
+    const int wr = is_state ? 0 : (wave - CPB) % RW;
+    const int bps = (a.chains + CPB - 1) / CPB;
+    const int sb = a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps), cb = blockIdx.x % bps;
+    const int k = a.k0 + sb;
+    const int chain = cb * CPB + team;
+    const int D = a.D, d = a.d, P = a.P, model = a.model;
+    const int64_t row0 = a.k_lim[k];
+    const int n = (int)(a.k_lim[k + 1] - row0);
+    const int dm = d < 64 ? d : 64;                   // cavity precision: rows / columns held pair-interleaved
+    const int tr = d - dm;                            // ... and the rows beyond (0..2 for D <= 32)
+    const int dpad = d + (d & 1);
+
+    double *Xs = reinterpret_cast<double *>(smem);
+    double *Oms = reinterpret_cast<double *>(smem + a.off_Om);        // [(pair p, row e)] -> (Om[e][2p], Om[e][2p+1])
+    double *Ots = reinterpret_cast<double *>(smem + a.off_tail);      // [row r - 64][column], stride dpad
+    double *slot = reinterpret_cast<double *>(smem + a.off_slot) + (size_t)team * a.slot_doubles;
+    volatile int *flags = reinterpret_cast<volatile int *>(smem + a.off_flag) + team * (1 + RW);
+    volatile int *f_job = flags, *f_res = flags + 1;
+
+    // ---- stage the site: rows HBM -> LDS once per site update (as k_nuts), cavity precision re-laid
+    {
+        const double *Xg = a.X + (size_t)row0 * D;
+        const int nslot = n * SPR;
+        for (int s = tid; s < nslot; s += blockDim.x) {
+            const int r = s / SPR, jp = s % SPR, c0 = 2 * jp;
+            double2 v;
+            if ((D & 1) == 0 && c0 + 1 < D) v = *reinterpret_cast<const double2 *>(Xg + (size_t)r * D + c0);
+            else {
+                v.x = c0 < D ? Xg[(size_t)r * D + c0] : 0.0;
+                v.y = c0 + 1 < D ? Xg[(size_t)r * D + c0 + 1] : 0.0;
+            }
+            const int sw = (r / RPL) & (SPR - 1);
+            *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
+        }
+        const double *Om_g = a.cav_Om + (size_t)k * d * d;                // column-major, symmetric
+        const int npair = (dm + 1) / 2;
+        for (int idx = tid; idx < npair * dm; idx += blockDim.x) {
+            const int p = idx / dm, e = idx % dm;
+            double2 v;
+            v.x = Om_g[(size_t)(2 * p) * d + e];
+            v.y = 2 * p + 1 < dm ? Om_g[(size_t)(2 * p + 1) * d + e] : 0.0;
+            *reinterpret_cast<double2 *>(Oms + 2 * (size_t)idx) = v;
+        }
+        for (int idx = tid; idx < tr * dpad; idx += blockDim.x) {
+            const int r = idx / dpad, j = idx % dpad;
+            Ots[idx] = j < d ? Om_g[(size_t)j * d + dm + r] : 0.0;
+        }
+        if (tid < CPB * (1 + RW)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
+    }
+    __syncthreads();                                   // the only workgroup barrier of the kernel
+    if (chain >= a.chains) return;
+
+    if (!is_state) {
+        // ================================================================= row wave
+        // responses of this lane's rows as a bit mask (row of iteration `it`: wr*64 + lane + it*64*RW)
+        unsigned long long ybits = 0;
+        {
+            int it = 0;
+            for (int r = wr * 64 + lane; r < n; r += 64 * RW, ++it)
+                if (a.y[row0 + r]) ybits |= 1ull << it;
+        }
+        for (int seq = 1;; ++seq) {
+            const int got = duo_wait(f_job, seq);
+            if (got != seq) {
+                if (got == DUO_TIMEOUT && lane == 0) atomicOr(a.err, 1);
+                return;
+            }
+            const double *job = slot + JOB;
+            const double alpha = job[0];
+            double beta_l = job[1 + (lane < DP ? lane : 0)];
+            if (lane >= D) beta_l = 0.0;
+            double bs[DP];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
+            // ---- fused row pass: f = alpha + x.beta, g = y - sigmoid(f), acc += g x   (nuts_gradient.inc)
+            double acc[DP];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) acc[j] = 0.0;
+            double da = 0.0, ll = 0.0, wprod = 1.0;
+            unsigned long long yb = ybits;
+            for (int r = wr * 64 + lane; r < n; r += 64 * RW) {
+                const double2 *rowp = reinterpret_cast<const double2 *>(Xs + (size_t)r * DP);
+                const int sw = (r / RPL) & (SPR - 1);
+                double x[DP];
+#pragma unroll
+                for (int jp = 0; jp < SPR; ++jp) {
+                    const double2 v = rowp[jp ^ sw];
+                    x[2 * jp] = v.x; x[2 * jp + 1] = v.y;
+                }
+                double f0 = alpha, f1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < DP; j += 2) { f0 = fma(x[j], bs[j], f0); f1 = fma(x[j + 1], bs[j + 1], f1); }
+                const double f = f0 + f1;
+                double l, w, g;
+                logistic_split(f, (double)(yb & 1ull), l, w, g);
+                yb >>= 1;
+                ll += l; wprod *= w; da += g;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) acc[j] = fma(g, x[j], acc[j]);
+            }
+            ll -= log_ge1_d(wprod);
+            butterfly<DP, 5>(acc, lane);
+            wave_sum2(da, ll);
+            double *res = slot + (RW == 1 ? 0 : JOB + wr * RES);
+            if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
+            if (lane == 0) { res[DP] = da; res[DP + 1] = ll; }
+            duo_publish(f_res + wr, seq);
+        }
+    }
+
+    // ===================================================================== state wave
+    const int wt = 0;
+    double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
+    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
+    auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
+    const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
+    const bool laplace = (model == 4);
+
+    V mu, inv_e, qs, gs, zq, zp, zg, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;
+    double lps = 0, zlp = 0, plp = 0, mlp = 0;
+    FORV {
+        const int e = lane + 64 * i;
+        mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
+        inv_e.v[i] = 1.0;
+        wmean.v[i] = 0.0; wm2.v[i] = 0.0;
+        gs.v[i] = 0; zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
+        mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
+    }
+    {
+        const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        FORV {
+            const int e = lane + 64 * i;
+            double q0 = 0.0;
+            if (e < P) {
+                if (a.init_mode == 2) q0 = lastp[e];
+                else if (a.init_mode == 0) {
+                    double u1, u2;
+                    rng_u2(key, 0, K_INIT, (uint32_t)(e >> 1), 0, u1, u2);
+                    q0 = -2.0 + 4.0 * ((e & 1) ? u2 : u1);
+                }
+            }
+            qs.v[i] = q0;
+        }
+    }
+    // adaptation state (stepsize_adaptation.hpp / windowed_adaptation.hpp @ Stan 2.17)
+    const double DELTA = 0.8, GAMMA = 0.05, T0 = 10.0, KAPPA = 0.75, LOG08 = -0.2231435513142097558;
+    double eps = 1.0, da_mu = log(10.0), s_bar = 0, x_bar = 0, da_count = 0;
+    int va_init_buf = 75, va_term = 50, va_base = 25;
+    if (va_init_buf + va_base + va_term > a.warmup && a.warmup >= 20) {
+        va_init_buf = (int)(0.15 * a.warmup);
+        va_term = (int)(0.1 * a.warmup);
+        va_base = a.warmup - (va_init_buf + va_term);
+    }
+    int va_counter = 0, va_wsize = va_base, va_next = va_init_buf + va_base - 1;
+    double va_n = 0;
+    double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
+    int ndiv = 0, npost = 0, kept = 0, failed = 0;
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
+    uint32_t ss_t = 0;
+    double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;
+    double u_dir = 0.0, gum = 0.0;
+    double dhb = 0.0, lw_m = -INFINITY, lw_s = 0.0;
+    FORV { zq.v[i] = qs.v[i]; }
+    const bool teacher = a.eps_in != nullptr;       // fixed step size / metric (test hook)
+    if (teacher) {
+        eps = a.eps_in[(size_t)sb * a.chains + chain];
+        if (a.inv_e_in) {
+            const double *ie = a.inv_e_in + ((size_t)sb * a.chains + chain) * P;
+            FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
+        }
+    }
+    const uint32_t toff = (uint32_t)a.t_offset + 1u;
+    auto flush_dh = [&](int cnt) {
+        const bool ok = lane < cnt;
+        const double dh = ok ? dhb : -INFINITY;
+        const double mb = wave_max(dh);
+        const double m_new = fmax(lw_m, mb);
+        double w = 0.0, me = 0.0;
+        if (ok) {
+            w = (m_new == -INFINITY) ? 0.0 : exp(dh - m_new);
+            me = dh > 0 ? 1.0 : exp(dh);
+        }
+        wave_sum2(w, me);
+        const double scale = (lw_m == -INFINITY) ? 0.0 : exp(lw_m - m_new);
+        lw_s = lw_s * scale + w;
+        lw_m = m_new;
+        sum_metro += me;
+    };
+
+    // per element: column of X'g its chain-rule term reads, clamped into the slot
+    int jdx[NV];
+    FORV {
+        const int e = lane + 64 * i;
+        int j;
+        if (model == 0) j = e - 1;
+        else if (model == 1) j = e - 3;
+        else if (model == 2) j = e <= D ? e - 1 : e - d - 1;
+        else j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
+        jdx[i] = j < 0 ? 0 : (j > DP - 1 ? DP - 1 : j);
+    }
+    const int rc = lane < tr ? lane : (tr > 0 ? tr - 1 : 0);
+    auto xtg = [&](int j) -> double {                  // X'g[j] summed over the chain's row waves, in wave order
+        if constexpr (RW == 1) return slot[j];
+        else {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) s += slot[JOB + w * RES + j];
+            return s;
+        }
+    };
+
+    // (zq, zp, zg) holds the last finished leapfrog state; `pending`: its bookkeeping is still to run
+    double f_lp = 0.0, f_kin = 0.0;
+    bool pending = false;
+    int seq = 0, bail = 0;
+    const int lane0 = lane;
+
+    for (;;) {
+        // `lane` is re-derived through an opaque move every leapfrog, otherwise the per-element index
+        // arithmetic below is hoisted out of the loop and spilled (as in k_nuts_spec)
+        int lane_v = lane0;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
+        // ---- first half of the leapfrog from (zq, zp, zg): speculative while `pending`
+        V sq, sp, sg, eq;
+        FORV sp.v[i] = zp.v[i] + 0.5 * eps_l * zg.v[i];
+        FORV sq.v[i] = zq.v[i] + eps_l * inv_e.v[i] * sp.v[i];
+        FORV eq.v[i] = exp_d(sq.v[i]);
+        double alpha, sa, eta, sb2 = 0.0, beta_l;
+        if (model == 0) {
+            sa = elemU(eq, 0); eta = elemU(sq, d);
+            alpha = eta * sa; beta_l = gatherV(sq, 1 + lane);
+        } else if (model == 1) {
+            sa = elemU(eq, 0); sb2 = elemU(eq, 1); eta = elemU(sq, 2);
+            alpha = eta * sa; beta_l = gatherV(sq, 3 + lane) * sb2;
+        } else if (model == 2) {
+            sa = elemU(eq, 0); eta = elemU(sq, d);
+            alpha = eta * sa; beta_l = gatherV(sq, d + 1 + lane) * gatherV(eq, 1 + lane);
+        } else {
+            sa = elemU(eq, 1); eta = elemU(sq, d);
+            alpha = elemU(sq, 0) + eta * sa;
+            beta_l = gatherV(sq, 2 + lane) + gatherV(sq, d + 1 + lane) * gatherV(eq, 2 + D + lane);
+        }
+        // ---- hand (alpha, beta) to the row waves
+        {
+            double *job = slot + JOB;
+            if (lane < DP) job[1 + lane] = beta_l;
+            if (lane == 0) job[0] = alpha;
+            ++seq;
+            duo_publish(f_job, seq);
+        }
+        const double job_eps = eps_l;
+
+        // ---- while they sweep the rows: the bookkeeping of the leapfrog that finished before this one
+        if (pending) {
+            pending = false;
+            zlp = f_lp;
+            const double kin = f_kin;
+            const int fwd_was = fwd;
+            ngrad += 1.0;
+            V n_rho, n_psl, n_pq, n_pg, psr;
+            double n_key = 0, n_plp = 0;
+            int leave = 0, parked = 1;
+            do {
+#define EPX_CHAIN_EXIT { leave = 1; parked = 0; break; }
+#define EPX_DBG_EXIT { leave = 2; parked = 0; break; }
+#define STAMP_LEAF do { } while (0)
+#include "nuts_state_machine.inc"
+#undef STAMP_LEAF
+#undef EPX_CHAIN_EXIT
+#undef EPX_DBG_EXIT
+                parked = 0;
+            } while (0);
+            // The trajectory goes on from the state just booked -- so the job in flight is the wanted
+            // one -- in two cases: the leaf was parked as a pending left sibling (`continue` inside the
+            // include), or a subtree was completed and the next doubling extends the SAME end of the
+            // tree (its first state is the leaf just booked; step size and metric only change between
+            // transitions).  Everything else (other end, new transition, step-size trial) restarts.
+            const bool same_end = mode == MODE_TREE && depth > 0 && fwd == fwd_was && eps_l == job_eps;
+            if (leave || !(parked || same_end)) {
+                // the job in flight continues a trajectory that is no longer wanted: let it land, drop it
+                for (int w = 0; w < RW; ++w) {
+                    const int got = duo_wait(f_res + w, seq);
+                    if (got != seq) bail = 1;
+                }
+                if (bail || leave) { bail |= leave << 1; break; }
+                continue;
+            }
+        }
+
+        // ---- cavity term Ov = Omega (phi - mu) of the position in flight ...
+        V vv, Ov;
+        FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? sq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
+        {
+            const int npair = (dm + 1) / 2;
+            const int e0 = lane < dm ? lane : dm - 1;
+            const double2 *Op = reinterpret_cast<const double2 *>(Oms) + e0;
+            const double2 *Tp = reinterpret_cast<const double2 *>(Ots + (size_t)rc * dpad);
+            for (int p = 0; p < npair; ++p) {
+                const double v0 = readlane_d(vv.v[0], (2 * p) & 63), v1 = readlane_d(vv.v[0], (2 * p + 1) & 63);
+                const double2 o = Op[(size_t)p * dm];
+                Ov.v[0] = fma(o.x, v0, Ov.v[0]);
+                Ov.v[0] = fma(o.y, 2 * p + 1 < dm ? v1 : 0.0, Ov.v[0]);
+                if constexpr (NV > 1) {
+                    if (tr > 0) {
+                        const double2 tt = Tp[p];
+                        Ov.v[1] = fma(tt.x, v0, Ov.v[1]);
+                        Ov.v[1] = fma(tt.y, 2 * p + 1 < dm ? v1 : 0.0, Ov.v[1]);
+                    }
+                }
+            }
+            if constexpr (NV > 1) {
+                for (int c = 0; c < tr; ++c) {                           // columns 64.. : the tail rows by symmetry
+                    const double vc = readlane_d(vv.v[1], c);
+                    Ov.v[0] = fma(Ots[(size_t)c * dpad + e0], vc, Ov.v[0]);
+                    Ov.v[1] = fma(Ots[(size_t)rc * dpad + dm + c], vc, Ov.v[1]);
+                }
+            }
+        }
+        FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
+        // ... and the parts of the chain rule that only need the position
+        V g_etbq, g_sbj;
+        FORV { g_etbq.v[i] = 0.0; g_sbj.v[i] = 0.0; }
+        if (model == 2) {
+            FORV { const int e = lane + 64 * i; const int j = e <= D ? e - 1 : e - d - 1;
+                   g_etbq.v[i] = gatherV(sq, d + 1 + j); g_sbj.v[i] = gatherV(eq, 1 + j); }
+        } else if (model >= 3) {
+            FORV { const int e = lane + 64 * i; const int j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
+                   g_etbq.v[i] = gatherV(sq, d + 1 + j); g_sbj.v[i] = gatherV(eq, 2 + D + j); }
+        }
+
+        // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
+        for (int w = 0; w < RW; ++w) {
+            const int got = duo_wait(f_res + w, seq);
+            if (got != seq) bail = 1;
+        }
+        if (bail) break;
+        double da, ll;
+        if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
+        else {
+            da = 0.0; ll = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) { da += slot[JOB + w * RES + DP]; ll += slot[JOB + w * RES + DP + 1]; }
+        }
+        da = uniform_d(da); ll = uniform_d(ll);
+        double lpt = 0.0;
+        {
+            double dot = 0.0;
+            if (model == 1) {
+                double tsum = 0.0;
+                FORV { const int e = lane + 64 * i; const double t2 = xtg(jdx[i]); if (e >= 3 && e < P) tsum += t2 * sq.v[i]; }
+                dot = wave_sum(tsum);
+            }
+            const double c_da = da, c_sa = da * eta * sa, c_eta = da * sa;
+            FORV {
+                const int e = lane + 64 * i;
+                const double q = sq.v[i];
+                const bool in_phi = e < d, in_par = e < P;
+                const double ov = Ov.v[i];
+                double g = in_phi ? -ov : 0.0;
+                const double lp_phi = -0.5 * vv.v[i] * ov;
+                const double lp_pri = laplace ? -fabs(q) : -0.5 * q * q;
+                lpt += in_phi ? lp_phi : (in_par ? lp_pri : 0.0);
+                const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;    // d/dq of the N(0,1)/Laplace term
+                const double g_eta = c_eta - pr;
+                double add = 0.0, g_etb = 0.0;
+                const double db = xtg(jdx[i]);
+                if (model == 0) {
+                    add = (e >= 1 && e <= D) ? db : add;
+                    add = e == 0 ? c_sa : add;
+                } else if (model == 1) {
+                    g_etb = db * sb2 - pr;
+                    add = e == 1 ? dot * sb2 : add;
+                    add = e == 0 ? c_sa : add;
+                } else if (model == 2) {
+                    g_etb = db * g_sbj.v[i] - pr;
+                    add = (e >= 1 && e <= D) ? db * g_etbq.v[i] * eq.v[i] : add;
+                    add = e == 0 ? c_sa : add;
+                } else {
+                    g_etb = db * g_sbj.v[i] - pr;
+                    add = (e >= 2 + D && in_phi) ? db * g_etbq.v[i] * eq.v[i] : add;
+                    add = (e >= 2 && e < 2 + D) ? db : add;
+                    add = e == 1 ? c_sa : add;
+                    add = e == 0 ? c_da : add;
+                }
+                g = in_phi ? g + add : g;
+                g = e == d ? g_eta : g;
+                g = (e > d && in_par) ? g_etb : g;
+                sg.v[i] = in_par ? g : 0.0;
+            }
+        }
+        double ks = 0.0;
+        FORV { sp.v[i] += 0.5 * eps_l * sg.v[i]; ks += inv_e.v[i] * sp.v[i] * sp.v[i]; }
+        // the trajectory continues from here unless the bookkeeping (next round, beside the next
+        // row pass) says otherwise
+        FORV { zq.v[i] = sq.v[i]; zp.v[i] = sp.v[i]; zg.v[i] = sg.v[i]; }
+        wave_sum2(lpt, ks);
+        f_lp = lpt + ll;
+        f_kin = 0.5 * ks;
+        pending = true;
+    }
+
+    // ------------------------------------------------------------- epilogue (the state wave owns the chain)
+    *f_job = DUO_EXIT;                                 // the row waves leave
+    if (bail & 1) {
+        if (lane == 0) atomicOr(a.err, 2);
+        failed = 2;
+    }
+    if (bail & 4) return;                              // test hook (a.dbg): lp and gradient are written
+    {
+        double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
+        FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
+        if (failed) {
+            for (int kk = 0; kk < a.nkeep; ++kk) {
+                double *dst = a.draws + (((size_t)k * a.chains + chain) * a.nkeep + kk) * P;
+                FORV { const int e = lane + 64 * i; if (e < P) dst[e] = qs.v[i]; }
+            }
+        }
+        if (lane == 0) {
+            double *st = a.chain_stats + ((size_t)k * a.chains + chain) * ST_COUNT;
+            st[ST_STEPSIZE_MEAN] = a.iter > 0 && !failed ? eps_sum / a.iter : 0.0;
+            st[ST_STEPSIZE_FINAL] = eps;
+            st[ST_NLEAP] = nleap_tot;
+            st[ST_NGRAD] = ngrad;
+            st[ST_NDIV] = ndiv;
+            st[ST_ACCEPT_MEAN] = npost ? acc_sum / npost : 0.0;
+            st[ST_DEPTH_MEAN] = npost ? depth_sum / npost : 0.0;
+            st[ST_FAIL] = failed;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side: LDS layout + dispatch over the instantiated shapes
+size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
+    const int nv = (a.P + 63) / 64;
+    const int d = a.d, dm = d < 64 ? d : 64, tr = d - dm, dpad = d + (d & 1);
+    size_t off = (size_t)n_max * dp * 8;
+    a.n_max = n_max; a.duo_rw = rw; a.cpb = cpb;
+    a.off_Om = (int)off; off += (size_t)((dm + 1) / 2) * dm * 16;
+    a.off_tail = (int)off; off += (size_t)tr * dpad * 8;
+    off = (off + 15) & ~(size_t)15;
+    a.slot_doubles = rw == 1 ? dp + 2 : (1 + rw) * (dp + 2);
+    a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
+    a.off_flag = (int)off; off += (size_t)cpb * (1 + rw) * 4;
+    off = (off + 15) & ~(size_t)15;
+    a.om_in_lds = 1;
+    const size_t cap = 160 * 1024;
+    const size_t stack = (size_t)cpb * a.max_depth * (4 * nv * 64 + 2) * 8;
+    a.stack_in_lds = 0; a.off_stack = (int)off;
+    if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
+    a.lds_bytes = (int)off;
+    return off;
+}
+
+template <int NV, int DP, int CPB, int RW>
+static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
+    auto go = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * CPB * (1 + RW)), a.lds_bytes, stream, a);
+        return (int)hipGetLastError();
+    };
+    return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true>) : go(k_nuts_duo<NV, DP, CPB, RW, false>);
+}
+
+template <int NV, int DP>
+static int launch_duo_shape(const NutsArgs &a, int nblocks, int cpb, int rw, hipStream_t stream) {
+    if (cpb == 4 && rw == 1) return launch_duo_one<NV, DP, 4, 1>(a, nblocks, stream);
+    if (cpb == 1 && rw == 4) return launch_duo_one<NV, DP, 1, 4>(a, nblocks, stream);
+    return -1;
+}
+
+bool nuts_duo_has(int cpb, int rw, int dp, int nv) {
+    return ((cpb == 4 && rw == 1) || (cpb == 1 && rw == 4)) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
+}
+
+int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream) {
+    if (!nuts_duo_has(cpb, rw, dp, nv)) return -1;
+    const int nblocks = count * ((a.chains + cpb - 1) / cpb);
+    if (nv == 1) return dp == 16 ? launch_duo_shape<1, 16>(a, nblocks, cpb, rw, stream) : launch_duo_shape<1, 32>(a, nblocks, cpb, rw, stream);
+    return dp == 16 ? launch_duo_shape<2, 16>(a, nblocks, cpb, rw, stream) : launch_duo_shape<2, 32>(a, nblocks, cpb, rw, stream);
+}
+
+}  // namespace epx
