@@ -143,6 +143,8 @@ def main():
     ap.add_argument('--siter', type=int, default=200)
     ap.add_argument('--prec-estim', default='sample')
     ap.add_argument('--layout', type=int, default=0)
+    ap.add_argument('--adapt', default='fresh', choices=['fresh', 'carry'],
+                    help="'fresh' = the reference's behaviour (default, the headline); 'carry' = opt-in carried adaptation")
     ap.add_argument('--cor-input', type=int, default=None, help='0: uncorrelated covariates (fit.py cor_input=False)')
     ap.add_argument('--cpu-sites', type=int, default=32, help='sites of the all-cores cpu_baseline leg; 0 disables it')
     ap.add_argument('--cpu-seq-sites', type=int, default=3, help='sites of the reference-faithful schedule')
@@ -200,7 +202,7 @@ def main():
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
                chains=args.chains, iter=args.siter, prec_estim=args.prec_estim,
                df0=models.default_df0(J), comm=comm, device=local_rank, layout=args.layout,
-               sync_sites=False)
+               adapt=args.adapt, sync_sites=False)
     rccl_rank, rccl_world = comm.size()
 
     def sync():
@@ -291,10 +293,12 @@ def main():
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'ep_iters_per_sec': steps / tmax,
         'config': {'workload': 'hierarchical logistic regression %s, J=%d sites (=%d/GPU), D=%d, n_j=%d, '
-                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s'
+                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s%s'
                                % (args.model, J, sites, D, n, args.chains, args.siter,
                                   args.chains * (args.siter - args.siter // 2), args.prec_estim,
-                                  '' if cor else ', uncorrelated covariates'),
+                                  '' if cor else ', uncorrelated covariates',
+                                  '' if args.adapt == 'fresh' else ', adapt=carry (NOT the reference\'s per-update re-adaptation)'),
+                   'adapt': args.adapt,
                    'name': args.config if (args.sites, args.D, args.n) == (None, None, None) else 'custom',
                    'parallelism': 'sites sharded over %d GPU(s), 1 RCCL all-reduce/iter inside libepx.so' % world,
                    'rccl_world_size': rccl_world},

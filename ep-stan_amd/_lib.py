@@ -70,6 +70,7 @@ SIGNATURES = {
     'epx_global_moments': (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p]),
     'epx_force_pd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, c_uint8_p]),
+    'epx_get_adapt': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p]),
     'epx_logdensity_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
     'epx_logdensity_grad_layout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int,
                                                   ctypes.POINTER(ctypes.c_double), c_double_p]),

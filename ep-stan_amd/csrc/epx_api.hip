@@ -261,7 +261,7 @@ int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)epx_comm_destroy(c);
-    void *ptrs[] = {c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -442,6 +442,15 @@ static int ensure_sampler_buffers(epx_ctx *c, int chains, int nkeep) {
         HIPCHK(dalloc(&c->chain_stats, K * chains * ST_COUNT));
         HIPCHK(dalloc(&c->site_stats, K * 8));
         HIPCHK(dalloc(&c->seeds_d, K));
+        if (c->carry_eps) (void)hipFree(c->carry_eps);
+        if (c->carry_metric) (void)hipFree(c->carry_metric);
+        c->carry_eps = c->carry_metric = nullptr; c->carry_chains = 0;
+        HIPCHK(dalloc(&c->carry_eps, K * chains));
+        HIPCHK(dalloc(&c->carry_metric, K * P));
+        {
+            std::vector<double> neg(K * chains, -1.0);       // no history yet
+            HIPCHK(hipMemcpy(c->carry_eps, neg.data(), neg.size() * 8, hipMemcpyHostToDevice));
+        }
         HIPCHK(hipMemset(c->last, 0, K * chains * P * 8));
         HIPCHK(hipMemset(c->chain_stats, 0, K * chains * ST_COUNT * 8));
         c->s_chains = chains; c->s_nkeep = nkeep; c->has_last = 0;
@@ -530,8 +539,9 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
             a = t;
             a.err = c->err_flag;
             layout = layout == 6 ? 6 : 5;
-            if (!a.stack_in_lds) {
-                const size_t need = (size_t)stack_sites * o.chains * o.max_depth * (4 * nv * 64 + 2);
+            const size_t per_chain = nuts_duo_chain_doubles(a, nv);
+            if (per_chain) {
+                const size_t need = (size_t)stack_sites * o.chains * per_chain;
                 if (c->stack_elems < need) {
                     if (c->stack) (void)hipFree(c->stack);
                     HIPCHK(dalloc(&c->stack, need));
@@ -604,6 +614,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv, &layout)) return -1;
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
     a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
+    const bool want_carry = (o.reserved & 2) != 0 && !eps_dev;
+    if (want_carry) { a.carry_eps = c->carry_eps; a.carry_metric = c->carry_metric; }
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
     // Split launch (epx_set_site_split): the leading sites of the order -- the ones expected to
     // need the most leapfrogs -- run one workgroup per chain (layout 2, shorter leapfrog) on a
@@ -624,6 +636,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
             else {
                 a2.seeds = c->seeds_d; a2.draws = c->draws; a2.last = c->last; a2.chain_stats = c->chain_stats;
                 a2.eps_in = nullptr; a2.inv_e_in = nullptr; a2.t_offset = t_offset;
+                a2.carry_eps = a.carry_eps; a2.carry_metric = a.carry_metric;
                 a2.order = a.order;
                 a.order = a.order + n_lead;
             }
@@ -663,6 +676,15 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     ra.draws = c->draws; ra.chain_stats = c->chain_stats; ra.site_stats = c->site_stats;
     hipLaunchKernelGGL(k_site_stats, dim3(count), dim3(128), 0, c->stream, ra);
     HIPCHK(hipGetLastError());
+    if (!eps_dev && !a.dbg) {
+        // history for `adapt = carry` (cheap: one pass over the kept draws); written after every real sampling call
+        CarryArgs ca;
+        ca.k0 = k0; ca.chains = o.chains; ca.nkeep = nkeep; ca.P = c->P;
+        ca.draws = c->draws; ca.chain_stats = c->chain_stats; ca.carry_eps = c->carry_eps; ca.carry_metric = c->carry_metric;
+        hipLaunchKernelGGL(k_carry_update, dim3(count), dim3(128), 0, c->stream, ca);
+        HIPCHK(hipGetLastError());
+        c->carry_chains = o.chains;
+    }
     c->has_last = 1;
     c->last_layout = layout;
     c->nsamp = o.chains * nkeep;
@@ -856,6 +878,15 @@ int epx_get_chain_stats(epx_ctx *c, int k0, int count, double *out) {
     if (!c->chain_stats) return fail("no sampling call yet");
     HIPCHK(hipMemcpy(out, c->chain_stats + (size_t)k0 * c->s_chains * ST_COUNT,
                      (size_t)count * c->s_chains * ST_COUNT * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int epx_get_adapt(epx_ctx *c, int k, double *eps, double *metric) {
+    CTX(c);
+    if (check_range(c, k, 1)) return -1;
+    if (!c->carry_chains) return fail("no sampling call yet");
+    if (eps) HIPCHK(hipMemcpy(eps, c->carry_eps + (size_t)k * c->s_chains, (size_t)c->s_chains * 8, hipMemcpyDeviceToHost));
+    if (metric) HIPCHK(hipMemcpy(metric, c->carry_metric + (size_t)k * c->P, (size_t)c->P * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -83,6 +83,8 @@ struct epx_ctx {
     int order_n;
     double *sweep_buf;        // damping sweep: target block + ndf x 5 criteria
     size_t sweep_elems;
+    double *carry_eps, *carry_metric;   // adapt = carry: K x chains step sizes, K x P diagonal metrics (lazily sized)
+    int carry_chains;                   // chains the history was recorded with (0: none)
     double *min_eig;          // force-pd fallback: smallest eigenvalue per site (K)
     // in-library RCCL binding (epx_comm.hip); comm == nullptr: single rank
     void *comm;               // ncclComm_t

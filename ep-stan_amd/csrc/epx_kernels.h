@@ -129,6 +129,12 @@ struct NutsArgs {
     const double *eps_in;         // test hook: per (site of batch, chain) fixed step size -> no step-size search
     const double *inv_e_in;       // test hook: per (site of batch, chain) x P diagonal inverse metric
     int t_offset;                 // test hook: transition index offset of the random stream
+    // opt-in `adapt = carry` (not the reference's behaviour, see include/epx.h): start from the step size the
+    // chain ended the previous call with and from the site's pooled sample variances of that call as diagonal
+    // metric; warm-up then adapts the step size only.  Indexed by ABSOLUTE site; NULL = adapt from scratch;
+    // a non-positive step size = no history for that chain
+    const double *carry_eps;      // K x chains
+    const double *carry_metric;   // K x P
     unsigned long long *stamps;   // diagnostic build (-DEPX_STAMPS): per block 8 cycle sums
     double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
     double *stack;                // per (site of batch, chain): max_depth * (4P + 2) doubles, or NULL when in LDS
@@ -159,6 +165,7 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream);
 size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max);
 bool nuts_duo_has(int cpb, int rw, int dp, int nv);
+size_t nuts_duo_chain_doubles(const NutsArgs &a, int nv);
 
 // streaming variant (nuts_stream.hip): one workgroup per site, chains in lock step, X through
 // an LDS-DMA ring; dpb in {64, 128}, nv = ceil(P/64) <= 7.  a.stack holds, per (site of the
@@ -176,6 +183,13 @@ struct RhatArgs {
     double *site_stats;           // count x EPX_ST_COUNT (batch-relative)
 };
 __global__ void k_site_stats(RhatArgs a);
+struct CarryArgs {
+    int k0, chains, nkeep, P;
+    const double *draws;          // K x chains x nkeep x P
+    const double *chain_stats;    // K x chains x ST_COUNT
+    double *carry_eps, *carry_metric;
+};
+__global__ void k_carry_update(CarryArgs a);
 __global__ void k_rng_probe(uint64_t seed, int chain, uint32_t t, uint32_t kind, uint32_t a,
                             uint32_t b, double *out4);
 

@@ -176,6 +176,14 @@ k_nuts(NutsArgs a) {
             FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
+    // opt-in carried adaptation: last call's step size of the chain, the site's pooled sample variances
+    const bool carry = !teacher && a.carry_eps != nullptr && a.carry_eps[(size_t)k * a.chains + chain] > 0.0;
+    if (carry) {
+        eps = a.carry_eps[(size_t)k * a.chains + chain];
+        da_mu = log(10.0 * eps);
+        const double *cm = a.carry_metric + (size_t)k * P;
+        FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
+    }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
     // reduce the buffered leaf energy errors (lanes 0..cnt-1 of dhb)
@@ -483,6 +491,14 @@ k_nuts_spec(NutsArgs a) {
             FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
+    // opt-in carried adaptation: last call's step size of the chain, the site's pooled sample variances
+    const bool carry = !teacher && a.carry_eps != nullptr && a.carry_eps[(size_t)k * a.chains + chain] > 0.0;
+    if (carry) {
+        eps = a.carry_eps[(size_t)k * a.chains + chain];
+        da_mu = log(10.0 * eps);
+        const double *cm = a.carry_metric + (size_t)k * a.P;
+        FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
+    }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
     auto flush_dh = [&](int cnt) {
         const bool ok = lane < cnt;
@@ -749,6 +765,31 @@ k_site_stats(RhatArgs a) {
         }
         out[0] = step / C; out[1] = isn ? NAN : r; out[2] = nleap; out[3] = ngrad;
         out[4] = ndiv; out[5] = acc / C; out[6] = dep / C; out[7] = fail;
+    }
+}
+
+// History for `adapt = carry`: per chain the step size its warm-up ended with, per site the pooled
+// variance of the kept draws of ALL its chains, regularised like Stan's windowed estimate
+// ((n / (n + 5)) var + 1e-3 (5 / (n + 5)), var_adaptation.hpp @ 2.17).  A site with a failed chain
+// keeps no history (step size -1): its next update adapts from scratch.
+__global__ void __launch_bounds__(128)
+k_carry_update(CarryArgs a) {
+    const int k = a.k0 + blockIdx.x, tid = threadIdx.x;
+    const int C = a.chains, P = a.P, n = C * a.nkeep;
+    double fail = 0.0;
+    for (int c = 0; c < C; ++c) fail += a.chain_stats[((size_t)k * C + c) * ST_COUNT + ST_FAIL];
+    const bool ok = fail == 0.0 && n >= 2;
+    if (tid < C) a.carry_eps[(size_t)k * C + tid] = ok ? a.chain_stats[((size_t)k * C + tid) * ST_COUNT + ST_STEPSIZE_FINAL] : -1.0;
+    if (!ok) return;
+    const double *base = a.draws + (size_t)k * n * P;               // draw s of the site at base + s * P (chain-major)
+    for (int e = tid; e < P; e += blockDim.x) {
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s += base[(size_t)t * P + e];
+        const double m = s / n;
+        double v = 0.0;
+        for (int t = 0; t < n; ++t) { const double dlt = base[(size_t)t * P + e] - m; v += dlt * dlt; }
+        const double s2 = v / (n - 1.0), nn = (double)n;
+        a.carry_metric[(size_t)k * P + e] = (nn / (nn + 5.0)) * s2 + 1e-3 * (5.0 / (nn + 5.0));
     }
 }
 

@@ -27,6 +27,27 @@ __device__ inline double elemU(const Vec<NV> &x, int e) {
     return r;
 }
 
+// A length-P vector kept in global memory behind the same `.v[i]` syntax (element e of lane e % 64 at
+// b[e]): for the vectors of the tree bookkeeping that change once per subtree or per transition.  `b`
+// is wave-uniform, so every access is `saddr + lane * 8 + immediate`.
+struct GRef {
+    double *p;
+    __device__ operator double() const { return *p; }
+    __device__ const GRef &operator=(double x) const { *p = x; return *this; }
+    __device__ const GRef &operator=(const GRef &o) const { const double x = *o.p; *p = x; return *this; }
+    __device__ const GRef &operator+=(double x) const { *p = *p + x; return *this; }
+};
+struct GIdx { double *b; int lane; __device__ GRef operator[](int i) const { return GRef{b + (lane + 64 * i)}; } };
+struct GVec { GIdx v; };
+enum { GV_QS, GV_GS, GV_PQ, GV_PP, GV_PG, GV_MQ, GV_MP, GV_MG, GV_RHO, GV_PSP, GV_PSM, GV_WMEAN, GV_WM2, GV_COUNT };
+
+__device__ inline double *uniform_ptr(double *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (double *)(((unsigned long long)hi32 << 32) | lo32);
+}
+
 template <int DP> struct Log2 { static constexpr int v = 1 + Log2<DP / 2>::v; };
 template <> struct Log2<1> { static constexpr int v = 0; };
 

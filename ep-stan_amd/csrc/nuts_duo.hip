@@ -26,6 +26,8 @@
 // reports it) instead of hanging the GPU.
 #include "nuts_common.h"
 
+#include <type_traits>
+
 namespace epx {
 
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23 };
@@ -44,9 +46,26 @@ __device__ inline void duo_publish(volatile int *flag, int v) {
     *flag = v;
 }
 
+// In-kernel cycle stamps exist only in the diagnostic build (-DEPX_STAMPS); its run time is never
+// quoted, only the shares.  Slots per workgroup (chain 0): state wave 0 prep / 1 bookkeeping /
+// 2 cavity term / 3 waiting for the row waves / 4 chain rule; row wave 5 waiting for a job / 6 row pass;
+// 7 = leapfrogs
+#ifdef EPX_STAMPS
+#define STAMP(i)                                                                   \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+        tacc[i] += t_ - tprev; tprev = t_;                                         \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+#define STAMP_INIT unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
 #define STAMP(i) do { } while (0)
+#define STAMP_INIT do { } while (0)
+#endif
 
-template <int NV, int DP, int CPB, int RW, bool STL>
+template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
 __global__ void __launch_bounds__(64 * CPB * (1 + RW))
 k_nuts_duo(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -72,13 +91,15 @@ k_nuts_duo(NutsArgs a) {
     const int D = a.D, d = a.d, P = a.P, model = a.model;
     const int64_t row0 = a.k_lim[k];
     const int n = (int)(a.k_lim[k + 1] - row0);
+    constexpr int OU = NV > 1 ? 4 : 8;                // column pairs of the cavity precision per round of the mat-vec
     const int dm = d < 64 ? d : 64;                   // cavity precision: rows / columns held pair-interleaved
     const int tr = d - dm;                            // ... and the rows beyond (0..2 for D <= 32)
-    const int dpad = d + (d & 1);
+    const int npair = (dm + 1) / 2, npad = (npair + OU - 1) / OU * OU;       // pairs, zero padded to whole rounds
+    const int tstride = 2 * npad + 2;                 // tail rows: [2 rows (zero when absent)][column], NV > 1 only
 
     double *Xs = reinterpret_cast<double *>(smem);
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);        // [(pair p, row e)] -> (Om[e][2p], Om[e][2p+1])
-    double *Ots = reinterpret_cast<double *>(smem + a.off_tail);      // [row r - 64][column], stride dpad
+    double *Ots = reinterpret_cast<double *>(smem + a.off_tail);      // [row r - 64][column], stride tstride
     double *slot = reinterpret_cast<double *>(smem + a.off_slot) + (size_t)team * a.slot_doubles;
     volatile int *flags = reinterpret_cast<volatile int *>(smem + a.off_flag) + team * (1 + RW);
     volatile int *f_job = flags, *f_res = flags + 1;
@@ -99,17 +120,18 @@ k_nuts_duo(NutsArgs a) {
             *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
         }
         const double *Om_g = a.cav_Om + (size_t)k * d * d;                // column-major, symmetric
-        const int npair = (dm + 1) / 2;
-        for (int idx = tid; idx < npair * dm; idx += blockDim.x) {
+        for (int idx = tid; idx < npad * dm; idx += blockDim.x) {
             const int p = idx / dm, e = idx % dm;
             double2 v;
-            v.x = Om_g[(size_t)(2 * p) * d + e];
+            v.x = 2 * p < dm ? Om_g[(size_t)(2 * p) * d + e] : 0.0;
             v.y = 2 * p + 1 < dm ? Om_g[(size_t)(2 * p + 1) * d + e] : 0.0;
             *reinterpret_cast<double2 *>(Oms + 2 * (size_t)idx) = v;
         }
-        for (int idx = tid; idx < tr * dpad; idx += blockDim.x) {
-            const int r = idx / dpad, j = idx % dpad;
-            Ots[idx] = j < d ? Om_g[(size_t)j * d + dm + r] : 0.0;
+        if constexpr (NV > 1) {
+            for (int idx = tid; idx < 2 * tstride; idx += blockDim.x) {
+                const int r = idx / tstride, j = idx % tstride;
+                Ots[idx] = (r < tr && j < d) ? Om_g[(size_t)j * d + dm + r] : 0.0;
+            }
         }
         if (tid < CPB * (1 + RW)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
     }
@@ -125,10 +147,18 @@ k_nuts_duo(NutsArgs a) {
             for (int r = wr * 64 + lane; r < n; r += 64 * RW, ++it)
                 if (a.y[row0 + r]) ybits |= 1ull << it;
         }
+        STAMP_INIT;
+        // the row pass is the longest link of a leapfrog's critical chain: it wins the SIMD's issue arbitration
+        // against the state wave (of another chain) it shares the SIMD with, whose bookkeeping has slack
+        __builtin_amdgcn_s_setprio(2);
         for (int seq = 1;; ++seq) {
             const int got = duo_wait(f_job, seq);
+            STAMP(5);
             if (got != seq) {
                 if (got == DUO_TIMEOUT && lane == 0) atomicOr(a.err, 1);
+#ifdef EPX_STAMPS
+                if (a.stamps && team == 0 && wr == 0 && lane == 0) { a.stamps[(size_t)blockIdx.x * 8 + 5] = tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] = tacc[6]; }
+#endif
                 return;
             }
             const double *job = slot + JOB;
@@ -144,25 +174,43 @@ k_nuts_duo(NutsArgs a) {
             for (int j = 0; j < DP; ++j) acc[j] = 0.0;
             double da = 0.0, ll = 0.0, wprod = 1.0;
             unsigned long long yb = ybits;
-            for (int r = wr * 64 + lane; r < n; r += 64 * RW) {
-                const double2 *rowp = reinterpret_cast<const double2 *>(Xs + (size_t)r * DP);
-                const int sw = (r / RPL) & (SPR - 1);
-                double x[DP];
+            // two rows per round: their logistic terms (a chain of ~25 dependent FP64 operations each)
+            // overlap; the sums still take the rows in order, so every value equals the row-by-row loop's.
+            // A lane whose second row is beyond n re-reads its first row and adds zeros.
+            for (int r = wr * 64 + lane; r < n; r += 2 * 64 * RW) {
+                const int r1 = r + 64 * RW;
+                const bool two = r1 < n;
+                const int r1c = two ? r1 : r;
+                const double2 *row0p = reinterpret_cast<const double2 *>(Xs + (size_t)r * DP);
+                const double2 *row1p = reinterpret_cast<const double2 *>(Xs + (size_t)r1c * DP);
+                const int sw0 = (r / RPL) & (SPR - 1), sw1 = (r1c / RPL) & (SPR - 1);
+                double x0[DP], x1[DP];
 #pragma unroll
                 for (int jp = 0; jp < SPR; ++jp) {
-                    const double2 v = rowp[jp ^ sw];
-                    x[2 * jp] = v.x; x[2 * jp + 1] = v.y;
+                    const double2 v = row0p[jp ^ sw0];
+                    x0[2 * jp] = v.x; x0[2 * jp + 1] = v.y;
                 }
-                double f0 = alpha, f1 = 0.0;
 #pragma unroll
-                for (int j = 0; j < DP; j += 2) { f0 = fma(x[j], bs[j], f0); f1 = fma(x[j + 1], bs[j + 1], f1); }
-                const double f = f0 + f1;
-                double l, w, g;
-                logistic_split(f, (double)(yb & 1ull), l, w, g);
-                yb >>= 1;
-                ll += l; wprod *= w; da += g;
+                for (int jp = 0; jp < SPR; ++jp) {
+                    const double2 v = row1p[jp ^ sw1];
+                    x1[2 * jp] = v.x; x1[2 * jp + 1] = v.y;
+                }
+                double fa0 = alpha, fa1 = 0.0, fb0 = alpha, fb1 = 0.0;
 #pragma unroll
-                for (int j = 0; j < DP; ++j) acc[j] = fma(g, x[j], acc[j]);
+                for (int j = 0; j < DP; j += 2) {
+                    fa0 = fma(x0[j], bs[j], fa0); fa1 = fma(x0[j + 1], bs[j + 1], fa1);
+                    fb0 = fma(x1[j], bs[j], fb0); fb1 = fma(x1[j + 1], bs[j + 1], fb1);
+                }
+                const double fa = fa0 + fa1, fb = fb0 + fb1;
+                double la, wa, ga, lb, wb, gb;
+                logistic_split(fa, (double)(yb & 1ull), la, wa, ga);
+                logistic_split(fb, (double)((yb >> 1) & 1ull), lb, wb, gb);
+                yb >>= 2;
+                lb = two ? lb : 0.0; wb = two ? wb : 1.0; gb = two ? gb : 0.0;
+                ll += la; wprod *= wa; da += ga;
+                ll += lb; wprod *= wb; da += gb;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) acc[j] = fma(gb, x1[j], fma(ga, x0[j], acc[j]));
             }
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
@@ -171,19 +219,37 @@ k_nuts_duo(NutsArgs a) {
             if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
             if (lane == 0) { res[DP] = da; res[DP + 1] = ll; }
             duo_publish(f_res + wr, seq);
+            STAMP(6);
         }
     }
 
     // ===================================================================== state wave
     const int wt = 0;
+    // global memory of the chain: the tree stack (unless it is in LDS), then the cold store (COLD)
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
-    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    const size_t g_stack = STL ? 0 : (size_t)a.max_depth * SREC;
+    double *stk_g = (STL && !COLD) ? nullptr
+        : uniform_ptr(a.stack + ((size_t)sb * a.chains + chain) * (g_stack + (COLD ? (size_t)GV_COUNT * NV * 64 : 0)));
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
 
-    V mu, inv_e, qs, gs, zq, zp, zg, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;
+    // The 13 vectors that change once per subtree / transition (current sample and its gradient, both
+    // tree ends, rho, p-sharps, Welford sums): registers, or (COLD) a per-chain store in global memory --
+    // at two registers per vector they are 52 VGPRs that the state wave spilled to scratch
+    using CV = typename std::conditional<COLD, GVec, V>::type;
+    V mu, inv_e, zq, zp, zg;
+    CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;
+    double *cold = COLD ? stk_g + g_stack : nullptr;
+    auto bind = [&](CV &x, int which, int ln) {
+        if constexpr (COLD) { x.v.b = cold + (size_t)which * NV * 64; x.v.lane = ln; }
+    };
+#define EPX_BIND_COLD(ln)                                                                              \
+    bind(qs, GV_QS, ln); bind(gs, GV_GS, ln); bind(pq, GV_PQ, ln); bind(pp, GV_PP, ln); bind(pg, GV_PG, ln); \
+    bind(mq, GV_MQ, ln); bind(mp, GV_MP, ln); bind(mg, GV_MG, ln); bind(rho, GV_RHO, ln);                 \
+    bind(psp, GV_PSP, ln); bind(psm, GV_PSM, ln); bind(wmean, GV_WMEAN, ln); bind(wm2, GV_WM2, ln)
+    EPX_BIND_COLD(lane);
     double lps = 0, zlp = 0, plp = 0, mlp = 0;
     FORV {
         const int e = lane + 64 * i;
@@ -237,6 +303,14 @@ k_nuts_duo(NutsArgs a) {
             FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
+    // opt-in carried adaptation: last call's step size of the chain, the site's pooled sample variances
+    const bool carry = !teacher && a.carry_eps != nullptr && a.carry_eps[(size_t)k * a.chains + chain] > 0.0;
+    if (carry) {
+        eps = a.carry_eps[(size_t)k * a.chains + chain];
+        da_mu = log(10.0 * eps);
+        const double *cm = a.carry_metric + (size_t)k * P;
+        FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
+    }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
     auto flush_dh = [&](int cnt) {
         const bool ok = lane < cnt;
@@ -266,7 +340,7 @@ k_nuts_duo(NutsArgs a) {
         else j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
         jdx[i] = j < 0 ? 0 : (j > DP - 1 ? DP - 1 : j);
     }
-    const int rc = lane < tr ? lane : (tr > 0 ? tr - 1 : 0);
+    const int rc = lane < 2 ? lane : 1;             // tail row of this lane (lanes beyond the tail re-read row 1)
     auto xtg = [&](int j) -> double {                  // X'g[j] summed over the chain's row waves, in wave order
         if constexpr (RW == 1) return slot[j];
         else {
@@ -278,10 +352,11 @@ k_nuts_duo(NutsArgs a) {
     };
 
     // (zq, zp, zg) holds the last finished leapfrog state; `pending`: its bookkeeping is still to run
-    double f_lp = 0.0, f_kin = 0.0;
+    double f_lpt = 0.0, f_ks = 0.0, f_ll = 0.0;     // its log density / kinetic energy, not yet summed over the lanes
     bool pending = false;
     int seq = 0, bail = 0;
     const int lane0 = lane;
+    STAMP_INIT;
 
     for (;;) {
         // `lane` is re-derived through an opaque move every leapfrog, otherwise the per-element index
@@ -289,6 +364,7 @@ k_nuts_duo(NutsArgs a) {
         int lane_v = lane0;
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
+        EPX_BIND_COLD(lane);
         // ---- first half of the leapfrog from (zq, zp, zg): speculative while `pending`
         V sq, sp, sg, eq;
         FORV sp.v[i] = zp.v[i] + 0.5 * eps_l * zg.v[i];
@@ -318,12 +394,15 @@ k_nuts_duo(NutsArgs a) {
             duo_publish(f_job, seq);
         }
         const double job_eps = eps_l;
+        __builtin_amdgcn_s_setprio(0);              // from here to the row waves' answer nothing waits for this wave
+        STAMP(0);
 
         // ---- while they sweep the rows: the bookkeeping of the leapfrog that finished before this one
         if (pending) {
             pending = false;
-            zlp = f_lp;
-            const double kin = f_kin;
+            wave_sum2(f_lpt, f_ks);                 // the two reductions only the bookkeeping needs: off the critical path
+            zlp = f_lpt + f_ll;
+            const double kin = 0.5 * f_ks;
             const int fwd_was = fwd;
             ngrad += 1.0;
             V n_rho, n_psl, n_pq, n_pg, psr;
@@ -351,38 +430,47 @@ k_nuts_duo(NutsArgs a) {
                     const int got = duo_wait(f_res + w, seq);
                     if (got != seq) bail = 1;
                 }
+                STAMP(3);
                 if (bail || leave) { bail |= leave << 1; break; }
                 continue;
             }
         }
+        STAMP(1);
 
         // ---- cavity term Ov = Omega (phi - mu) of the position in flight ...
         V vv, Ov;
         FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? sq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
         {
-            const int npair = (dm + 1) / 2;
+            // OU column pairs per round, loads first: the LDS latency is paid once per round.  The padding
+            // pairs (and absent tail rows) hold zeros, so they add nothing and the sums keep order and value
             const int e0 = lane < dm ? lane : dm - 1;
             const double2 *Op = reinterpret_cast<const double2 *>(Oms) + e0;
-            const double2 *Tp = reinterpret_cast<const double2 *>(Ots + (size_t)rc * dpad);
-            for (int p = 0; p < npair; ++p) {
-                const double v0 = readlane_d(vv.v[0], (2 * p) & 63), v1 = readlane_d(vv.v[0], (2 * p + 1) & 63);
-                const double2 o = Op[(size_t)p * dm];
-                Ov.v[0] = fma(o.x, v0, Ov.v[0]);
-                Ov.v[0] = fma(o.y, 2 * p + 1 < dm ? v1 : 0.0, Ov.v[0]);
-                if constexpr (NV > 1) {
-                    if (tr > 0) {
-                        const double2 tt = Tp[p];
-                        Ov.v[1] = fma(tt.x, v0, Ov.v[1]);
-                        Ov.v[1] = fma(tt.y, 2 * p + 1 < dm ? v1 : 0.0, Ov.v[1]);
+            const double2 *Tp = reinterpret_cast<const double2 *>(Ots + (size_t)rc * tstride);
+            for (int p0 = 0; p0 < npad; p0 += OU) {
+                double2 o[OU], tt[OU];
+#pragma unroll
+                for (int u = 0; u < OU; ++u) {
+                    o[u] = Op[(size_t)(p0 + u) * dm];
+                    if constexpr (NV > 1) tt[u] = Tp[p0 + u]; else tt[u] = o[u];
+                }
+#pragma unroll
+                for (int u = 0; u < OU; ++u) {
+                    const int p = p0 + u;
+                    const double v0 = readlane_d(vv.v[0], (2 * p) & 63), v1 = readlane_d(vv.v[0], (2 * p + 1) & 63);
+                    Ov.v[0] = fma(o[u].x, v0, Ov.v[0]);
+                    Ov.v[0] = fma(o[u].y, v1, Ov.v[0]);
+                    if constexpr (NV > 1) {
+                        Ov.v[1] = fma(tt[u].x, v0, Ov.v[1]);
+                        Ov.v[1] = fma(tt[u].y, v1, Ov.v[1]);
                     }
                 }
             }
-            if constexpr (NV > 1) {
-                for (int c = 0; c < tr; ++c) {                           // columns 64.. : the tail rows by symmetry
-                    const double vc = readlane_d(vv.v[1], c);
-                    Ov.v[0] = fma(Ots[(size_t)c * dpad + e0], vc, Ov.v[0]);
-                    Ov.v[1] = fma(Ots[(size_t)rc * dpad + dm + c], vc, Ov.v[1]);
-                }
+            if constexpr (NV > 1) {                                      // columns 64.. : the tail rows by symmetry
+                const double a0 = Ots[e0], a1 = Ots[tstride + e0];
+                const double b0 = Ots[(size_t)rc * tstride + dm], b1 = Ots[(size_t)rc * tstride + dm + 1];
+                const double w0 = readlane_d(vv.v[1], 0), w1 = readlane_d(vv.v[1], 1);
+                Ov.v[0] = fma(a0, w0, Ov.v[0]); Ov.v[1] = fma(b0, w0, Ov.v[1]);
+                Ov.v[0] = fma(a1, w1, Ov.v[0]); Ov.v[1] = fma(b1, w1, Ov.v[1]);
             }
         }
         FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
@@ -397,11 +485,14 @@ k_nuts_duo(NutsArgs a) {
                    g_etbq.v[i] = gatherV(sq, d + 1 + j); g_sbj.v[i] = gatherV(eq, 2 + D + j); }
         }
 
+        STAMP(2);
         // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
         for (int w = 0; w < RW; ++w) {
             const int got = duo_wait(f_res + w, seq);
             if (got != seq) bail = 1;
         }
+        STAMP(3);
+        __builtin_amdgcn_s_setprio(3);              // chain rule, half kick, drift, publish: the row waves wait for it
         if (bail) break;
         double da, ll;
         if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
@@ -462,11 +553,16 @@ k_nuts_duo(NutsArgs a) {
         // the trajectory continues from here unless the bookkeeping (next round, beside the next
         // row pass) says otherwise
         FORV { zq.v[i] = sq.v[i]; zp.v[i] = sp.v[i]; zg.v[i] = sg.v[i]; }
-        wave_sum2(lpt, ks);
-        f_lp = lpt + ll;
-        f_kin = 0.5 * ks;
+        f_lpt = lpt; f_ks = ks; f_ll = ll;
         pending = true;
+        STAMP(4);
     }
+#ifdef EPX_STAMPS
+    if (a.stamps && team == 0 && lane == 0) {
+        for (int i = 0; i < 5; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
+        a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)seq;
+    }
+#endif
 
     // ------------------------------------------------------------- epilogue (the state wave owns the chain)
     *f_job = DUO_EXIT;                                 // the row waves leave
@@ -502,11 +598,12 @@ k_nuts_duo(NutsArgs a) {
 // host side: LDS layout + dispatch over the instantiated shapes
 size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     const int nv = (a.P + 63) / 64;
-    const int d = a.d, dm = d < 64 ? d : 64, tr = d - dm, dpad = d + (d & 1);
+    const int ou = nv > 1 ? 4 : 8;                                                     // as the kernel (OU)
+    const int d = a.d, dm = d < 64 ? d : 64, npad = ((dm + 1) / 2 + ou - 1) / ou * ou;
     size_t off = (size_t)n_max * dp * 8;
     a.n_max = n_max; a.duo_rw = rw; a.cpb = cpb;
-    a.off_Om = (int)off; off += (size_t)((dm + 1) / 2) * dm * 16;
-    a.off_tail = (int)off; off += (size_t)tr * dpad * 8;
+    a.off_Om = (int)off; off += (size_t)npad * dm * 16;
+    a.off_tail = (int)off; off += nv > 1 ? (size_t)2 * (2 * npad + 2) * 8 : 0;
     off = (off + 15) & ~(size_t)15;
     a.slot_doubles = rw == 1 ? dp + 2 : (1 + rw) * (dp + 2);
     a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
@@ -521,6 +618,12 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     return off;
 }
 
+// doubles of global memory per chain: the tree stack when it is not in LDS + the cold store at nv = 2
+size_t nuts_duo_chain_doubles(const NutsArgs &a, int nv) {
+    const bool cold = nv >= 2 || a.cpb > 1;          // as launch_duo_one instantiates
+    return (a.stack_in_lds ? 0 : (size_t)a.max_depth * (4 * nv * 64 + 2)) + (cold ? (size_t)GV_COUNT * nv * 64 : 0);
+}
+
 template <int NV, int DP, int CPB, int RW>
 static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
     auto go = [&](auto kern) -> int {
@@ -530,7 +633,8 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * CPB * (1 + RW)), a.lds_bytes, stream, a);
         return (int)hipGetLastError();
     };
-    return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true>) : go(k_nuts_duo<NV, DP, CPB, RW, false>);
+    constexpr bool COLD = NV >= 2 || CPB > 1;
+    return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true, COLD>) : go(k_nuts_duo<NV, DP, CPB, RW, false, COLD>);
 }
 
 template <int NV, int DP>

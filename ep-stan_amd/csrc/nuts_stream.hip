@@ -228,6 +228,14 @@ k_nuts_stream(NutsArgs a) {
             FORV { const int e = lane0 + 64 * i; if (e < P) inv_e.v[i] = ie[e]; }
         }
     }
+    // opt-in carried adaptation: last call's step size of the chain, the site's pooled sample variances
+    const bool carry = active && !teacher && a.carry_eps != nullptr && a.carry_eps[(size_t)k * a.chains + chain] > 0.0;
+    if (carry) {
+        eps = a.carry_eps[(size_t)k * a.chains + chain];
+        da_mu = log(10.0 * eps);
+        const double *cm = a.carry_metric + (size_t)k * a.P;
+        FORV { const int e = lane0 + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
+    }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
     auto flush_dh = [&](int cnt) {

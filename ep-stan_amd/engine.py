@@ -178,9 +178,11 @@ class HipEngine(object):
     # ---- tilted
     @staticmethod
     def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random',
-                     max_depth=10, layout=0, flags=0):
+                     max_depth=10, layout=0, flags=0, adapt='fresh'):
         o = SamplerOpts()
-        o.reserved = int(flags)          # bit 0: layout 2 without the speculative bookkeeping wave
+        if adapt not in ('fresh', 'carry'):
+            raise ValueError("adapt must be 'fresh' (the reference's behaviour) or 'carry'")
+        o.reserved = int(flags) | (2 if adapt == 'carry' else 0)    # bit 0: layout 2 without the speculative bookkeeping wave
         o.chains, o.iter, o.thin = int(chains), int(iter), int(thin)
         o.warmup = -1 if warmup is None else int(warmup)
         if init not in INIT_IDS:
@@ -241,6 +243,13 @@ class HipEngine(object):
         out = np.empty((S, self.P if all_params else self.d), order='F')
         check(self.lib.epx_get_draws(self.ctx, int(k), 1 if all_params else 0, dptr(out)))
         return out
+
+    def get_adapt(self, k, chains):
+        """Adaptation history of site k: (final step size per chain, diagonal metric (P))."""
+        eps = np.zeros(chains)
+        metric = np.zeros(self.P)
+        check(self.lib.epx_get_adapt(self.ctx, int(k), dptr(eps), dptr(metric)))
+        return eps, metric
 
     def nuts_transitions(self, seeds, q0, eps, inv_e, nt=1, t_offset=0, layout=0, k0=0):
         """TEST HOOK: nt un-adapted transitions from q0 (count, chains, P)."""

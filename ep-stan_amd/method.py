@@ -176,7 +176,7 @@ class Worker(object):
         return _engine.HipEngine.sampler_opts(
             chains=sp['chains'], iter=sp['iter'], warmup=sp['warmup'], thin=sp['thin'],
             init=init, max_depth=m.max_treedepth if m is not None else 10,
-            layout=m.layout if m is not None else 0)
+            layout=m.layout if m is not None else 0, adapt=m.adapt if m is not None else 'fresh')
 
     def _cur_estim(self):
         if self.prec_estim == 'sample' or self.prec_estim_skip > 0:
@@ -401,7 +401,13 @@ class Master(object):
     2 block per (site, chain), 3 streaming), `sync_sites` (gather the site arrays
     of all ranks into the host mirrors when `run` returns, default True),
     `balance_sites` (dispatch the sites of an iteration in decreasing order of the
-    leapfrogs they took in the previous one; results do not depend on it, default True).
+    leapfrogs they took in the previous one; results do not depend on it, default True),
+    `adapt`: 'fresh' (default; every site update adapts step size and metric from scratch like
+    the reference's fresh `model.sampling` call, util.py:716) or 'carry' (NOT the reference's
+    behaviour: a site update starts from the step sizes its chains ended the previous one with
+    and from the site's pooled sample variances as metric, warm-up tunes the step size only --
+    same target distribution, far fewer leapfrogs; SURVEY.md Appendix A sanctions it as a
+    reported opt-in).
     """
 
     INFO_OK = 0
@@ -436,6 +442,7 @@ class Master(object):
         layout            = 0,
         sync_sites        = True,
         balance_sites     = True,
+        adapt             = 'fresh',
         _engine_factory   = None,
     )
 
@@ -450,6 +457,9 @@ class Master(object):
         self.layout = gpu['layout']
         self.sync_sites = gpu['sync_sites']
         self.balance_sites = gpu['balance_sites']
+        if gpu['adapt'] not in ('fresh', 'carry'):
+            raise ValueError("adapt must be 'fresh' or 'carry'")
+        self.adapt = gpu['adapt']
         self.comm = gpu['comm'] if gpu['comm'] is not None else _dist.LocalComm()
         self._sample_injector = None        # test hook: f(data, stan_params) -> (S, d) draws
         self.last_site_stats = None         # sampler statistics of the last iteration (local sites)

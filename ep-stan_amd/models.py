@@ -24,56 +24,47 @@ B_ABS_MIN_SUM = 1e-4
 
 
 def rand_corr_vine(d, alpha=2, beta=2, pmin=-0.8, pmax=0.8, seed=None):
-    """Random correlation matrix by the vine method (common.py:33-78)."""
+    """Random correlation matrix by the C-vine construction (the reference's common.py:33-78).
+
+    Partial correlations rho[k, i] (k < i), Beta(alpha, beta) draws stretched to [pmin, pmax], are
+    turned into correlations by conditioning out the variables k = i-1, ..., 0 one after the other;
+    a random permutation of the variables follows.  Random numbers are consumed and combined in the
+    reference's order, so a given seed gives the reference's matrix."""
     rs = seed if isinstance(seed, np.random.RandomState) else np.random.RandomState(seed)
-    P = np.empty((d, d))
-    uinds = np.triu_indices(d, 1)
-    betas = rs.beta(alpha, beta, size=len(uinds[0]))
-    betas *= pmax - pmin
-    betas += pmin
-    P[uinds] = betas
-    np.square(betas, out=betas)
-    P.T[uinds] = betas
+    upper = np.triu_indices(d, 1)
+    draws = rs.beta(alpha, beta, size=upper[0].shape[0])
+    draws *= pmax - pmin
+    draws += pmin
+    rho = np.zeros((d, d))                     # rho[k, i], k < i: partial correlation of i and k given 0..k-1
+    rho[upper] = draws
+    rho_sq = np.square(rho)
     C = np.eye(d)
-    for i in range(d - 1):
-        for j in range(i + 1, d):
-            cur = P[i, j]
-            for k in range(i - 1, -1, -1):
-                cur *= np.sqrt((1 - P[i, k])*(1 - P[j, k]))
-                cur += P[k, i]*P[k, j]
-            C[i, j] = cur
-            C[j, i] = cur
-    perm = rs.permutation(d)
-    return C[np.ix_(perm, perm)]
+    for i, j in zip(*upper):
+        corr = rho[i, j]
+        for k in reversed(range(i)):
+            corr = corr * np.sqrt((1 - rho_sq[k, i]) * (1 - rho_sq[k, j])) + rho[k, i] * rho[k, j]
+        C[i, j] = C[j, i] = corr
+    order = rs.permutation(d)
+    return C[order][:, order]
 
 
 def calc_input_param_classification(alpha, beta, Sigma_x=None):
-    """mu_x, sigma_x per group for alpha (J,), beta (D,) or (J,D), D > 1
-    (the two multi-group branches of common.py:260-315)."""
+    """Input location and scale (mu_x, sigma_x) per group such that the class probabilities stay
+    away from 0 and 1: alpha (J,), beta (D,) or (J, D), D > 1 (the multi-group branches of the
+    reference's common.py:260-315).  With sd(x beta) = sigma_x * s, s^2 = beta' Sigma_x beta:
+    a group whose intercept is small (|alpha| < DELTA_MAX) keeps mu_x = 0 and takes the largest
+    scale that leaves P(f beyond logit(P_0)) = GAMMA_0; otherwise the inputs are shifted so that the
+    mean of f sits at +-DELTA_MAX and the scale gives sd(f) = SIGMA_F0."""
     alpha = np.asarray(alpha, dtype=np.float64)
     beta = np.asarray(beta, dtype=np.float64)
     J = alpha.shape[0]
-    sbeta = np.sum(beta, axis=-1)
-    if Sigma_x is None:
-        ssbeta = np.sqrt(np.sum(np.square(beta), axis=-1))
-    else:
-        ssbeta = beta.dot(Sigma_x)
-        ssbeta *= beta
-        ssbeta = np.sqrt(np.sum(ssbeta, axis=-1))
-    sbeta = np.broadcast_to(sbeta, (J,))
-    ssbeta = np.broadcast_to(ssbeta, (J,))
-    divisor = np.sqrt(2) * ERFINVGAMMA0 * ssbeta
-    mu_x = np.zeros(J)
-    sigma_x = np.empty(J)
-    for j in range(J):
-        if np.abs(alpha[j]) < DELTA_MAX:
-            sigma_x[j] = (LOGITP0 + np.abs(alpha[j])) / divisor[j]
-        else:
-            if alpha[j] > 0:
-                mu_x[j] = (DELTA_MAX - alpha[j])/sbeta[j]
-            else:
-                mu_x[j] = (-DELTA_MAX - alpha[j])/sbeta[j]
-            sigma_x[j] = SIGMA_F0/ssbeta[j]
+    total = np.broadcast_to(np.sum(beta, axis=-1), (J,))
+    quad = np.square(beta) if Sigma_x is None else beta.dot(Sigma_x) * beta
+    s = np.broadcast_to(np.sqrt(np.sum(quad, axis=-1)), (J,))
+    small = np.abs(alpha) < DELTA_MAX
+    target = np.where(alpha > 0, DELTA_MAX, -DELTA_MAX)
+    mu_x = np.where(small, 0.0, (target - alpha) / total)
+    sigma_x = np.where(small, (LOGITP0 + np.abs(alpha)) / (np.sqrt(2) * ERFINVGAMMA0 * s), SIGMA_F0 / s)
     return mu_x, sigma_x
 
 
@@ -125,119 +116,6 @@ def _draw_X(rng, Nj, j_lim, D, mu_x_j, sigma_x_j, Sigma_x):
     return X
 
 
-class m1b(object):
-    """y ~ bernoulli_logit(alpha_j + x beta), alpha ~ N(0, sigma_a),
-    phi = [log sigma_a, beta] (models/m1b.py)."""
-    SIGMA_A = 1            # m1b.py:36-40
-    SIGMA_AH = None
-    SIGMA_B = 1.0
-    M0_A, V0_A, M0_B, V0_B = 0, 1.5**2, 0, 1.5**2     # m1b.py:46-50
-    site_model = 'm1b_sg'
-
-    def __init__(self, J, D, npg):
-        self.J, self.D, self.npg = J, D, npg
-        self.dphi = D + 1
-
-    def simulate_data(self, Sigma_x=None, rng=None):
-        J, D = self.J, self.D
-        if not isinstance(rng, np.random.RandomState):
-            rng = np.random.RandomState(rng)
-        seed_input_cov = rng.randint(2**31 - 1)
-        if isinstance(Sigma_x, str) and Sigma_x == 'rand':
-            Sigma_x = rand_corr_vine(D, seed=seed_input_cov)
-        Nj, j_lim = _sizes(rng, J, self.npg)
-        sigma_a = self.SIGMA_A
-        beta = rng.randn(D)*self.SIGMA_B
-        beta_sum = np.sum(beta)
-        while np.abs(beta_sum) < B_ABS_MIN_SUM:
-            index = rng.randint(D)
-            beta_sum -= beta[index]
-            beta[index] = rng.randn()*self.SIGMA_B
-            beta_sum += beta[index]
-        alpha_j = rng.randn(J)*sigma_a
-        phi_true = np.append(np.log(sigma_a), beta)
-        mu_x_j, sigma_x_j = calc_input_param_classification(alpha_j, beta, Sigma_x)
-        X = _draw_X(rng, Nj, j_lim, D, mu_x_j, sigma_x_j, Sigma_x)
-        j_ind = np.repeat(np.arange(J), Nj)
-        f = alpha_j[j_ind] + X.dot(beta)
-        p = 1/(1 + np.exp(-f))
-        y = (rng.rand(X.shape[0]) < p).astype(int)
-        return Data(X, y, Nj, j_lim, phi_true,
-                    {'mu_x': mu_x_j, 'sigma_x': sigma_x_j, 'Sigma_x': Sigma_x})
-
-    def get_prior(self):
-        D = self.D
-        S0 = np.diag(np.append(self.V0_A, np.ones(D)*self.V0_B)).T
-        m0 = np.append(self.M0_A, np.ones(D)*self.M0_B)
-        Q0 = np.diag(np.append(1./self.V0_A, np.ones(D)/self.V0_B)).T
-        r0 = np.append(self.M0_A/self.V0_A, np.ones(D)*(self.M0_B/self.V0_B))
-        return S0, m0, Q0, r0
-
-
-class m4b(object):
-    """y ~ bernoulli_logit(alpha_j + x beta_j), alpha_j ~ N(mu_a, sigma_a),
-    beta_jd ~ N(mu_b_d, sigma_b_d), phi = [mu_a, log sigma_a, mu_b, log sigma_b]
-    (models/m4b.py; the paper's model)."""
-    MU_A = 1.5                      # m4b.py:44-47
-    MU_B = (-2.0, 2.0)
-    LOG_SIGMA_A = 0.4
-    LOG_SIGMA_B = (-0.5, 0.5)
-    V0_MA, V0_SA, V0_MB, V0_SB = 4**2, 2**2, 4**2, 2**2      # m4b.py:50-61
-    site_model = 'm4b_sg'
-
-    def __init__(self, J, D, npg):
-        self.J, self.D, self.npg = J, D, npg
-        self.dphi = 2*D + 2
-
-    def simulate_data(self, Sigma_x=None, rng=None):
-        J, D = self.J, self.D
-        if not isinstance(rng, np.random.RandomState):
-            rng = np.random.RandomState(rng)
-        seed_input_cov = rng.randint(2**31 - 1)
-        if isinstance(Sigma_x, str) and Sigma_x == 'rand':
-            Sigma_x = rand_corr_vine(D, seed=seed_input_cov)
-        Nj, j_lim = _sizes(rng, J, self.npg)
-        mu_a = self.MU_A
-        mu_b = rng.rand(D)*(self.MU_B[1] - self.MU_B[0]) + self.MU_B[0]
-        sigma_a = np.exp(self.LOG_SIGMA_A)
-        sigma_b = np.exp(rng.rand(D)*(self.LOG_SIGMA_B[1] - self.LOG_SIGMA_B[0]) + self.LOG_SIGMA_B[0])
-        alpha_j = mu_a + rng.randn(J)*sigma_a
-        beta_j = mu_b + rng.randn(J, D)*sigma_b
-        for j in range(J):
-            beta_sum = np.sum(beta_j[j])
-            while np.abs(beta_sum) < B_ABS_MIN_SUM:
-                index = rng.randint(D)
-                beta_sum -= beta_j[j, index]
-                beta_j[j, index] = mu_b[index] + rng.randn()*sigma_b[index]
-                beta_sum += beta_j[j, index]
-        phi_true = np.empty(self.dphi)
-        phi_true[0] = mu_a
-        phi_true[1] = np.log(sigma_a)
-        phi_true[2:2+D] = mu_b
-        phi_true[2+D:] = np.log(sigma_b)
-        mu_x_j, sigma_x_j = calc_input_param_classification(alpha_j, beta_j, Sigma_x)
-        X = _draw_X(rng, Nj, j_lim, D, mu_x_j, sigma_x_j, Sigma_x)
-        j_ind = np.repeat(np.arange(J), Nj)
-        f = alpha_j[j_ind] + np.einsum('nd,nd->n', X, beta_j[j_ind])
-        p = 1/(1 + np.exp(-f))
-        y = (rng.rand(X.shape[0]) < p).astype(int)
-        return Data(X, y, Nj, j_lim, phi_true,
-                    {'mu_x': mu_x_j, 'sigma_x': sigma_x_j, 'Sigma_x': Sigma_x})
-
-    def get_prior(self):
-        D = self.D
-        S0 = np.empty(self.dphi)
-        S0[0] = self.V0_MA
-        S0[1] = self.V0_SA
-        S0[2:2+D] = self.V0_MB
-        S0[2+D:] = self.V0_SB
-        S0 = np.diag(S0).T
-        m0 = np.zeros(self.dphi)
-        Q0 = np.diag(1/np.diag(S0)).T
-        r0 = m0/np.diag(S0)
-        return S0, m0, Q0, r0
-
-
 def _bernoulli(rng, f):
     return (rng.rand(f.shape[0]) < 1/(1 + np.exp(-f))).astype(int)
 
@@ -282,6 +160,63 @@ class _LogisticBase(object):
         v = self._prior_var()
         m0 = np.zeros(self.dphi)
         return np.diag(v).T, m0, np.diag(1/v).T, m0/v
+
+
+class m1b(_LogisticBase):
+    """y ~ bernoulli_logit(alpha_j + x beta), alpha_j ~ N(0, sigma_a), beta shared by the groups,
+    phi = [log sigma_a, beta] (models/m1b.py; density m1b_sg.stan)."""
+    SIGMA_A = 1            # m1b.py:36-40
+    SIGMA_AH = None
+    SIGMA_B = 1.0
+    M0_A, V0_A, M0_B, V0_B = 0, 1.5**2, 0, 1.5**2     # m1b.py:46-50
+    site_model = 'm1b_sg'
+
+    def _dphi(self, D):
+        return D + 1
+
+    def _draw_parameters(self, rng):
+        beta = rng.randn(self.D)*self.SIGMA_B
+        _regulate_rows(rng, beta[None, :], lambda index: rng.randn()*self.SIGMA_B)
+        alpha_j = rng.randn(self.J)*self.SIGMA_A
+        return alpha_j, beta, np.append(np.log(self.SIGMA_A), beta)
+
+    def get_prior(self):
+        D = self.D
+        var = np.append(self.V0_A, np.full(D, self.V0_B))
+        mean = np.append(self.M0_A, np.full(D, self.M0_B))
+        return np.diag(var).T, mean, np.diag(1./var).T, np.append(self.M0_A/self.V0_A, np.ones(D)*(self.M0_B/self.V0_B))
+
+
+class m4b(_LogisticBase):
+    """y ~ bernoulli_logit(alpha_j + x beta_j), alpha_j ~ N(mu_a, sigma_a),
+    beta_jd ~ N(mu_b_d, sigma_b_d), phi = [mu_a, log sigma_a, mu_b, log sigma_b]
+    (models/m4b.py; the paper's model)."""
+    MU_A = 1.5                      # m4b.py:44-47
+    MU_B = (-2.0, 2.0)
+    LOG_SIGMA_A = 0.4
+    LOG_SIGMA_B = (-0.5, 0.5)
+    V0_MA, V0_SA, V0_MB, V0_SB = 4**2, 2**2, 4**2, 2**2      # m4b.py:50-61
+    site_model = 'm4b_sg'
+
+    def _dphi(self, D):
+        return 2*D + 2
+
+    def _prior_var(self):
+        D = self.D
+        return np.concatenate(([self.V0_MA, self.V0_SA], np.full(D, self.V0_MB), np.full(D, self.V0_SB))).astype(np.float64)
+
+    def _draw_parameters(self, rng):
+        J, D = self.J, self.D
+        lo, hi = self.MU_B
+        mu_b = rng.rand(D)*(hi - lo) + lo
+        lo, hi = self.LOG_SIGMA_B
+        sigma_a = np.exp(self.LOG_SIGMA_A)
+        sigma_b = np.exp(rng.rand(D)*(hi - lo) + lo)
+        alpha_j = self.MU_A + rng.randn(J)*sigma_a
+        beta_j = mu_b + rng.randn(J, D)*sigma_b
+        _regulate_rows(rng, beta_j, lambda index: mu_b[index] + rng.randn()*sigma_b[index])
+        phi_true = np.concatenate(([self.MU_A, np.log(sigma_a)], mu_b, np.log(sigma_b)))
+        return alpha_j, beta_j, phi_true
 
 
 class m2b(_LogisticBase):

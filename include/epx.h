@@ -62,9 +62,17 @@ typedef struct epx_sampler_opts {
     int32_t layout;      /* 0 auto, 1 one block per site (rows resident in LDS), 2 one block per
                             (site, chain), 3 streaming (rows through an LDS-DMA ring, chains in lock step;
                             chosen automatically when the rows do not fit LDS or D > 32), 4 lock step with
-                            the rows resident in LDS (D <= 32; default for multi-group sites) */
+                            the rows resident in LDS (D <= 32; default for multi-group sites), 5 one block per
+                            site with a state wave + a row wave per chain (the default for batches that fill
+                            the chip; same draws as 1), 6 one block per chain with a state wave + 4 row waves */
     int32_t reserved;    /* flags; bit 0: layout 2 without the speculative bookkeeping wave (same draws,
-                            used for A/B measurements and tests) */
+                            used for A/B measurements and tests);
+                            bit 1: `adapt = carry` -- NOT the reference's behaviour (a fresh model.sampling per site
+                            update re-adapts from scratch, util.py:716), an opt-in the survey sanctions when it is
+                            reported: every chain starts from the step size its previous call ended with and from
+                            the site's pooled sample variances of that call as diagonal metric (regularised like
+                            Stan's estimate), and warm-up adapts the step size only.  Same target distribution;
+                            sites without history (first call, a failed chain) adapt from scratch. */
 } epx_sampler_opts;
 
 /* per-site sampler statistics written by epx_tilted_batch (doubles) */
@@ -206,6 +214,10 @@ int epx_global_moments(epx_ctx *ctx, double *S, double *m);
  * local site; where it is < thresh, adds (min_eig_target - min_eig) to the
  * diagonal of Qi.  forced[K_local] out. */
 int epx_force_pd(epx_ctx *ctx, double df, double thresh, double min_eig_target, uint8_t *forced);
+
+/* Adaptation history of site k kept for `adapt = carry` (written by every sampling call): final step size of
+ * each chain (chains entries, -1: none) and the site's diagonal metric (P entries).  Either may be NULL. */
+int epx_get_adapt(epx_ctx *ctx, int k, double *eps, double *metric);
 
 /* TEST HOOK: log density and gradient of site k at theta (P) against the
  * cavity currently held for that site (Appendix A of SURVEY.md). */

@@ -43,6 +43,8 @@ class OracleEngine(object):
         self.draws = None
         self.last = None
         self.chain_stats = None
+        self.carry_eps = None
+        self.carry_metric = None
 
     def close(self):
         pass
@@ -108,14 +110,17 @@ class OracleEngine(object):
 
     # ---- tilted
     @staticmethod
-    def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random', max_depth=10, layout=0, flags=0):
-        return dict(chains=chains, iter=iter, warmup=warmup, thin=thin, init=init, max_depth=max_depth)
+    def sampler_opts(chains=4, iter=1000, warmup=None, thin=1, init='random', max_depth=10, layout=0, flags=0,
+                     adapt='fresh'):
+        return dict(chains=chains, iter=iter, warmup=warmup, thin=thin, init=init, max_depth=max_depth,
+                    carry=(adapt == 'carry'))
 
     def sample_batch(self, seeds, opts, k0=0, count=None):
         count = self.K - k0 if count is None else count
         o = opts if isinstance(opts, dict) else dict(
             chains=opts.chains, iter=opts.iter, warmup=None if opts.warmup < 0 else opts.warmup,
-            thin=opts.thin, init={0: 'random', 1: '0', 2: 'prev'}[opts.init], max_depth=opts.max_depth)
+            thin=opts.thin, init={0: 'random', 1: '0', 2: 'prev'}[opts.init], max_depth=opts.max_depth,
+            carry=bool(opts.reserved & 2))
         sl = slice(k0, k0 + count)
         lim = self.k_lim[k0:k0 + count + 1]
         init = None
@@ -132,13 +137,17 @@ class OracleEngine(object):
             self.model, self.X[lim[0]:lim[-1]], self.y[lim[0]:lim[-1]], lim - lim[0],
             self.cav_mu[sl], self.cav_Om[sl], seeds, chains=o['chains'], iter=o['iter'],
             warmup=o['warmup'], thin=o['thin'], max_depth=o['max_depth'], init=init,
-            nthreads=self.nthreads, **grp)
+            nthreads=self.nthreads, **grp, **self._carry_args(o, sl, draws_shape=None))
         ms = (time.time() - t0) * 1e3
         if self.draws is None or self.draws.shape[1:] != draws.shape[1:]:
             self.draws = np.zeros((self.K,) + draws.shape[1:])
             self.last = np.zeros((self.K,) + last.shape[1:])
             self.chain_stats = np.zeros((self.K,) + stats.shape[1:])
         self.draws[sl] = draws; self.last[sl] = last; self.chain_stats[sl] = stats
+        ce, cm = no.carry_history(draws, stats)                     # what the device keeps after every call
+        if self.carry_eps is None or self.carry_eps.shape[1] != ce.shape[1]:
+            self.carry_eps = -np.ones((self.K, ce.shape[1])); self.carry_metric = np.ones((self.K, cm.shape[1]))
+        self.carry_eps[sl] = ce; self.carry_metric[sl] = cm
         site = np.zeros((count, 8))
         for j in range(count):
             cs = stats[j]
@@ -147,6 +156,14 @@ class OracleEngine(object):
             site[j, 2] = cs[:, 2].sum(); site[j, 3] = cs[:, 3].sum(); site[j, 4] = cs[:, 4].sum()
             site[j, 5] = cs[:, 5].mean(); site[j, 6] = cs[:, 6].mean(); site[j, 7] = cs[:, 7].sum()
         return site, ms
+
+    def _carry_args(self, o, sl, draws_shape=None):
+        if not o.get('carry') or self.carry_eps is None or self.carry_eps.shape[1] != o['chains']:
+            return {}
+        return dict(carry_eps=self.carry_eps[sl], carry_metric=self.carry_metric[sl])
+
+    def get_adapt(self, k, chains):
+        return self.carry_eps[k].copy(), self.carry_metric[k].copy()
 
     def _moments(self, k, samp, prec_estim):
         dQ, dr, mt, scatter, ok = eo.tilted_moments(samp, self.Q, self.r, prec_estim)

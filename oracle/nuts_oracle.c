@@ -538,7 +538,7 @@ static int va_learn(var_adapt *v, double *var, const double *q, int P) {
 static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter, int warmup,
                       int thin, int max_depth, const double *init, double *draws,
                       double *last, double *stats, double eps_in, const double *inv_e_in,
-                      int t_offset) {
+                      int t_offset, double carry_eps, const double *carry_inv_e) {
     const int P = site_in->P, D = site_in->D, d = site_in->d;
     site_t site = *site_in;
     const size_t nvec = 24 + 4 * (size_t)EPO_MAX_DEPTH_CAP;
@@ -586,11 +586,21 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     const double delta = 0.8, gamma = 0.05, t0 = 10.0, kappa = 0.75;
     c.eps = 1.0;
     double da_mu = log(10.0 * c.eps), s_bar = 0.0, x_bar = 0.0, da_count = 0.0;
+    /* opt-in `adapt = carry` of the device library (include/epx.h, epx_sampler_opts.reserved bit 1; not the
+     * reference's behaviour): start from the step size the chain ended its previous call with and from
+     * the site's pooled sample variances as metric; warm-up adapts the step size only */
+    const int carry = eps_in <= 0 && carry_eps > 0 && carry_inv_e;
     if (eps_in > 0) {                      /* test hook: fixed step size / metric */
         c.eps = eps_in;
         if (inv_e_in) memcpy(c.inv_e, inv_e_in, sizeof(double) * P);
-    } else
+    } else {
+        if (carry) {
+            c.eps = carry_eps;
+            da_mu = log(10.0 * c.eps);
+            memcpy(c.inv_e, carry_inv_e, sizeof(double) * P);
+        }
         init_stepsize(&c, 0);
+    }
     var_adapt va;
     va_init(&va, warmup, P, vabuf);
     double eps_sum = 0.0, acc_sum = 0.0, depth_sum = 0.0;
@@ -609,7 +619,7 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
             double x_eta = pow(da_count, -kappa);
             x_bar = (1.0 - x_eta) * x_bar + x_eta * x;
             c.eps = exp(x);
-            if (va_learn(&va, c.inv_e, c.qs, P)) {
+            if (!carry && va_learn(&va, c.inv_e, c.qs, P)) {
                 init_stepsize(&c, (uint32_t)(t + 1));
                 da_mu = log(10.0 * c.eps);
                 da_count = 0; s_bar = 0; x_bar = 0;
@@ -679,12 +689,13 @@ static void bind_site(site_t *s, int model, int D, int d, int k, const int64_t *
     s->P = epo_npar_groups(model, D, s->ng);
 }
 
-int epo_nuts_sites_groups(int model, int nsites, int D, const int64_t *k_lim, const int32_t *g_cnt,
-                          const int64_t *g_lim, const double *X,
-                          const int32_t *y, const double *mu, const double *Omega,
-                          const int64_t *seeds, int chains, int iter, int warmup, int thin,
-                          int max_depth, const double *init, double *draws, double *last,
-                          double *stats, int nthreads) {
+/* carry_eps (nsites x chains, <= 0: none) / carry_metric (nsites x Pm): the `adapt = carry` history, or NULL */
+int epo_nuts_sites_carry(int model, int nsites, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                         const int64_t *g_lim, const double *X,
+                         const int32_t *y, const double *mu, const double *Omega,
+                         const int64_t *seeds, int chains, int iter, int warmup, int thin,
+                         int max_depth, const double *init, double *draws, double *last,
+                         double *stats, int nthreads, const double *carry_eps, const double *carry_metric) {
     const int d = epo_dphi(model, D), Pm = sites_pmax(model, D, nsites, g_cnt);
     if (d < 0 || Pm < 0 || max_depth > EPO_MAX_DEPTH_CAP || thin < 1 || warmup > iter) return -1;
     const int nkeep = (iter - warmup + thin - 1) / thin;
@@ -712,7 +723,8 @@ int epo_nuts_sites_groups(int model, int nsites, int D, const int64_t *k_lim, co
         double *la = dr + (size_t)nkeep * s.P, *in0 = la + s.P;
         if (init) memcpy(in0, init + jc * Pm, sizeof(double) * s.P);
         run_chain(&s, (uint64_t)seeds[k], c, iter, warmup, thin, max_depth,
-                  init ? in0 : NULL, dr, la, stats + jc * ST_COUNT, -1.0, NULL, 0);
+                  init ? in0 : NULL, dr, la, stats + jc * ST_COUNT, -1.0, NULL, 0,
+                  carry_eps ? carry_eps[jc] : -1.0, carry_metric ? carry_metric + (size_t)k * Pm : NULL);
         for (int t = 0; t < nkeep; ++t) {
             double *dst = draws + (jc * nkeep + t) * Pm;
             memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);
@@ -724,6 +736,15 @@ int epo_nuts_sites_groups(int model, int nsites, int D, const int64_t *k_lim, co
     }
     free(g_off);
     return 0;
+}
+int epo_nuts_sites_groups(int model, int nsites, int D, const int64_t *k_lim, const int32_t *g_cnt,
+                          const int64_t *g_lim, const double *X,
+                          const int32_t *y, const double *mu, const double *Omega,
+                          const int64_t *seeds, int chains, int iter, int warmup, int thin,
+                          int max_depth, const double *init, double *draws, double *last,
+                          double *stats, int nthreads) {
+    return epo_nuts_sites_carry(model, nsites, D, k_lim, g_cnt, g_lim, X, y, mu, Omega, seeds, chains, iter, warmup,
+                                thin, max_depth, init, draws, last, stats, nthreads, NULL, NULL);
 }
 int epo_nuts_sites(int model, int nsites, int D, const int64_t *k_lim, const double *X,
                    const int32_t *y, const double *mu, const double *Omega,
@@ -769,7 +790,7 @@ int epo_nuts_transitions_groups(int model, int nsites, int D, const int64_t *k_l
         memcpy(in0, q0 + jc * Pm, sizeof(double) * s.P);
         memcpy(ie, inv_e + jc * Pm, sizeof(double) * s.P);
         run_chain(&s, (uint64_t)seeds[k], c, nt, 0, 1, max_depth, in0, dr, la, stats + jc * ST_COUNT, eps[jc],
-                  ie, t_offset);
+                  ie, t_offset, -1.0, NULL);
         for (int t = 0; t < nt; ++t) {
             double *dst = draws + (jc * nt + t) * Pm;
             memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);

@@ -105,8 +105,24 @@ def logdensity_grad(model, X, y, mu, Omega, theta, gl=None):
     return lp.value, g
 
 
+def carry_history(draws, stats):
+    """The `adapt = carry` history the device library keeps after a sampling call (k_carry_update,
+    csrc/nuts.hip): final step size per chain (-1 for a site with a failed chain) and the site's
+    pooled variances, regularised like Stan's windowed estimate.  draws (K, chains, nkeep, P)."""
+    K, C, nk, P = draws.shape
+    n = C * nk
+    eps = stats[:, :, 1].copy()
+    flat = draws.reshape(K, n, P)
+    var = flat.var(axis=1, ddof=1)
+    metric = (n / (n + 5.0)) * var + 1e-3 * (5.0 / (n + 5.0))
+    bad = stats[:, :, 7].sum(axis=1) > 0
+    eps[bad] = -1.0
+    return eps, metric
+
+
 def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=None,
-               thin=1, max_depth=10, init=None, nthreads=0, g_cnt=None, g_lim=None):
+               thin=1, max_depth=10, init=None, nthreads=0, g_cnt=None, g_lim=None,
+               carry_eps=None, carry_metric=None):
     """Sample every site; returns (draws (K,chains,nkeep,P), last (K,chains,P),
     stats (K,chains,8)). mu (K,d), Omega (K,d,d) symmetric.  With groups (g_cnt, g_lim) P is the
     largest coordinate count over the sites and shorter sites are zero padded."""
@@ -131,12 +147,17 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
     if init is not None:
         init = np.ascontiguousarray(init, dtype=np.float64).reshape(K, chains, P)
         ip = _p(init)
-    rc = L.epo_nuts_sites_groups(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
-                                 None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
-                                 None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
-                                 _yp(y), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
-                                 chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
-                                 _p(stats), nthreads)
+    ce = cm = None
+    if carry_eps is not None:
+        carry_eps = np.ascontiguousarray(carry_eps, dtype=np.float64).reshape(K, chains)
+        carry_metric = np.ascontiguousarray(carry_metric, dtype=np.float64).reshape(K, P)
+        ce, cm = _p(carry_eps), _p(carry_metric)
+    rc = L.epo_nuts_sites_carry(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
+                                None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
+                                None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
+                                _yp(y), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
+                                chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
+                                _p(stats), nthreads, ce, cm)
     if rc != 0:
         raise ValueError('epo_nuts_sites rc=%d' % rc)
     return draws, last, stats

@@ -8,6 +8,8 @@ from epstan_amd import models, _lib
 from epstan_amd.method import Master
 
 NAMES = ['prep(beta)', 'row loop', 'butterfly', 'Omega matvec', 'exchange', 'chain rule', 'state machine']
+NAMES_DUO = ['S: kick/drift/transforms/publish', 'S: tree bookkeeping', 'S: cavity term + gathers', 'S: waiting for the row waves',
+             'S: chain rule + finish', 'R: waiting for a job', 'R: row pass + butterfly + publish']
 
 def main():
     J = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -32,8 +34,8 @@ def main():
           % (J, eng.last_layout(), info, nit, np.round(M.sampling_ms, 1)))
     print('leapfrogs per chain: mean %.0f max %.0f; per transition %.0f' % (lf.mean(), lf.max(), lf.mean() / 200))
     print('cycles per leapfrog (median over %d blocks), total %.0f' % (nb, med.sum()))
-    for nm, v in zip(NAMES, med):
-        print('    %-14s %8.0f  %5.1f%%' % (nm, v, 100 * v / med.sum()))
+    for nm, v in zip(NAMES_DUO if eng.last_layout() >= 5 else NAMES, med):
+        print('    %-36s %8.0f  %5.1f%%' % (nm, v, 100 * v / med.sum()))
     wg = lf.max(axis=1)
     print('us per leapfrog of the slowest chain of a workgroup ~ %.2f' % (M.sampling_ms[-1] * 1e3 / wg.max()))
 

@@ -446,8 +446,9 @@ def test_site_order_hint_does_not_change_results(model, D, n, layout):
 @pytest.mark.parametrize('model,D,n,K', [('m1b_sg', 4, 30, 330), ('m4b_sg', 32, 300, 200)])
 def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n, K):
     """epx_set_site_split: the leading sites of the order give exactly the draws of layout 2, the
-    others those of layout 1, whatever the split (the two launches share every buffer).  K: enough
-    sites for the library to pick layout 1 by itself (320 when two layout-2 workgroups fit a CU)."""
+    others those of layout 1 (= layout 5's, bit for bit), whatever the split (the two launches share
+    every buffer).  K: enough sites for the library to pick one workgroup per site by itself (320
+    when two layout-2 workgroups fit a CU): layout 5 where the shape is instantiated, else layout 1."""
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 5, K=K, tight=30.0)
     eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     seeds = np.arange(K, dtype=np.int64) + 11
@@ -463,7 +464,7 @@ def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n, K):
         eng.set_site_split(n_lead)
         stats, ms = eng.sample_batch(seeds, opts)
         m = eng.last_split()
-        assert eng.last_layout() == 1 and 1 <= m <= n_lead
+        assert eng.last_layout() == (5 if D >= 9 else 1) and 1 <= m <= n_lead
         assert m == n_lead or n_lead == 150          # clamped to half of the CUs
         dr = np.stack([eng.get_draws(k, True) for k in range(K)])
         cs = eng.get_chain_stats(4)
@@ -1072,8 +1073,9 @@ def test_layout_policy_for_the_baseline_shapes():
 
     assert picked('m4b_sg', 64, 16, 200) == 2          # C2: fewer sites than CUs -> one workgroup per chain
     assert picked('m4b_sg', 256, 16, 200) == 2         # two such workgroups share a CU: still ahead (measured)
-    assert picked('m4b_sg', 400, 16, 200) == 1         # many small sites -> one workgroup per site
-    assert picked('m4b_sg', 512, 32, 500) == 1         # C3 / C4 per GPU
+    assert picked('m4b_sg', 400, 16, 200) == 5         # many small sites -> one workgroup per site (row + state waves)
+    assert picked('m4b_sg', 512, 32, 500) == 5         # C3 / C4 per GPU
+    assert picked('m1b_sg', 400, 4, 50) == 1           # D <= 8: the one-wave-per-chain kernel
     assert picked('m4b_sg', 100, 32, 500) == 2
     assert picked('m4b_sg', 4, 128, 2000) == 3         # C5 site size: rows beyond the LDS -> streaming
     assert picked('m1b_sg', 6, 64, 100) == 3           # D > 32

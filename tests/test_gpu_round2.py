@@ -1,0 +1,364 @@
+"""Round-2 device tests: the row-wave / state-wave sampler (layouts 5, 6), carried adaptation,
+the BASELINE configs at their own size, the fused update phase, named parameter draws.
+
+Everything goes through the C ABI (ctypes).  References are the oracle (oracle/), golden vectors
+produced by the imported reference (tests/golden/), and bit-equality between layouts that run the
+same arithmetic."""
+
+import os
+
+import numpy as np
+import pytest
+
+from epstan_amd import _lib, models
+from epstan_amd.engine import DQI, QI, HipEngine
+from epstan_amd.method import Master, Worker
+from oracle import ep_oracle as eo
+from oracle import nuts_oracle as no
+from test_gpu_parity import _engine_with_cavity, _site_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _all_draws(eng, K):
+    return np.stack([eng.get_draws(k, all_params=True) for k in range(K)])
+
+
+# ------------------------------------------------------------------ layouts 5 / 6 (nuts_duo.hip)
+@pytest.mark.parametrize('model,D,n,chains,it', [
+    ('m4b_sg', 16, 200, 4, 44),      # C2 site: one register per vector, everything in LDS
+    ('m4b_sg', 32, 500, 4, 30),      # C3 site: d = 66 (two tail rows of the cavity precision), stack + cold store in HBM
+    ('m4b_sg', 22, 300, 3, 40),      # two registers per vector, d = 46 < 64, odd chain count
+    ('m1b_sg', 16, 120, 4, 44), ('m2b_sg', 21, 333, 2, 44), ('m3b_sg', 32, 300, 4, 44), ('m5b_sg', 32, 150, 8, 30),
+    ('m4b_sg', 9, 77, 1, 44),        # odd D: padded columns
+])
+def test_row_and_state_waves_give_the_draws_of_one_wave_per_chain(model, D, n, chains, it):
+    """Layout 5 splits a chain over a row wave and a state wave that runs the tree bookkeeping one
+    leapfrog behind; every accepted state is the sequential algorithm's, in the same arithmetic
+    order: draws, last states and every statistic equal layout 1's bit for bit."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 31 + D, K=3)
+    eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([5, 6, 7], dtype=np.int64)
+    out = {}
+    for layout in (1, 5):
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=layout))
+        assert eng.last_layout() == layout
+        out[layout] = (_all_draws(eng, 3), eng.get_chain_stats(chains))
+    np.testing.assert_array_equal(out[5][0], out[1][0])
+    np.testing.assert_array_equal(out[5][1], out[1][1])
+    assert out[1][1][:, :, 7].sum() == 0
+    # warm start from the previous call's last draws: still identical
+    for layout in (1, 5):
+        eng.sample_batch(seeds + 9, HipEngine.sampler_opts(chains=chains, iter=20, init='random', layout=layout))
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=20, init='prev', layout=layout))
+        out[layout] = _all_draws(eng, 3)
+    np.testing.assert_array_equal(out[5], out[1])
+
+
+@pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m4b_sg', 32, 500), ('m1b_sg', 32, 300), ('m5b_sg', 21, 333),
+                                       ('m3b_sg', 11, 64), ('m2b_sg', 32, 100)])
+def test_duo_gradients_match_oracle(model, D, n):
+    """Every layout evaluates the density with its own gradient code: 5 (one row wave) and 6 (four
+    row waves, partial sums added by the state wave) against the C restatement."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 100 + D)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    rng = np.random.RandomState(8)
+    for k in range(2):
+        theta = rng.randn(P) * 0.5
+        lo, hi = k_lim[k], k_lim[k + 1]
+        lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta)
+        for layout in (5, 6):
+            lp, g = eng.logdensity_grad(k, theta, layout=layout)
+            assert eng.last_layout() == layout
+            assert abs(lp - lp_o) <= 1e-11 * max(1.0, abs(lp_o))
+            np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
+
+
+@pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m4b_sg', 32, 120)])
+def test_layout_6_follows_the_oracle_run(model, D, n):
+    """One workgroup per chain with four row waves: whole site updates against the C restatement,
+    chain by chain until rounding differences are amplified past a decision (as for layouts 1, 2)."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([101, 202, 303], dtype=np.int64)
+    it = 44
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=6))
+    assert eng.last_layout() == 6
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=4, iter=it)
+    cs = eng.get_chain_stats(4)
+    n_full = 0
+    for k in range(3):
+        dev = eng.get_draws(k, all_params=True)
+        ref = draws_o[k].reshape(-1, P)
+        err = np.abs(dev - ref).reshape(4, it // 2, P).max(axis=2) / max(1.0, np.abs(ref).max())
+        for c in range(4):
+            assert np.all(err[c, :5] < 1e-3), (k, c, err[c, :5])
+            if np.all(err[c] < 1e-4):
+                n_full += 1
+                assert cs[k, c, 3] == st_o[k, c, 3]
+    print('layout 6: chains equal to the oracle to the end: %d of 12' % n_full)
+    assert n_full >= 9, n_full
+
+
+def test_layout_policy_prefers_the_duo_kernel_for_large_batches():
+    """Auto layout: batches that fill the chip run the row-wave / state-wave kernel when the shape is
+    instantiated (D padded to 16 or 32), the one-wave-per-chain kernel otherwise; an explicit layout
+    is honoured; a lead split keeps working."""
+    mod = models.m4b(330, 16, 60)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=12)
+    eng = M.engine
+    seeds = np.arange(330) + 1
+    ref = {}
+    for layout in (0, 1, 5, 2):
+        eng.set_site_order(None)
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', layout=layout, max_depth=6))
+        ref[layout] = (_all_draws(eng, 330), eng.last_layout())
+    assert [ref[l][1] for l in (0, 1, 5, 2)] == [5, 1, 5, 2]
+    np.testing.assert_array_equal(ref[0][0], ref[1][0])
+    # split launch: the lead sites of the order run one workgroup per chain (layout 2's draws)
+    order = np.arange(330, dtype=np.int32)[::-1].copy()
+    eng.set_site_order(order)
+    eng.set_site_split(9)
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', max_depth=6))
+    m = eng.last_split()
+    assert eng.last_layout() == 5 and 1 <= m <= 9
+    dr = _all_draws(eng, 330)
+    lead = order[:m]
+    rest = order[m:]
+    np.testing.assert_array_equal(dr[lead], ref[2][0][lead])
+    np.testing.assert_array_equal(dr[rest], ref[1][0][rest])
+    eng.set_site_order(None)
+    eng.set_site_split(0)
+
+
+# ------------------------------------------------------------------ adapt = 'carry'
+def test_carried_adaptation_history_and_second_call_follow_the_oracle():
+    """`adapt='carry'` (opt-in, not the reference's behaviour): (1) without history the call IS a
+    fresh one; (2) the history the library keeps (final step sizes, pooled regularised variances)
+    equals the NumPy statement of it; (3) the next call, started from that history, follows the C
+    restatement given the same history, chain by chain until they part."""
+    model, D, n, it = 'm4b_sg', 16, 200, 60
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 23, K=3, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([41, 42, 43], dtype=np.int64)
+    for layout in (1, 2, 5):
+        eng2, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+        eng2.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=layout))
+        fresh = _all_draws(eng2, 3)
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=layout, adapt='carry'))
+        np.testing.assert_array_equal(_all_draws(eng, 3), fresh)                 # (1): no history yet
+        cs = eng.get_chain_stats(4)
+        eps_h, met_h = no.carry_history(_all_draws(eng, 3).reshape(3, 4, it // 2, P), cs)
+        for k in range(3):                                                      # (2)
+            e, m = eng.get_adapt(k, 4)
+            np.testing.assert_array_equal(e, cs[k, :, 1])
+            np.testing.assert_allclose(e, eps_h[k], rtol=0)
+            np.testing.assert_allclose(m, met_h[k], rtol=1e-11)
+        hist = [eng.get_adapt(k, 4) for k in range(3)]
+        last = _all_draws(eng, 3).reshape(3, 4, it // 2, P)[:, :, -1, :]
+        eng.sample_batch(seeds + 50, HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=layout, adapt='carry'))
+        cs2 = eng.get_chain_stats(4)
+        draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds + 50, chains=4, iter=it, init=last,
+                                         carry_eps=np.stack([h[0] for h in hist]),
+                                         carry_metric=np.stack([h[1] for h in hist]))
+        n_full = 0
+        for k in range(3):                                                      # (3)
+            dev = eng.get_draws(k, all_params=True)
+            ref = draws_o[k].reshape(-1, P)
+            err = np.abs(dev - ref).reshape(4, it // 2, P).max(axis=2) / max(1.0, np.abs(ref).max())
+            for c in range(4):
+                assert np.all(err[c, :5] < 1e-3), (layout, k, c, err[c, :5])
+                if np.all(err[c] < 1e-4):
+                    n_full += 1
+                    assert cs2[k, c, 3] == st_o[k, c, 3]
+        print('carry, layout %d: chains equal to the oracle to the end: %d of 12' % (layout, n_full))
+        assert n_full >= 9, (layout, n_full)
+        # the metric stayed the carried one: the step size was tuned around the carried value, not from 1
+        assert np.all(cs2[:, :, 1] > 0.2 * np.stack([h[0] for h in hist])) and np.all(cs2[:, :, 1] < 5 * np.stack([h[0] for h in hist]))
+
+
+def test_ep_with_carried_adaptation_agrees_with_the_fresh_path_and_needs_fewer_leapfrogs():
+    """Same target distribution: the EP posterior with adapt='carry' agrees with adapt='fresh' within
+    the Monte-Carlo spread of two fresh seeds; the carried runs need fewer gradients per iteration."""
+    mod = models.m4b(24, 8, 120)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+
+    def run(adapt, seed):
+        M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=400,
+                   df0=models.default_df0(24), adapt=adapt)
+        info, (m_s, S_s) = M.run(8, verbose=False, seed=seed)
+        assert info == 0
+        return m_s[-1], np.sqrt(np.diag(S_s[-1])), np.array(M.ngrad_log)
+
+    m_a, s_a, g_a = run('fresh', 1)
+    m_b, s_b, g_b = run('fresh', 2)
+    m_c, s_c, g_c = run('carry', 1)
+    spread = np.abs(m_a - m_b) / s_a
+    dev = np.abs(m_c - m_a) / s_a
+    print('EP mean, |fresh(1) - fresh(2)| / sd: max %.2f ; |carry - fresh| / sd: max %.2f ; gradients per iteration '
+          'fresh %.3g, carry %.3g' % (spread.max(), dev.max(), g_a[2:].mean(), g_c[2:].mean()))
+    assert dev.max() < max(3.0 * spread.max(), 0.6)
+    np.testing.assert_allclose(s_c, s_a, rtol=0.5)
+    assert g_c[2:].mean() < g_a[2:].mean()
+
+
+# ------------------------------------------------------------------ BASELINE configs at their own size
+def test_one_ep_iteration_at_c3_size_with_invariants():
+    """C3 = C4 per GPU: J = 512 sites, D = 32, n_j = 500, m4b, 4 x 200.  Two EP iterations through the
+    default path (layout 5, HBM tree stack + cold store, fused update): finite, positive definite,
+    symmetric, site sums consistent with the global approximation, one site's moment stage against
+    the oracle from the device's own draws, and the split launch reproduces the unsplit draws."""
+    J, D, n = 512, 32, 500
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
+               df0=models.default_df0(J))
+    eng = M.engine
+    info, (m_s, S_s), (st, ms, rh, ot) = M.run(2, verbose=False, return_analytics=True, seed=1)
+    assert info == 0 and eng.last_layout() == 5
+    assert np.all(np.isfinite(m_s)) and np.all(np.isfinite(S_s))
+    for S in S_s:
+        np.testing.assert_allclose(S, S.T, rtol=1e-10, atol=1e-14)
+        assert np.linalg.eigvalsh(S)[0] > 0
+    np.testing.assert_allclose(M.Q, M.Q0 + M.Qi.sum(axis=2), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(M.r, M.r0 + M.ri.sum(axis=1), rtol=1e-9, atol=1e-8)
+    stats = M.last_site_stats
+    assert stats[:, 7].sum() == 0 and np.all(stats[:, 2] > 0)
+    print('C3: leapfrogs per transition %.0f, sampling launches %s ms, update phase %s ms'
+          % (stats[:, 2].sum() / (J * 4 * 200), np.round(M.sampling_ms, 1), np.round(ot * 1e3, 2)))
+    # one site's moment stage from the device's own draws (method.py:413-458)
+    k = 137
+    samp = eng.get_draws(k)
+    Mat, vec, nsamp = eng.get_tilted(k)
+    assert nsamp == 400
+    np.testing.assert_allclose(vec, samp.mean(axis=0), rtol=1e-10, atol=1e-12)
+    c = samp - samp.mean(axis=0)
+    np.testing.assert_allclose(Mat, c.T.dot(c), rtol=1e-8, atol=1e-9)
+    # the split launch (lead sites one workgroup per chain) against explicit layouts on the same state
+    seeds = np.arange(J) + 77
+    ref = {}
+    eng.set_site_order(None)
+    for layout in (5, 2):
+        eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=16, init='random', layout=layout, max_depth=7))
+        ref[layout] = _all_draws(eng, J)
+    order = np.argsort(-stats[:, 2]).astype(np.int32)
+    eng.set_site_order(order)
+    eng.set_site_split(12)
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=16, init='random', max_depth=7))
+    m = eng.last_split()
+    assert m >= 1
+    dr = _all_draws(eng, J)
+    np.testing.assert_array_equal(dr[order[:m]], ref[2][order[:m]])
+    np.testing.assert_array_equal(dr[order[m:]], ref[5][order[m:]])
+
+
+def test_one_damped_iteration_at_c5_site_size_through_the_sweep():
+    """C5 site shape (D = 128, n_j = 2000, d = 258; rows streamed from HBM, dense kernels on the
+    global workspace) on 64 sites: one EP iteration through run(..., sweep=) with prec_estim='olse'
+    (S = 400 draws against d = 258: the `sample` estimator's S > d + 2 barely holds)."""
+    J, D, n = 64, 128, 2000
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(rng=100)                     # uncorrelated covariates (footnote)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
+               prec_estim='olse', df0=0.2)
+    d = M.dphi
+    assert d == 258
+    S0, m0 = M.cur_approx()
+    damps = 0.85 ** np.arange(31)
+    sw = dict(damps=damps, m_target=m0, S_target=S0)
+    info, (m_s, S_s) = M.run(1, verbose=False, seed=5, sweep=sw)
+    assert info == 0 and M.engine.last_layout() == 3
+    log = M.sweep_log[0]
+    assert log['global_pd'].shape == (31,) and np.all(np.isfinite(log['kls'][log['cav_pd']]))
+    assert log['cav_pd'].any()
+    np.testing.assert_allclose(S_s[0], S_s[0].T, rtol=1e-9, atol=1e-13)
+    assert np.linalg.eigvalsh(S_s[0])[0] > 0
+    np.testing.assert_allclose(M.Q, M.Q0 + M.Qi.sum(axis=2), rtol=1e-9, atol=1e-8)
+    # the accepted factor's criteria against a host computation on the downloaded state
+    i = int(np.argmin(np.abs(damps - M.df_log[-1])))
+    if abs(damps[i] - M.df_log[-1]) < 1e-12 and log['cav_pd'][i]:
+        mse = np.mean((m_s[0] - m0) ** 2)
+        np.testing.assert_allclose(log['mses'][i], mse, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ host contract on the device
+def test_master_init_golden_partition_and_init_site_on_gpu(golden_dir):
+    """G5 (vectors produced by the imported reference's Master.__init__): partition arrays, initial
+    global approximation and cavities with init_site, on the DEVICE engine (method.py:696-730, 853-882)."""
+    alg = np.load(os.path.join(golden_dir, 'algebra.npz'))
+    X, y, sizes = alg['g5_X'], alg['g5_y'], alg['g5_sizes']
+    M = Master('m1b_sg', X, y, site_sizes=sizes, dphi=4, init_site=3.0)
+    assert isinstance(M.engine, HipEngine)
+    np.testing.assert_array_equal(M.k_lim, alg['g5_k_lim'])
+    np.testing.assert_array_equal(M.k_ind, alg['g5_k_ind'])
+    np.testing.assert_allclose(M.Q, alg['g5_Q'], rtol=1e-12)
+    np.testing.assert_allclose(M.Qi, alg['g5_Qi'], rtol=1e-12)
+    S, m = M.cur_approx()
+    np.testing.assert_allclose(S, alg['g5_S'], rtol=1e-11)
+    ind_ord = np.repeat(np.arange(3), sizes)
+    M2 = Master('m1b_sg', X, y, site_ind_ord=ind_ord, dphi=4)
+    np.testing.assert_array_equal(M2.k_lim, alg['g5_ord_k_lim'])
+    np.testing.assert_allclose(M2.workers[1].Mat, alg['g5_w1_Mat'], rtol=1e-12)
+    np.testing.assert_allclose(M2.workers[1].vec, alg['g5_w1_vec'], atol=1e-14)
+    perm = np.random.RandomState(0).permutation(30)
+    M3 = Master('m1b_sg', X[perm], y[perm], site_ind=ind_ord[perm], dphi=4)
+    np.testing.assert_array_equal(M3.k_lim, alg['g5_k_lim'])
+    with pytest.raises(ValueError):
+        Master('m1b_sg', X, y, site_sizes=np.array([7, 0, 23]), dphi=4)
+
+
+def test_force_pd_keeps_the_tilted_moments(golden_dir):
+    """the force-pd fallback used the tilted means as scratch.  After an iteration that goes
+    through it, mix_phi and Worker.vec still equal the pooled moments of the injected draws."""
+    import injectors
+    runs = np.load(os.path.join(golden_dir, 'master_run.npz'))
+    Nj = runs['g6_Nj'][:3]
+    nrow = int(Nj.sum())
+    M = Master('m1b_sg', runs['g6_X'][:nrow], runs['g6_y'][:nrow], site_sizes=Nj,
+               prior={'Q': runs['g6_Q0'], 'r': runs['g6_r0']}, A_k={'site_id': np.arange(3)}, chains=4, iter=200,
+               df0=1.0, df_treshold=0.9)
+    inj = injectors.GaussianTilted('wide_first')
+    M._sample_injector = inj
+    seen = []
+    M._sample_injector = lambda data, sp: seen.append(inj(data, sp)) or seen[-1]
+    info = M.run(1, verbose=False, calc_moments=False, seed=1)
+    assert info == 0
+    samp = seen[-3:]
+    S_mix, m_mix = M.mix_phi()
+    pooled = np.concatenate(samp)
+    means = np.array([s.mean(axis=0) for s in samp])
+    np.testing.assert_allclose(m_mix, means.mean(axis=0), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(S_mix, np.cov(pooled.T, ddof=1) if False else
+                               (sum((s - s.mean(0)).T.dot(s - s.mean(0)) for s in samp)
+                                + samp[0].shape[0] * (means - means.mean(0)).T.dot(means - means.mean(0))) / (pooled.shape[0] - 1),
+                               rtol=1e-9, atol=1e-11)
+
+
+def test_named_parameter_draws_from_the_device():
+    """Worker.tilted(save_samples=...) / Master.run(save_last_param=...) by parameter name
+    (method.py:352-359, 387-392; experiment/fit.py:366 passes ('alpha', 'beta'))."""
+    mod = models.m4b(4, 3, 60)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=80, df0=0.4)
+    info = M.run(2, verbose=False, calc_moments=False, save_last_param=('alpha', 'beta'), seed=2)
+    assert info == 0
+    for k, w in enumerate(M.workers):
+        th = M.engine.get_draws(k, all_params=True)
+        assert set(w.saved_samp) == {'alpha', 'beta'}
+        assert w.saved_samp['alpha'].shape == (160,) and w.saved_samp['beta'].shape == (160, 3)
+        np.testing.assert_allclose(w.saved_samp['alpha'], th[:, 0] + th[:, 8] * np.exp(th[:, 1]), rtol=1e-13)
+        np.testing.assert_allclose(w.saved_samp['beta'], th[:, 2:5] + th[:, 9:12] * np.exp(th[:, 5:8]), rtol=1e-13)
+    w = M.workers[1]
+    dQ, dr = np.zeros((8, 8), order='F'), np.zeros(8)
+    assert w.tilted(dQ, dr, save_samples=['phi', 'sigma_a'], seed=3)
+    np.testing.assert_array_equal(w.saved_samp['phi'], M.engine.get_draws(1))
+    with pytest.raises(ValueError, match='not defined'):
+        w.cavity(M.Q, M.r, M.Qi[:, :, 1], M.ri[:, 1])
+        w.tilted(dQ, dr, save_samples=['gamma'], seed=3)
