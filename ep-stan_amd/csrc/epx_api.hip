@@ -539,9 +539,9 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
             a = t;
             a.err = c->err_flag;
             layout = layout == 6 ? 6 : 5;
-            const size_t per_chain = nuts_duo_chain_doubles(a, nv);
-            if (per_chain) {
-                const size_t need = (size_t)stack_sites * o.chains * per_chain;
+            {
+                a.stack_stride = nuts_resident_chain_doubles(nv, o.max_depth);
+                const size_t need = (size_t)stack_sites * o.chains * a.stack_stride;
                 if (c->stack_elems < need) {
                     if (c->stack) (void)hipFree(c->stack);
                     HIPCHK(dalloc(&c->stack, need));
@@ -583,8 +583,8 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {
-        const size_t need = layout >= 3 ? (size_t)stack_sites * o.chains * nuts_stream_chain_doubles(nv, o.max_depth)
-                                        : (size_t)stack_sites * o.chains * o.max_depth * (4 * nv * 64 + 2);
+        a.stack_stride = layout >= 3 ? nuts_stream_chain_doubles(nv, o.max_depth) : nuts_resident_chain_doubles(nv, o.max_depth);
+        const size_t need = (size_t)stack_sites * o.chains * a.stack_stride;
         if (c->stack_elems < need) {
             if (c->stack) (void)hipFree(c->stack);
             HIPCHK(dalloc(&c->stack, need));

@@ -137,7 +137,12 @@ struct NutsArgs {
     const double *carry_metric;   // K x P
     unsigned long long *stamps;   // diagnostic build (-DEPX_STAMPS): per block 8 cycle sums
     double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
-    double *stack;                // per (site of batch, chain): max_depth * (4P + 2) doubles, or NULL when in LDS
+    double *stack;                // global memory of the chains of the resident layouts, indexed by (site of the batch,
+                                  // chain): stack_stride doubles each -- tree stack (max_depth * (4 NV 64 + 2)) first,
+                                  // then the state wave's cold store (nuts_duo.hip); one stride for every kernel of a
+                                  // call, so the two kernels of a split launch can share the buffer.  Streaming layout:
+                                  // nuts_stream_chain_doubles() per chain
+    size_t stack_stride;
     // dynamic LDS layout (byte offsets), computed on the host
     int n_max;                    // rows reserved for X in LDS
     int off_y, off_Om, off_mu, off_xch, off_stack, lds_bytes;
@@ -165,7 +170,7 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream);
 size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max);
 bool nuts_duo_has(int cpb, int rw, int dp, int nv);
-size_t nuts_duo_chain_doubles(const NutsArgs &a, int nv);
+size_t nuts_resident_chain_doubles(int nv, int max_depth);
 
 // streaming variant (nuts_stream.hip): one workgroup per site, chains in lock step, X through
 // an LDS-DMA ring; dpb in {64, 128}, nv = ceil(P/64) <= 7.  a.stack holds, per (site of the

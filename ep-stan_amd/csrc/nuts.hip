@@ -102,7 +102,7 @@ k_nuts(NutsArgs a) {
     auto om_at = [&](int idx) -> double { if constexpr (OML) return Oms[idx]; else return Om_g[idx]; };
 
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
-    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.stack_stride;
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
 
@@ -438,7 +438,7 @@ k_nuts_spec(NutsArgs a) {
 
     // =============================================================== bookkeeping wave
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack);
-    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.max_depth * SREC;
+    double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.stack_stride;
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);

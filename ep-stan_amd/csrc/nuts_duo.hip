@@ -227,9 +227,8 @@ k_nuts_duo(NutsArgs a) {
     const int wt = 0;
     // global memory of the chain: the tree stack (unless it is in LDS), then the cold store (COLD)
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
-    const size_t g_stack = STL ? 0 : (size_t)a.max_depth * SREC;
-    double *stk_g = (STL && !COLD) ? nullptr
-        : uniform_ptr(a.stack + ((size_t)sb * a.chains + chain) * (g_stack + (COLD ? (size_t)GV_COUNT * NV * 64 : 0)));
+    const size_t g_stack = (size_t)a.max_depth * SREC;                 // the cold store sits behind the stack's place
+    double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)sb * a.chains + chain) * a.stack_stride);
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
@@ -618,10 +617,9 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     return off;
 }
 
-// doubles of global memory per chain: the tree stack when it is not in LDS + the cold store at nv = 2
-size_t nuts_duo_chain_doubles(const NutsArgs &a, int nv) {
-    const bool cold = nv >= 2 || a.cpb > 1;          // as launch_duo_one instantiates
-    return (a.stack_in_lds ? 0 : (size_t)a.max_depth * (4 * nv * 64 + 2)) + (cold ? (size_t)GV_COUNT * nv * 64 : 0);
+// doubles of global memory per chain of the resident layouts: tree stack + cold store (NutsArgs::stack)
+size_t nuts_resident_chain_doubles(int nv, int max_depth) {
+    return (size_t)max_depth * (4 * nv * 64 + 2) + (size_t)GV_COUNT * nv * 64;
 }
 
 template <int NV, int DP, int CPB, int RW>

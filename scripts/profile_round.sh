@@ -19,14 +19,15 @@ for w in $WHICH; do
   rm -rf $OUT/${w}_*
   case $w in
   c2)
-    python3 $REPO/bench.py > $OUT/c2_bench.json 2> $OUT/c2_bench.err
-    prof c2 --steps 3 --warmup 1 ;;
+    python3 $REPO/bench.py --config c2 > $OUT/c2_bench.json 2> $OUT/c2_bench.err
+    prof c2 --config c2 --steps 3 --warmup 1 ;;
   c3)
-    python3 $REPO/bench.py --sites 512 --D 32 --n 500 --steps 6 --warmup 3 --cpu-sites 0 > $OUT/c3_bench.json 2> $OUT/c3_bench.err
-    prof c3 --sites 512 --D 32 --n 500 --steps 3 --warmup 3 ;;
+    # the driver's command: the default workload (C3), default steps / warm-up
+    python3 $REPO/bench.py > $OUT/c3_bench.json 2> $OUT/c3_bench.err
+    prof c3 --steps 3 --warmup 5 ;;
   stream)
-    python3 $REPO/bench.py --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1 --cpu-sites 0 > $OUT/stream_bench.json 2> $OUT/stream_bench.err
-    prof stream --sites 512 --D 128 --n 2000 --cor-input 0 --steps 1 --warmup 1 ;;
+    python3 $REPO/bench.py --config c5shard --cpu-sites 0 > $OUT/stream_bench.json 2> $OUT/stream_bench.err
+    prof stream --config c5shard ;;
   esac
 done
 ls -R $OUT | head -60

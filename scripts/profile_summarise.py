@@ -6,7 +6,7 @@ Usage: python scripts/profile_summarise.py [round_tag]"""
 import glob, json, os, shutil, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'round')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 
 
 def dbs(d):
@@ -65,7 +65,7 @@ for name in ('c2', 'c3', 'stream'):
         if kernel_rows(db)[0] is not None:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
                                    os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.csv' % (tag, name))])
-    warmup, key = {'c2': (1, [64, 16, 200, 'm4b', 4, 200]), 'c3': (3, [512, 32, 500, 'm4b', 4, 200]),
+    warmup, key = {'c2': (1, [64, 16, 200, 'm4b', 4, 200]), 'c3': (5, [512, 32, 500, 'm4b', 4, 200]),
                    'stream': (1, [512, 128, 2000, 'm4b', 4, 200])}[name]
     f, f_it, f_ms = pmc_sums(name + '_fetch', warmup)
     w, w_it, w_ms = pmc_sums(name + '_write', warmup)
