@@ -79,8 +79,6 @@ typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) int lds_i32;
 __device__ inline lds_f64 *lds_d(unsigned byte_off) { return reinterpret_cast<lds_f64 *>(byte_off); }
 __device__ inline lds_i32 *lds_i(unsigned byte_off) { return reinterpret_cast<lds_i32 *>(byte_off); }
-typedef double v2f64 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) v2f64 lds_d2;
 
 // Byte offsets from the start of the engine's LDS block (the start of the dynamic segment).  The
 // block depends on the largest number of groups per site (K < J: several (eta, etb) blocks per
@@ -160,10 +158,6 @@ template <int DPB> struct PassArgs {
     int slot_i;                 // ring: slot the next DMA goes to       (loader)
     int t_i;                    // ring: site tile the next DMA fetches  (loader)
     int wave, lane;
-    // cavity term fused into the pass (om_cpp > 0): Omega (phi - mu) for the 4 chains, om_cpp columns per tile phase
-    const double *Om_g;         // the site's cavity precision, d x d column-major (symmetric), global memory
-    int d, om_cpp;
-    unsigned vs4_lds, ovs_lds;  // LDS byte addresses of (phi - mu)[e][chain] and of the result Omega (phi - mu)[e][chain]
     unsigned off[StreamGeom<DPB>::NI];   // loader: per-lane byte offsets of the pieces of a full tile
 };
 struct PassOut { double ll; int slot_f, slot_i, t_i; };
@@ -271,9 +265,7 @@ __device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
 template <int DPB>
 __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, const int *yg, int n, int D, int ntile,
                                                              int ngmax, int ntmax, unsigned lds0, int slot_f0,
-                                                             int slot_i0, int t_i0, int wave_, int lane,
-                                                             const double *Om_g, int d_, int om_cpp_,
-                                                             unsigned vs4_lds_, unsigned ovs_lds_) {
+                                                             int slot_i0, int t_i0, int wave_, int lane) {
     using Gm = StreamGeom<DPB>;
     PassArgs<DPB> s;
     s.Xg = Xg; s.yg = yg; s.n = n; s.D = D; s.ntile = ntile; s.lds0 = lds0;
@@ -296,30 +288,6 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
         double acc[Gm::MB];
 #pragma unroll
         for (int mb = 0; mb < Gm::MB; ++mb) acc[mb] = 0.0;
-        // ---- the cavity term rides along (om_cpp > 0): Omega (phi - mu) is pure streaming of d x d doubles and
-        // depends on nothing the pass produces, so its columns are spread over the tile phases instead of
-        // taking a pass of their own.  Lane = row: wave w owns rows 64 w + lane and, beyond 256 rows,
-        // 256 + 64 w + lane; every phase takes om_cpp (<= 4) columns whose loads were issued the phase before
-        // (global loads of THIS wave: its own vmcnt, the loader's DMA ring is not touched).
-        const int om_cpp = __builtin_amdgcn_readfirstlane(om_cpp_), od = __builtin_amdgcn_readfirstlane(d_);
-        const unsigned vs4b = __builtin_amdgcn_readfirstlane(vs4_lds_), ovsb = __builtin_amdgcn_readfirstlane(ovs_lds_);
-        const int orow0 = wave * 64 + lane, orow1 = 256 + wave * 64 + lane;
-        const bool o_two = 256 + wave * 64 < od;            // wave-uniform: this wave has rows beyond 256
-        const double *om0p = Om_g + (orow0 < od ? orow0 : od - 1);
-        const double *om1p = Om_g + (orow1 < od ? orow1 : od - 1);
-        double omA[4] = {0, 0, 0, 0}, omB[4] = {0, 0, 0, 0};      // the coming phase's columns of the two rows
-        double oA[4] = {0, 0, 0, 0}, oB[4] = {0, 0, 0, 0};        // Omega (phi - mu), rows orow0 / orow1 x 4 chains
-        auto om_fetch = [&](int ph) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = ph * om_cpp + u;
-                if (u < om_cpp && j < od) {                 // wave-uniform
-                    omA[u] = om0p[(size_t)j * od];
-                    if (o_two) omB[u] = om1p[(size_t)j * od];
-                }
-            }
-        };
-        if (om_cpp > 0) om_fetch(0);
         int g_bq = -1, g_acc = -1;              // group whose coefficients are in bq / whose gradient is in acc
         int g_l = 0, g_b = 0;                   // groups of tiles p-1, p-2
         int g_n = tile_group(0);                // group of the tile of the coming phase (fetched one phase ahead)
@@ -386,42 +354,12 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
                     for (int mb = 0; mb < Gm::MB; ++mb)
                         acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[ks * Gm::MB + mb], bb[ks], acc[mb], 0, 0, 0);
             }
-            if (om_cpp > 0) {
-                double cA[4], cB[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { cA[u] = omA[u]; cB[u] = omB[u]; }
-                om_fetch(p + 1);                // next phase's columns, in flight across the barrier
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = p * om_cpp + u;
-                    if (u < om_cpp && j < od) {
-                        const v2f64 v01 = *reinterpret_cast<lds_d2 *>(vs4b + j * 32);
-                        const v2f64 v23 = *reinterpret_cast<lds_d2 *>(vs4b + j * 32 + 16);
-                        oA[0] = fma(cA[u], v01.x, oA[0]); oA[1] = fma(cA[u], v01.y, oA[1]);
-                        oA[2] = fma(cA[u], v23.x, oA[2]); oA[3] = fma(cA[u], v23.y, oA[3]);
-                        if (o_two) {
-                            oB[0] = fma(cB[u], v01.x, oB[0]); oB[1] = fma(cB[u], v01.y, oB[1]);
-                            oB[2] = fma(cB[u], v23.x, oB[2]); oB[3] = fma(cB[u], v23.y, oB[3]);
-                        }
-                    }
-                }
-            }
             slot_b = slot_l; slot_l = slot_f;
             g_b = g_l; g_l = g_f;
             g_n = __builtin_amdgcn_readfirstlane(g_next) >> 8;
             if (p < nt) slot_f = slot_f + 1 == NSL ? 0 : slot_f + 1;
         }
         if (g_acc >= 0) flush();                // publish G[group][column][chain] of the last group
-        if (om_cpp > 0) {
-            if (orow0 < od) {
-                *reinterpret_cast<lds_d2 *>(ovsb + orow0 * 32) = v2f64{oA[0], oA[1]};
-                *reinterpret_cast<lds_d2 *>(ovsb + orow0 * 32 + 16) = v2f64{oA[2], oA[3]};
-            }
-            if (o_two && orow1 < od) {
-                *reinterpret_cast<lds_d2 *>(ovsb + orow1 * 32) = v2f64{oB[0], oB[1]};
-                *reinterpret_cast<lds_d2 *>(ovsb + orow1 * 32 + 16) = v2f64{oB[2], oB[3]};
-            }
-        }
     } else if (wave == NCH) {
         // ------------------------------------------------ loader
         int slot_i = __builtin_amdgcn_readfirstlane(s.slot_i), t_i = __builtin_amdgcn_readfirstlane(s.t_i);
@@ -495,7 +433,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
 template <int DPB>
 __device__ inline PassOut stream_pass(const PassArgs<DPB> &s) {
     return stream_pass_impl<DPB>(s.Xg, s.yg, s.n, s.D, s.ntile, s.ngmax, s.ntmax, s.lds0, s.slot_f, s.slot_i, s.t_i,
-                                 s.wave, s.lane, s.Om_g, s.d, s.om_cpp, s.vs4_lds, s.ovs_lds);
+                                 s.wave, s.lane);
 }
 
 // ====================================================================== resident variant

@@ -123,7 +123,6 @@ k_nuts_stream(NutsArgs a) {
     site.ngmax = a.ngmax; site.ntmax = a.ntmax;
     site.lds0 = (unsigned)(size_t)smem; site.slot_f = 0; site.slot_i = 0; site.t_i = 0;
     site.wave = wave; site.lane = lane0;
-    site.Om_g = nullptr; site.d = d; site.om_cpp = 0; site.vs4_lds = 0; site.ovs_lds = 0;
     {
         // tile table: every group's rows are tiled on their own
         int *nt_s = sh_done + 1;
@@ -152,18 +151,6 @@ k_nuts_stream(NutsArgs a) {
     const double *Om_g = a.cav_Om + (size_t)k * d * d;
     if constexpr (RES) {
         if (a.om_in_lds) { for (int i = tid; i < d * d; i += NT) Om_s[i] = Om_g[i]; }
-    }
-    // Streaming variant: the cavity term Omega (phi - mu) rides inside the row pass (epx_stream_tile.h) when its
-    // d columns spread over the tile phases at <= 4 columns per phase (C5: 258 columns over 127 phases) and the
-    // rows fit two per lane of the four chain waves (d <= 512); otherwise it keeps a pass of its own below.
-    bool fuse_om = false;
-    if constexpr (!RES) {
-        const int cpp = (d + site.ntile + 1) / (site.ntile + 2);
-        fuse_om = cpp <= 4 && d <= 512;
-        if (fuse_om) {
-            site.Om_g = Om_g; site.d = d; site.om_cpp = cpp;
-            site.vs4_lds = (unsigned)(size_t)vs4; site.ovs_lds = (unsigned)(size_t)Ovs;
-        }
     }
     const size_t chain_slot = (size_t)sb * a.chains + (active ? chain : 0);
     // wave-uniform base pointers (held in scalar registers; lanes add lane*8)
@@ -364,7 +351,7 @@ k_nuts_stream(NutsArgs a) {
                         *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[h][2], o[h][3]);
                     }
                 }
-            } else if (!fuse_om && tid < d) {
+            } else if (tid < d) {
                 // thread = row
                 double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
                 const double *omp = Om_g + tid;
@@ -390,15 +377,8 @@ k_nuts_stream(NutsArgs a) {
                 *reinterpret_cast<double2 *>(Ovs + tid * NCH + 2) = make_double2(o2, o3);
             }
         }
-        if (RES || !fuse_om) lds_barrier();     // (fused: the pass's closing barrier publishes Omega (phi - mu) too)
+        lds_barrier();
         STAMP(1);
-        if constexpr (RES) {
-            ll = resident_pass<DPB>(site.lds0, RM, site.ntile, a.ngmax, wave, lane, NT, tid);
-        } else {
-            const PassOut po = stream_pass<DPB>(site);
-            site.slot_f = po.slot_f; site.slot_i = po.slot_i; site.t_i = po.t_i;
-            ll = po.ll;
-        }
         if (is_chain) {
             // cavity part of the gradient and of lp
             FORV {
@@ -415,6 +395,13 @@ k_nuts_stream(NutsArgs a) {
                 }
                 zg.v[i] = g;
             }
+        }
+        if constexpr (RES) {
+            ll = resident_pass<DPB>(site.lds0, RM, site.ntile, a.ngmax, wave, lane, NT, tid);
+        } else {
+            const PassOut po = stream_pass<DPB>(site);
+            site.slot_f = po.slot_f; site.slot_i = po.slot_i; site.t_i = po.t_i;
+            ll = po.ll;
         }
         }
         STAMP(2);
