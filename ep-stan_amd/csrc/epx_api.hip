@@ -510,14 +510,11 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         a.no_spec = 0;
         return 0;
     }
-    if (c->multi && c->gauss)
-        return fail("Gaussian-likelihood models with several groups per site need D <= 32, at most 128 sampled coordinates and "
-                    "the site's rows, cavity precision, tree stack and mailbox in LDS; this shape (D = %d, P = %d, n_max = %d) "
-                    "is not supported", c->D, c->P, c->n_max);
+    // (Gaussian-likelihood sites that do not fit the resident forms above are streamed: layout 3)
     if (layout == 2 && c->multi) layout = 0;
-    if ((layout == 4 || (layout == 0 && c->multi)) && c->D <= 32 && nv <= 7) {
+    if ((layout == 4 || (layout == 0 && c->multi)) && c->D <= 32 && nv <= 7 && !c->gauss) {
         const int dpl = c->D <= 16 ? 16 : 32;
-        size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max);
+        size_t lds = nuts_stream_lds_bytes(nv, dpl, c->d, c->ng_max, c->nt_max, c->n_max, 0);
         if (lds <= LDS_CAP) {
             lock = true; layout = 4; dp = dpl;
             a.cpb = 4; a.n_max = c->n_max; a.stack_in_lds = 0; a.om_in_lds = 0;
@@ -565,11 +562,10 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         if (lds > LDS_CAP) resident = false;
     }
     if (c->gauss) {
-        // Gaussian-likelihood family: built for the everything-in-LDS forms of the resident kernels
+        // Gaussian-likelihood family: the resident kernels are built for their everything-in-LDS forms; any other
+        // shape (rows beyond the LDS, D > 32, several groups with many coordinates) is streamed (layout 3)
         const bool ok = resident && a.om_in_lds && (wpc == 1 || (a.stack_in_lds && a.off_spec > 0 && !no_spec));
-        if (!ok) return fail("Gaussian-likelihood models need the site's rows, the cavity precision and (one workgroup "
-                             "per chain) the tree stack in LDS; this shape (D = %d, n_max = %d, layout %d) is not supported",
-                             c->D, c->n_max, o.layout);
+        if (!ok) resident = false;
     }
     if (!resident && !lock) {
         // rows (or parameters) do not fit the resident kernel: stream X through an LDS tile
@@ -579,7 +575,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         dp = c->D <= 64 ? 64 : 128;
         a.cpb = 4; wpc = 1;
         a.stack_in_lds = 0; a.om_in_lds = 0;
-        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d, c->ng_max, c->nt_max, 0);
+        a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d, c->ng_max, c->nt_max, 0, c->gauss);
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {

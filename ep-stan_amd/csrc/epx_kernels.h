@@ -176,7 +176,7 @@ size_t nuts_resident_chain_doubles(int nv, int max_depth);
 // an LDS-DMA ring; dpb in {64, 128}, nv = ceil(P/64) <= 7.  a.stack holds, per (site of the
 // batch, chain), nuts_stream_chain_doubles() doubles (tree stack + cold store).
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream);
-size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int nmax_res);
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int nmax_res, int gauss);
 size_t nuts_stream_chain_doubles(int nv, int max_depth);
 
 struct RhatArgs {

@@ -85,7 +85,8 @@ __device__ inline lds_i32 *lds_i(unsigned byte_off) { return reinterpret_cast<ld
 // site, each with its own coefficients / gradient) and of tiles per site of the launch.
 struct StreamMap {
     unsigned ring;      // NSL slots of TR row images
-    unsigned yring;     // NSL x TR responses (int32)
+    unsigned yring;     // NSL x TR responses: int32 (logistic family) or float64 (Gaussian family)
+    unsigned is2;       // 4 chains: 1 / sigma^2 of the Gaussian likelihood (published with alpha, beta)
     unsigned part;      // 2 buffers x 4 waves x [chain][row] forward partials
     unsigned gs;        // 2 buffers x [chain][row] residuals
     unsigned red;       // 4 chains x {-, ll}
@@ -96,12 +97,13 @@ struct StreamMap {
     unsigned da;        // groups x 4 sums of residuals
     unsigned end;
 };
-template <int DPB> __host__ __device__ inline StreamMap stream_map(int ngmax, int ntmax) {
+template <int DPB> __host__ __device__ inline StreamMap stream_map(int ngmax, int ntmax, int gauss) {
     using Gm = StreamGeom<DPB>;
     StreamMap m;
     unsigned o = 0;
     m.ring = o; o += NSL * Gm::SLOTB;
-    m.yring = o; o += NSL * TR * 4;
+    m.yring = o; o += NSL * TR * (gauss ? 8 : 4);
+    m.is2 = o; o += gauss ? NCH * 8 : 0;
     m.part = o; o += 2 * 4 * 64 * 8;
     m.gs = o; o += 2 * 64 * 8;
     m.red = o; o += NCH * 2 * 8;
@@ -116,10 +118,11 @@ template <int DPB> __host__ __device__ inline StreamMap stream_map(int ngmax, in
 
 // what the sampler kernel touches directly (generic pointers into the same block)
 struct StreamLds {
-    double *beta_s, *Gs, *alpha_s, *da_s;
+    double *beta_s, *Gs, *alpha_s, *da_s, *is2_s;
     int *tdesc;
-    template <int DPB> __device__ void carve(unsigned char *base, int ngmax, int ntmax) {
-        const StreamMap m = stream_map<DPB>(ngmax, ntmax);
+    template <int DPB> __device__ void carve(unsigned char *base, int ngmax, int ntmax, int gauss) {
+        const StreamMap m = stream_map<DPB>(ngmax, ntmax, gauss);
+        is2_s = reinterpret_cast<double *>(base + m.is2);
         beta_s = reinterpret_cast<double *>(base + m.beta);
         Gs = reinterpret_cast<double *>(base + m.gsum);
         alpha_s = reinterpret_cast<double *>(base + m.alpha);
@@ -150,7 +153,8 @@ __host__ __device__ inline int build_tiles(int ng, const long long *glim_rel, in
 // callee's lazy loads of it put vmcnt(0) waits inside the loader's loop)
 template <int DPB> struct PassArgs {
     const double *Xg;           // first row of the site
-    const int *yg;              // its responses (int32)
+    const int *yg;              // its responses: int32 0/1, or (gauss) the float64 responses viewed as int32 pairs
+    int gauss;                  // Gaussian likelihood: y real, residual (y - f) / sigma^2 with 1/sigma^2 per chain in LDS
     int n, D, ntile;
     int ngmax, ntmax;           // LDS map parameters of the launch
     unsigned lds0;              // LDS byte address of the engine's block
@@ -239,7 +243,12 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
             glds16(src, dst + q * 1024);
         }
     }
-    {
+    if (s.gauss) {
+        // 16 doubles = 32 dwords: lane -> (row lane / 2, half lane % 2); the DMA writes consecutive dwords
+        const int r = (lane >> 1) & (TR - 1);
+        const int row = row0 + (r < nval ? r : nval - 1);
+        if (lane < 2 * TR) glds4(s.yg + 2 * (size_t)row + (lane & 1), s.lds0 + M.yring + slot * TR * 8);
+    } else {
         const int r = lane & (TR - 1);
         const int row = row0 + (r < nval ? r : nval - 1);
         if (lane < TR) glds4(s.yg + row, s.lds0 + M.yring + slot * TR * 4);
@@ -249,7 +258,7 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
 // Prime the ring: the first three tiles (loader wave; the site must have at least one row).
 template <int DPB>
 __device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
-    const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax);
+    const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax, s.gauss);
     for (int i = 0; i < 3; ++i) {
         ring_issue<DPB>(s, M, s.t_i, s.slot_i, lane);
         s.t_i = s.t_i + 1 == s.ntile ? 0 : s.t_i + 1;
@@ -265,15 +274,16 @@ __device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
 template <int DPB>
 __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, const int *yg, int n, int D, int ntile,
                                                              int ngmax, int ntmax, unsigned lds0, int slot_f0,
-                                                             int slot_i0, int t_i0, int wave_, int lane) {
+                                                             int slot_i0, int t_i0, int wave_, int lane, int gauss_) {
     using Gm = StreamGeom<DPB>;
     PassArgs<DPB> s;
     s.Xg = Xg; s.yg = yg; s.n = n; s.D = D; s.ntile = ntile; s.lds0 = lds0;
+    s.gauss = __builtin_amdgcn_readfirstlane(gauss_);
     s.ngmax = __builtin_amdgcn_readfirstlane(ngmax); s.ntmax = __builtin_amdgcn_readfirstlane(ntmax);
     s.slot_f = slot_f0; s.slot_i = slot_i0; s.t_i = t_i0; s.wave = wave_; s.lane = lane;
     const int wave = __builtin_amdgcn_readfirstlane(s.wave);
     if (wave == NCH) loader_init<DPB>(s, lane);
-    const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax);
+    const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax, s.gauss);
     const int nt = __builtin_amdgcn_readfirstlane(s.ntile);
     const unsigned B0 = __builtin_amdgcn_readfirstlane(s.lds0);
     const int l15 = lane & 15, lg = lane >> 4, l3 = lane & 3;
@@ -381,6 +391,8 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
         // two dependent LDS round trips plus a read-modify-write per tile made it this one.
         double ll = 0.0, da_acc = 0.0, alpha_l = 0.0;
         double wprod = 1.0, wlog = 0.0;         // log-likelihood = sum(lin) - log(prod(w)), see logistic_split
+        const bool gauss = s.gauss != 0;
+        const double is2 = gauss ? *lds_d(B0 + M.is2 + lg * 8) : 0.0;     // 1 / sigma^2 of this lane's chain
         for (int i = lane; i < s.ngmax * NCH; i += 64) *lds_d(B0 + M.da + i * 8) = 0.0;
         int pk_n = __builtin_amdgcn_readfirstlane(*lds_i(B0 + M.tdesc + 4));       // tile 0
         int g_cur = -1;
@@ -407,7 +419,10 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
 #pragma unroll
                 for (int w = 0; w < 4; ++w) f += *lds_d(B0 + M.part + ((pb * 4 + w) * 64 + lane) * 8);
                 double l = 0.0, w = 1.0, g = 0.0;
-                logistic_split(f, (double)*lds_i(B0 + M.yring + (slot_l * TR + l15) * 4), l, w, g);
+                if (gauss) {            // -(y - f)^2 / (2 sigma^2); the -n log sigma term is the caller's (m*a_sg.stan)
+                    const double res = *lds_d(B0 + M.yring + (slot_l * TR + l15) * 8) - f;
+                    g = res * is2; l = -0.5 * res * g;
+                } else logistic_split(f, (double)*lds_i(B0 + M.yring + (slot_l * TR + l15) * 4), l, w, g);
                 const bool ok = l15 < nval;
                 g = ok ? g : 0.0;
                 *lds_d(B0 + M.gs + (pb * 64 + lane) * 8) = g;
@@ -433,7 +448,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
 template <int DPB>
 __device__ inline PassOut stream_pass(const PassArgs<DPB> &s) {
     return stream_pass_impl<DPB>(s.Xg, s.yg, s.n, s.D, s.ntile, s.ngmax, s.ntmax, s.lds0, s.slot_f, s.slot_i, s.t_i,
-                                 s.wave, s.lane);
+                                 s.wave, s.lane, s.gauss);
 }
 
 // ====================================================================== resident variant

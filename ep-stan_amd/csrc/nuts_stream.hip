@@ -91,6 +91,9 @@ k_nuts_stream(NutsArgs a) {
     const int g0 = a.site_g0 ? a.site_g0[k] : 0;
     const int ng = a.site_g0 ? a.site_g0[k + 1] - g0 : 1;
     const int P = d + ng * (model == 0 ? 1 : 1 + D);
+    // Gaussian-likelihood family (experiment/models/m*a.stan): phi = [log sigma | the b-model's phi]: the b-model's
+    // hyper-parameters sit O = 1 further on; responses are real (a.yd)
+    const int O = a.gauss ? 1 : 0;
 
     // ---- LDS carve-up
     StreamLds L;
@@ -103,8 +106,8 @@ k_nuts_stream(NutsArgs a) {
         L.tdesc = reinterpret_cast<int *>(smem + RM.tdesc);
         eng_end = RM.end;
     } else {
-        L.template carve<DPB>(smem, a.ngmax, a.ntmax);
-        eng_end = stream_map<DPB>(a.ngmax, a.ntmax).end;
+        L.template carve<DPB>(smem, a.ngmax, a.ntmax, a.gauss);
+        eng_end = stream_map<DPB>(a.ngmax, a.ntmax, a.gauss).end;
     }
     double *mu_s = reinterpret_cast<double *>(smem + eng_end);     // d (padded to even)
     double *vs4 = mu_s + ((d + 1) & ~1);                           // d x 4: phi - mu, [e][chain]
@@ -118,7 +121,9 @@ k_nuts_stream(NutsArgs a) {
     for (int e = tid; e < d; e += NT) mu_s[e] = a.cav_mu[(size_t)k * d + e];
 
     PassArgs<DPB> site;
-    site.Xg = a.X + (size_t)row0 * D; site.yg = a.y32 + row0;
+    site.Xg = a.X + (size_t)row0 * D;
+    site.gauss = a.gauss;
+    site.yg = a.gauss ? reinterpret_cast<const int *>(a.yd + row0) : a.y32 + row0;
     site.n = (int)(a.k_lim[k + 1] - row0); site.D = D;
     site.ngmax = a.ngmax; site.ntmax = a.ntmax;
     site.lds0 = (unsigned)(size_t)smem; site.slot_f = 0; site.slot_i = 0; site.t_i = 0;
@@ -286,8 +291,9 @@ k_nuts_stream(NutsArgs a) {
             FORV { qc[lane + 64 * i] = zq.v[i]; eqc[lane + 64 * i] = exp_d(zq.v[i]); }
             // theta = [phi (d) | eta (ng) | etb (ng x D)]; per group j: alpha_j, beta_j (Appendix A of
             // SURVEY.md, m*b.stan); a0 + eta_j * sa and b0[c] + etb_j[c] * sbv[c]
-            sa = eqc[model >= 3 ? 1 : 0];
-            const double a0 = model >= 3 ? qc[0] : 0.0;
+            sa = eqc[O + (model >= 3 ? 1 : 0)];
+            const double a0 = model >= 3 ? qc[O] : 0.0;
+            if (O && lane == 0) L.is2_s[wave] = exp_d(-2.0 * qc[0]);          // 1 / sigma^2
             for (int g = 0; g < ng; ++g) {
 #pragma unroll
                 for (int b = 0; b < (DPB + 63) / 64; ++b) {
@@ -296,10 +302,10 @@ k_nuts_stream(NutsArgs a) {
                     double bj = 0.0;
                     if (c < D) {
                         const double eb = model == 0 ? 0.0 : qc[d + ng + g * D + c];
-                        if (model == 0) bj = qc[1 + c];
-                        else if (model == 1) bj = eb * eqc[1];
-                        else if (model == 2) bj = eb * eqc[1 + c];
-                        else bj = qc[2 + c] + eb * eqc[2 + D + c];
+                        if (model == 0) bj = qc[O + 1 + c];
+                        else if (model == 1) bj = eb * eqc[O + 1];
+                        else if (model == 2) bj = eb * eqc[O + 1 + c];
+                        else bj = qc[O + 2 + c] + eb * eqc[O + 2 + D + c];
                     }
                     L.beta_s[(g * DPB + c) * NCH + wave] = bj;
                 }
@@ -426,6 +432,10 @@ k_nuts_stream(NutsArgs a) {
                 }
                 dot = wave_sum(tsum);
             }
+            // Gaussian likelihood: the pass returned sum -(y - f)^2 / (2 sigma^2); d/d log sigma = sum (y - f)^2 / sigma^2 - n
+            // and lp gets -n log sigma (as in the resident kernels, nuts_gradient.inc)
+            double c_ls = 0.0;
+            if (O) { c_ls = -2.0 * ll - (double)site.n; ll -= (double)site.n * qc[0]; }
             // sums over the groups that the shared coordinates need
             double s_da = 0.0, s_daeta = 0.0;
             for (int g = 0; g < ng; ++g) { const double t = dag(g); s_da += t; s_daeta += t * qc[d + g]; }
@@ -438,13 +448,15 @@ k_nuts_stream(NutsArgs a) {
                 if (e < d) {
                     // hyper-parameters: every group contributes
                     const int isa = model >= 3 ? 1 : 0;
-                    if (model >= 3 && e == 0) g += s_da;
-                    else if (e == isa) g += s_daeta * sa;
-                    else if (model == 1) { if (e == 1) g += dot * eqc[1]; }
+                    const int eb = e - O;                                   // index in the b-model's phi
+                    if (O && e == 0) g += c_ls;                             // log sigma
+                    else if (model >= 3 && eb == 0) g += s_da;
+                    else if (eb == isa) g += s_daeta * sa;
+                    else if (model == 1) { if (eb == 1) g += dot * eqc[O + 1]; }
                     else {
                         // slope block(s): m1b beta (1..D); m3b log sigma_b (1..D); m4b/m5b mu_b (2..1+D), log sigma_b (2+D..)
-                        const int c = model >= 3 ? (e < 2 + D ? e - 2 : e - 2 - D) : e - 1;
-                        const bool scale = model == 2 || (model >= 3 && e >= 2 + D);
+                        const int c = model >= 3 ? (eb < 2 + D ? eb - 2 : eb - 2 - D) : eb - 1;
+                        const bool scale = model == 2 || (model >= 3 && eb >= 2 + D);
                         double acc = 0.0;
                         for (int gg = 0; gg < ng; ++gg)
                             acc += scale ? Gg(gg, c) * qc[d + ng + gg * D + c] : Gg(gg, c);
@@ -454,7 +466,7 @@ k_nuts_stream(NutsArgs a) {
                     g = dag(e - d) * sa - pr;                               // eta_g
                 } else if (e < P) {
                     const int idx = e - d - ng, gg = idx / D, c = idx - gg * D;   // etb_g[c]
-                    const double sbv = model == 1 ? eqc[1] : (model == 2 ? eqc[1 + c] : eqc[2 + D + c]);
+                    const double sbv = model == 1 ? eqc[O + 1] : (model == 2 ? eqc[O + 1 + c] : eqc[O + 2 + D + c]);
                     g = Gg(gg, c) * sbv - pr;
                 }
                 zg.v[i] = e < P ? g : 0.0;
@@ -514,7 +526,7 @@ k_nuts_stream(NutsArgs a) {
 }
 
 // LDS bytes of the streaming kernel
-size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int nmax_res) {
+size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int nmax_res, int gauss) {
     const size_t pmax = 64 * (size_t)nv;
     size_t eng;
     size_t dbl = (size_t)((d + 1) & ~1) + 2 * (size_t)d * NCH + 2 * NCH * pmax + 2;
@@ -522,7 +534,7 @@ size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int n
         eng = dpb == 16 ? res_map<16>(nmax_res, ngmax, ntmax).end : res_map<32>(nmax_res, ngmax, ntmax).end;
         dbl += (size_t)NCH * d * NCH - (size_t)d * NCH;
     } else
-        eng = dpb == 64 ? stream_map<64>(ngmax, ntmax).end : stream_map<128>(ngmax, ntmax).end;
+        eng = dpb == 64 ? stream_map<64>(ngmax, ntmax, gauss).end : stream_map<128>(ngmax, ntmax, gauss).end;
     return eng + dbl * 8;
 }
 // doubles of global memory per chain: tree stack + cold store
@@ -560,7 +572,7 @@ int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
     const bool res = dpb <= 32;
-    const size_t lds = res ? (size_t)a.lds_bytes : nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax, 0);
+    const size_t lds = res ? (size_t)a.lds_bytes : nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax, 0, a.gauss);
     if (dpb == 16) return launch_stream_nv<16, true>(a, nblocks, nv, lds, stream);
     if (dpb == 32) return launch_stream_nv<32, true>(a, nblocks, nv, lds, stream);
     if (dpb == 64) return launch_stream_nv<64, false>(a, nblocks, nv, lds, stream);

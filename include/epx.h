@@ -116,12 +116,12 @@ int epx_ctx_create_groups(int device, int model, int K_local, int D, const int64
 
 /* The same for the Gaussian-likelihood models (EPX_M1A_SG..EPX_M5A_SG; `real y[N]` in
  * experiment/models/m1a_sg.stan:16, simulated in models/m1a.py:150-176): y holds real responses.
- * One group per site; the site's rows, cavity precision (and, for one workgroup per chain, the tree
- * stack) must fit the LDS -- other shapes are refused by the sampling calls. */
+ * One group per site.  Sites whose rows, cavity precision (and, for one workgroup per chain, the tree stack) fit
+ * the LDS run on the resident kernels, all others (D > 32, rows beyond the LDS) on the streaming layout. */
 int epx_ctx_create_real(int device, int model, int K_local, int D, const int64_t *k_lim, const double *X,
                         const double *y, epx_ctx **out);
 /* ... with several groups per site (experiment/models/m1a.stan:11-45, `j_ind`; g_cnt / g_lim as in
- * epx_ctx_create_groups): served by the one-workgroup-per-chain layout only (D <= 32, <= 128 coordinates). */
+ * epx_ctx_create_groups): the one-workgroup-per-chain layout (D <= 32, <= 128 coordinates), else streaming. */
 int epx_ctx_create_real_groups(int device, int model, int K_local, int D, const int64_t *k_lim, const int32_t *g_cnt,
                                const int64_t *g_lim, const double *X, const double *y, epx_ctx **out);
 int epx_ctx_destroy(epx_ctx *ctx);

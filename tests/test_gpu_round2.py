@@ -75,6 +75,27 @@ def test_duo_gradients_match_oracle(model, D, n):
             np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
 
 
+@pytest.mark.parametrize('chains,it,thin,init', [(2, 40, 3, '0'), (8, 24, 1, 'random'), (3, 30, 2, 'random')])
+def test_duo_chain_counts_thinning_partial_batches(chains, it, thin, init):
+    """chains != 4, thinning, init='0' and a sub-range of the sites (k0 > 0) through layout 5: the draws of
+    layout 1, which the oracle-based tests pin (method.py:154-160, 579-583; find_damp.py uses 8 chains)."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 12, 70, 77, K=5, tight=100.0)
+    eng, _, _ = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    seeds = np.arange(5, dtype=np.int64) + 3
+    out = {}
+    for layout in (1, 5):
+        opts = HipEngine.sampler_opts(chains=chains, iter=it, thin=thin, init=init, layout=layout)
+        eng.sample_batch(seeds, opts)
+        full = _all_draws(eng, 5)
+        eng.sample_batch(seeds[2:4], opts, k0=2, count=2)                  # sites 2, 3 again, alone
+        assert eng.last_layout() == layout
+        part = _all_draws(eng, 5)
+        np.testing.assert_array_equal(part, full)
+        out[layout] = full
+    np.testing.assert_array_equal(out[5], out[1])
+    assert eng.num_draws() == chains * ((it - it // 2 + thin - 1) // thin)
+
+
 @pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m4b_sg', 32, 120)])
 def test_layout_6_follows_the_oracle_run(model, D, n):
     """One workgroup per chain with four row waves: whole site updates against the C restatement,
@@ -132,6 +153,87 @@ def test_layout_policy_prefers_the_duo_kernel_for_large_batches():
     np.testing.assert_array_equal(dr[rest], ref[1][0][rest])
     eng.set_site_order(None)
     eng.set_site_split(0)
+
+
+# ------------------------------------------------------------------ Gaussian-likelihood family, streamed (layout 3)
+@pytest.mark.parametrize('model,D,n', [('m1a_sg', 40, 150), ('m4a_sg', 128, 300), ('m3a_sg', 64, 100), ('m2a_sg', 100, 257),
+                                       ('m5a_sg', 33, 90), ('m4a_sg', 16, 2500), ('m1a_sg', 8, 90)])
+def test_gaussian_family_streams_when_the_site_is_not_lds_resident(model, D, n):
+    """experiment/models/m{1..5}a_sg.stan on sites the resident kernels cannot hold (D > 32, or rows beyond the
+    LDS): served by the streaming layout since round 2 (refused before).  Gradient against the oracle; the
+    last shape is resident-size and takes the streaming layout on request."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 100 + D)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    rng = np.random.RandomState(5)
+    for k in range(2):
+        for trial in range(2):
+            theta = rng.randn(P) * (0.2 + 0.4 * trial)
+            lo, hi = k_lim[k], k_lim[k + 1]
+            lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta)
+            lp, g = eng.logdensity_grad(k, theta, layout=3 if D <= 8 else 0)
+            assert eng.last_layout() == 3
+            assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o)), (lp, lp_o)
+            np.testing.assert_allclose(g, g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+
+
+@pytest.mark.parametrize('model,D,n,chains', [('m4a_sg', 40, 100, 4), ('m1a_sg', 16, 120, 3)])
+def test_gaussian_family_streamed_run_follows_the_oracle(model, D, n, chains):
+    """Whole site updates of the Gaussian family through layout 3, chain by chain against the C restatement."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 9 + D, K=3, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([11, 22, 33], dtype=np.int64)
+    it = 44
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=3))
+    assert eng.last_layout() == 3
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it)
+    cs = eng.get_chain_stats(chains)
+    n_full = 0
+    for k in range(3):
+        dev = eng.get_draws(k, all_params=True)
+        ref = draws_o[k].reshape(-1, P)
+        err = np.abs(dev - ref).reshape(chains, it // 2, P).max(axis=2) / max(1.0, np.abs(ref).max())
+        for c in range(chains):
+            assert np.all(err[c, :5] < 1e-3), (k, c, err[c, :5])
+            if np.all(err[c] < 1e-4):
+                n_full += 1
+                assert cs[k, c, 3] == st_o[k, c, 3]
+    print('Gaussian family, layout 3: chains equal to the oracle to the end: %d of %d' % (n_full, 3 * chains))
+    assert n_full >= (3 * chains * 3) // 4, n_full
+
+
+def test_gaussian_family_with_many_groups_per_site_streams():
+    """m4a with 8 groups per site: 35 + 8 * 17 = 171 sampled coordinates, beyond the resident multi-group kernel:
+    gradient and a short site update through layout 3 against the oracle (experiment/models/m4a.stan)."""
+    rng = np.random.RandomState(3)
+    D, groups = 16, [[20] * 8, [15, 25, 20, 20, 20, 20, 20, 20]]
+    sizes = [sum(g) for g in groups]
+    N = sum(sizes)
+    X = rng.randn(N, D)
+    y = 0.3 + X.dot(rng.randn(D) * 0.4) + 0.7 * rng.randn(N)
+    k_lim = np.concatenate(([0], np.cumsum(sizes)))
+    g_cnt = np.array([len(g) for g in groups], dtype=np.int32)
+    g_lim = np.concatenate(([0], np.cumsum([n for g in groups for n in g])))
+    eng = HipEngine('m4a', X, y, k_lim, g_cnt=g_cnt, g_lim=g_lim)
+    d = eng.d
+    A = rng.randn(d, d + 3)
+    Om = A.dot(A.T) / (d + 3) + 0.5 * np.eye(d)
+    mu = 0.3 * rng.randn(d)
+    for k in range(2):
+        assert eng.cavity_site(k, Om + np.eye(d), Om.dot(mu), np.eye(d), np.zeros(d))
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(2)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(2)])
+    assert eng.P == d + 8 * (1 + D)
+    off = np.concatenate(([0], np.cumsum(g_cnt)))
+    for k in range(2):
+        theta = 0.3 * rng.randn(eng.P)
+        gl = g_lim[off[k]:off[k + 1] + 1] - k_lim[k]
+        lp_o, g_o = no.logdensity_grad('m4a', X[k_lim[k]:k_lim[k + 1]], y[k_lim[k]:k_lim[k + 1]], mu_dev[k], Om_dev[k], theta, gl=gl)
+        lp, g = eng.logdensity_grad(k, theta, layout=0)
+        assert eng.last_layout() == 3
+        assert abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o))
+        np.testing.assert_allclose(g, g_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g_o).max()))
+    stats, ms = eng.sample_batch(np.array([5, 6]), HipEngine.sampler_opts(chains=2, iter=24, init='random'))
+    assert eng.last_layout() == 3 and np.all(np.isfinite(stats)) and stats[:, 7].sum() == 0
 
 
 # ------------------------------------------------------------------ adapt = 'carry'
