@@ -30,6 +30,13 @@
 
 namespace epx {
 
+// s_setprio levels (A/B, scripts/ab_duo.py): with the critical-path shortcut the state wave is the longer of the
+// two, so the row wave must NOT outrank it (row wave 2 / state wave 0: 1 390 ms; all equal: 1 175 ms per launch)
+#ifndef EPX_PRIO_R
+#define EPX_PRIO_R 0
+#define EPX_PRIO_S_BG 0
+#define EPX_PRIO_S_CRIT 2
+#endif
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23 };
 
 __device__ inline int duo_wait(const volatile int *flag, int want) {
@@ -150,7 +157,7 @@ k_nuts_duo(NutsArgs a) {
         STAMP_INIT;
         // the row pass is the longest link of a leapfrog's critical chain: it wins the SIMD's issue arbitration
         // against the state wave (of another chain) it shares the SIMD with, whose bookkeeping has slack
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(EPX_PRIO_R);
         for (int seq = 1;; ++seq) {
             const int got = duo_wait(f_job, seq);
             STAMP(5);
@@ -355,6 +362,25 @@ k_nuts_duo(NutsArgs a) {
     bool pending = false;
     int seq = 0, bail = 0;
     const int lane0 = lane;
+    // ---- the critical-path shortcut (m4b / m5b, one row wave).  (alpha, beta) of the NEXT position depend on
+    // 3 (D + 1) of the P coordinates only, and the hierarchical structure is the same for every one of them:
+    //   beta_j = mu_b[j] + etb[j] exp(lsig_b[j])   (lane j < D)      alpha = mu_a + eta exp(lsig_a)   (lane LA)
+    // with gradients  d mu = -Ov + t,  d raw = t exp(lsig) - prior'(raw),  d lsig = -Ov + t raw exp(lsig),
+    // t = (X'g)[j] for beta_j and sum g for alpha.  Lane j keeps ITS triple (position, half-kicked momentum,
+    // metric) of the position in flight in registers -- a "view" of the state vectors in the row waves' lane
+    // order.  When the row wave's sums arrive, the view alone gives the next (alpha, beta): ~60 dependent
+    // instructions instead of the whole chain rule + kick + drift + transforms with their cross-lane gathers;
+    // the job goes out, THEN the full vectors are brought up to date (same operations on the same values: the
+    // view and the vectors agree bit for bit, and so do the draws with layout 1).
+    constexpr int LA = 32;                              // the lane that carries alpha's triple (D <= 32)
+    const bool fast_ok = RW == 1 && model >= 3;
+    const bool v_lane = lane0 < D || lane0 == LA;
+    const int ve1 = !v_lane ? 0 : (lane0 == LA ? 0 : 2 + lane0);            // location:  mu_a | mu_b[j]
+    const int ve2 = !v_lane ? 0 : (lane0 == LA ? d : d + 1 + lane0);        // raw:       eta  | etb[j]
+    const int ve3 = !v_lane ? 0 : (lane0 == LA ? 1 : 2 + D + lane0);        // log scale: lsig_a | lsig_b[j]
+    double vq1 = 0, vq2 = 0, vq3 = 0, vp1 = 0, vp2 = 0, vp3 = 0, vm1 = 1, vm2 = 1, vm3 = 1, vex3 = 1, vo1 = 0, vo3 = 0;
+    bool fast_pub = false;                              // the job of the position in flight went out by the shortcut
+    double job_eps = 0.0;
     STAMP_INIT;
 
     for (;;) {
@@ -364,36 +390,49 @@ k_nuts_duo(NutsArgs a) {
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
         EPX_BIND_COLD(lane);
-        // ---- first half of the leapfrog from (zq, zp, zg): speculative while `pending`
+        // ---- first half of the leapfrog from (zq, zp, zg): speculative while `pending`.  When the shortcut has
+        // already sent the job of this position, the full vectors are only needed AFTER the bookkeeping below
+        // (which leaves (zq, zp, zg) alone unless it restarts the trajectory): computing them there keeps
+        // three vectors out of the bookkeeping's register budget
         V sq, sp, sg, eq;
-        FORV sp.v[i] = zp.v[i] + 0.5 * eps_l * zg.v[i];
-        FORV sq.v[i] = zq.v[i] + eps_l * inv_e.v[i] * sp.v[i];
-        FORV eq.v[i] = exp_d(sq.v[i]);
-        double alpha, sa, eta, sb2 = 0.0, beta_l;
-        if (model == 0) {
-            sa = elemU(eq, 0); eta = elemU(sq, d);
-            alpha = eta * sa; beta_l = gatherV(sq, 1 + lane);
-        } else if (model == 1) {
-            sa = elemU(eq, 0); sb2 = elemU(eq, 1); eta = elemU(sq, 2);
-            alpha = eta * sa; beta_l = gatherV(sq, 3 + lane) * sb2;
-        } else if (model == 2) {
-            sa = elemU(eq, 0); eta = elemU(sq, d);
-            alpha = eta * sa; beta_l = gatherV(sq, d + 1 + lane) * gatherV(eq, 1 + lane);
-        } else {
-            sa = elemU(eq, 1); eta = elemU(sq, d);
-            alpha = elemU(sq, 0) + eta * sa;
-            beta_l = gatherV(sq, 2 + lane) + gatherV(sq, d + 1 + lane) * gatherV(eq, 2 + D + lane);
-        }
-        // ---- hand (alpha, beta) to the row waves
-        {
+        double sa = 0.0, eta = 0.0, sb2 = 0.0;
+        auto first_half = [&]() {
+            FORV sp.v[i] = zp.v[i] + 0.5 * eps_l * zg.v[i];
+            FORV sq.v[i] = zq.v[i] + eps_l * inv_e.v[i] * sp.v[i];
+            FORV eq.v[i] = exp_d(sq.v[i]);
+            if (model == 0) { sa = elemU(eq, 0); eta = elemU(sq, d); }
+            else if (model == 1) { sa = elemU(eq, 0); sb2 = elemU(eq, 1); eta = elemU(sq, 2); }
+            else if (model == 2) { sa = elemU(eq, 0); eta = elemU(sq, d); }
+            else { sa = elemU(eq, 1); eta = elemU(sq, d); }
+        };
+        const bool sent = fast_pub;
+        if (!sent) first_half();
+        if (!fast_pub) {
+            double alpha, beta_l;
+            if (model == 0) { alpha = eta * sa; beta_l = gatherV(sq, 1 + lane); }
+            else if (model == 1) { alpha = eta * sa; beta_l = gatherV(sq, 3 + lane) * sb2; }
+            else if (model == 2) { alpha = eta * sa; beta_l = gatherV(sq, d + 1 + lane) * gatherV(eq, 1 + lane); }
+            else {
+                alpha = elemU(sq, 0) + eta * sa;
+                beta_l = gatherV(sq, 2 + lane) + gatherV(sq, d + 1 + lane) * gatherV(eq, 2 + D + lane);
+            }
+            // ---- hand (alpha, beta) to the row waves
             double *job = slot + JOB;
             if (lane < DP) job[1 + lane] = beta_l;
             if (lane == 0) job[0] = alpha;
             ++seq;
             duo_publish(f_job, seq);
+            job_eps = eps_l;
+            if (fast_ok) {
+                // (re)build the view of the position in flight from the vectors: start of the chain, or the
+                // bookkeeping restarted the trajectory elsewhere
+                vq1 = gatherV(sq, ve1); vq2 = gatherV(sq, ve2); vq3 = gatherV(sq, ve3);
+                vp1 = gatherV(sp, ve1); vp2 = gatherV(sp, ve2); vp3 = gatherV(sp, ve3);
+                vm1 = gatherV(inv_e, ve1); vm2 = gatherV(inv_e, ve2); vm3 = gatherV(inv_e, ve3);
+                vex3 = gatherV(eq, ve3);
+            }
         }
-        const double job_eps = eps_l;
-        __builtin_amdgcn_s_setprio(0);              // from here to the row waves' answer nothing waits for this wave
+        __builtin_amdgcn_s_setprio(EPX_PRIO_S_BG);      // from here to the row waves' answer nothing waits for this wave
         STAMP(0);
 
         // ---- while they sweep the rows: the bookkeeping of the leapfrog that finished before this one
@@ -431,9 +470,11 @@ k_nuts_duo(NutsArgs a) {
                 }
                 STAMP(3);
                 if (bail || leave) { bail |= leave << 1; break; }
+                fast_pub = false;               // the new start goes out by the full transforms at the loop top
                 continue;
             }
         }
+        if (sent) first_half();
         STAMP(1);
 
         // ---- cavity term Ov = Omega (phi - mu) of the position in flight ...
@@ -473,7 +514,46 @@ k_nuts_duo(NutsArgs a) {
             }
         }
         FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
-        // ... and the parts of the chain rule that only need the position
+        if (fast_ok) { vo1 = gatherV(Ov, ve1); vo3 = gatherV(Ov, ve3); }
+
+        STAMP(2);
+        // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
+        for (int w = 0; w < RW; ++w) {
+            const int got = duo_wait(f_res + w, seq);
+            if (got != seq) bail = 1;
+        }
+        STAMP(3);
+        __builtin_amdgcn_s_setprio(EPX_PRIO_S_CRIT);    // chain rule, half kick, drift, publish: the row waves wait for it
+        if (bail) break;
+        double da, ll, dbf[NV];
+        if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
+        else {
+            da = 0.0; ll = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) { da += slot[JOB + w * RES + DP]; ll += slot[JOB + w * RES + DP + 1]; }
+        }
+        FORV dbf[i] = xtg(jdx[i]);                  // (the shortcut reuses the slot for the next job: fetch first)
+        if (fast_ok) {
+            const double t = slot[lane == LA ? DP : (lane < DP ? lane : 0)];
+            const double pr2 = laplace ? (double)((vq2 > 0) - (vq2 < 0)) : vq2;
+            const double g1 = -vo1 + t, g2 = t * vex3 - pr2, g3 = -vo3 + t * vq2 * vex3;
+            // second half of this leapfrog, first half of the next one (the loop top's formulas, element by element)
+            const double fp1 = vp1 + 0.5 * eps_l * g1, fp2 = vp2 + 0.5 * eps_l * g2, fp3 = vp3 + 0.5 * eps_l * g3;
+            vp1 = fp1 + 0.5 * eps_l * g1; vp2 = fp2 + 0.5 * eps_l * g2; vp3 = fp3 + 0.5 * eps_l * g3;
+            vq1 = vq1 + eps_l * vm1 * vp1; vq2 = vq2 + eps_l * vm2 * vp2; vq3 = vq3 + eps_l * vm3 * vp3;
+            vex3 = exp_d(vq3);
+            const double ba = vq1 + vq2 * vex3;
+            double *job = slot + JOB;
+            if (lane < DP) job[1 + lane] = ba;
+            if (lane == LA) job[0] = ba;
+            ++seq;
+            duo_publish(f_job, seq);
+            job_eps = eps_l;
+            fast_pub = true;
+            __builtin_amdgcn_s_setprio(EPX_PRIO_S_BG);  // the row waves are off again: what follows has their whole pass
+        }
+        da = uniform_d(da); ll = uniform_d(ll);
+        // the parts of the chain rule that only need the position (cross-lane gathers)
         V g_etbq, g_sbj;
         FORV { g_etbq.v[i] = 0.0; g_sbj.v[i] = 0.0; }
         if (model == 2) {
@@ -483,30 +563,12 @@ k_nuts_duo(NutsArgs a) {
             FORV { const int e = lane + 64 * i; const int j = e < 2 + D ? e - 2 : (e < d ? e - 2 - D : e - d - 1);
                    g_etbq.v[i] = gatherV(sq, d + 1 + j); g_sbj.v[i] = gatherV(eq, 2 + D + j); }
         }
-
-        STAMP(2);
-        // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
-        for (int w = 0; w < RW; ++w) {
-            const int got = duo_wait(f_res + w, seq);
-            if (got != seq) bail = 1;
-        }
-        STAMP(3);
-        __builtin_amdgcn_s_setprio(3);              // chain rule, half kick, drift, publish: the row waves wait for it
-        if (bail) break;
-        double da, ll;
-        if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
-        else {
-            da = 0.0; ll = 0.0;
-#pragma unroll
-            for (int w = 0; w < RW; ++w) { da += slot[JOB + w * RES + DP]; ll += slot[JOB + w * RES + DP + 1]; }
-        }
-        da = uniform_d(da); ll = uniform_d(ll);
         double lpt = 0.0;
         {
             double dot = 0.0;
             if (model == 1) {
                 double tsum = 0.0;
-                FORV { const int e = lane + 64 * i; const double t2 = xtg(jdx[i]); if (e >= 3 && e < P) tsum += t2 * sq.v[i]; }
+                FORV { const int e = lane + 64 * i; const double t2 = dbf[i]; if (e >= 3 && e < P) tsum += t2 * sq.v[i]; }
                 dot = wave_sum(tsum);
             }
             const double c_da = da, c_sa = da * eta * sa, c_eta = da * sa;
@@ -522,7 +584,7 @@ k_nuts_duo(NutsArgs a) {
                 const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;    // d/dq of the N(0,1)/Laplace term
                 const double g_eta = c_eta - pr;
                 double add = 0.0, g_etb = 0.0;
-                const double db = xtg(jdx[i]);
+                const double db = dbf[i];
                 if (model == 0) {
                     add = (e >= 1 && e <= D) ? db : add;
                     add = e == 0 ? c_sa : add;
