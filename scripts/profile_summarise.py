@@ -102,6 +102,7 @@ for name in ('c2', 'c3', 'stream'):
             summary['traffic_over_algorithmic'] = summary['hbm_bytes_per_launch_corrected'] / summary['algorithmic_bytes_per_launch']
         # the bench line was printed before these passes ran: its traffic field is (re)filled from them
         roof['traffic'] = summary['hbm_bytes_per_launch_corrected']
+        roof['traffic_source'] = 'profiles/%s_%s_pmc_hbm.json (this capture)' % (tag, name)
         open(os.path.join(ROOT, 'profiles', '%s_%s_bench.json' % (tag, name)), 'w').write(json.dumps(bench) + '\n')
     json.dump(summary, open(os.path.join(ROOT, 'profiles', '%s_%s_pmc_hbm.json' % (tag, name)), 'w'), indent=1)
     print(name, json.dumps({k: summary.get(k) for k in ('timed_launches', 'hbm_bytes_per_launch_corrected', 'bench_launch_ms', 'launch_ms_pmc_passes', 'algorithmic_bytes_per_launch')}))
