@@ -170,6 +170,8 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max);
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream);
 size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max);
 bool nuts_duo_has(int cpb, int rw, int dp, int nv);
+// doubles per level of a chain's tree stack: (rho, p_sharp of the left end) of a pending left sibling
+constexpr int nuts_stack_record(int nv) { return 2 * nv * 64; }
 size_t nuts_resident_chain_doubles(int nv, int max_depth);
 
 // streaming variant (nuts_stream.hip): one workgroup per site, chains in lock step, X through

@@ -53,7 +53,7 @@ k_nuts(NutsArgs a) {
     constexpr int SPR = DP / 2;                       // 16-B slots per row
     constexpr int RPL = DP >= 32 ? 1 : 32 / DP;       // rows per 256-B bank line
     constexpr int XREC = 64 * (1 + NV) + 2;           // per-wave exchange record (doubles)
-    constexpr int SREC = 4 * NV * 64 + 2;             // per-level stack record (doubles)
+    constexpr int SREC = nuts_stack_record(NV);       // per-level stack record (doubles)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int team = wave / WPC, wt = wave % WPC;
@@ -111,8 +111,8 @@ k_nuts(NutsArgs a) {
 
     // ------------------------------------------------------------- state
     V mu, inv_e, qs, gs, zq, zp, zg, pq, pp, pg, mq, mp, mg, rho, psp, psm;
-    V n_rho, n_psl, n_pq, n_pg, psr, wmean, wm2;
-    double lps = 0, zlp = 0, plp = 0, mlp = 0, n_key = 0, n_plp = 0;
+    V n_rho, n_psl, bq, bg, psr, wmean, wm2;
+    double lps = 0, zlp = 0, plp = 0, mlp = 0, b_key = 0, b_plp = 0;
     FORV {
         const int e = lane + 64 * i;
         mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
@@ -120,7 +120,7 @@ k_nuts(NutsArgs a) {
         wmean.v[i] = 0.0; wm2.v[i] = 0.0;
         gs.v[i] = 0; zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
         mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
-        n_rho.v[i] = 0; n_psl.v[i] = 0; n_pq.v[i] = 0; n_pg.v[i] = 0; psr.v[i] = 0;
+        n_rho.v[i] = 0; n_psl.v[i] = 0; bq.v[i] = 0; bg.v[i] = 0; psr.v[i] = 0;
     }
     // initial position (method.py:159 init / :404-406 init_prev)
     {
@@ -292,7 +292,7 @@ k_nuts_spec(NutsArgs a) {
     constexpr int SPR = DP / 2;
     constexpr int RPL = DP >= 32 ? 1 : 32 / DP;
     constexpr int XREC = 64 * (1 + NV) + 2;
-    constexpr int SREC = 4 * NV * 64 + 2;
+    constexpr int SREC = nuts_stack_record(NV);
     constexpr int MREC = 3 * NV * 64 + 4 + 64;        // mailbox: q, p, grad, ll, -, generation, -, per-lane lp terms
     constexpr int CREC = 4 * NV * 64 + 4;             // control: q, p, grad, metric, eps_l, command, stamp
 
@@ -442,10 +442,10 @@ k_nuts_spec(NutsArgs a) {
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
-    V qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, sent_e, in_q, in_p, in_g;
-    double lps = 0, plp = 0, mlp = 0;
+    V qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, bq, bg, sent_e, in_q, in_p, in_g;
+    double lps = 0, plp = 0, mlp = 0, b_key = 0, b_plp = 0;
     FORV {
-        wmean.v[i] = 0.0; wm2.v[i] = 0.0; gs.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
+        bq.v[i] = 0; bg.v[i] = 0; wmean.v[i] = 0.0; wm2.v[i] = 0.0; gs.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
         mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
     }
     {
@@ -552,8 +552,7 @@ k_nuts_spec(NutsArgs a) {
         zlp = lpt + m[3 * NV * 64];
         const double kin = 0.5 * ks;
         ngrad += 1.0;
-        V n_rho, n_psl, n_pq, n_pg, psr;
-        double n_key = 0, n_plp = 0;
+        V n_rho, n_psl, psr;
 #define EPX_CHAIN_EXIT { post(s, SPEC_EXIT); __syncthreads(); break; }
 #define EPX_DBG_EXIT { post(s, SPEC_EXIT); __syncthreads(); return; }
 #define STAMP_LEAF do { } while (0)
@@ -619,7 +618,7 @@ size_t nuts_lds_layout(NutsArgs &a, int wpc, int dp, int n_max) {
     const size_t om = (size_t)a.d * a.d * 8;
     a.om_in_lds = 0; a.off_Om = (int)off;
     if (off + om <= cap) { a.om_in_lds = 1; off += om; off = (off + 15) & ~(size_t)15; }
-    const size_t stack = (size_t)a.cpb * a.max_depth * (4 * nv * 64 + 2) * 8;
+    const size_t stack = (size_t)a.cpb * a.max_depth * nuts_stack_record(nv) * 8;
     a.stack_in_lds = 0; a.off_stack = (int)off;
     if (a.om_in_lds && off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
     if (wpc > 1 && !a.stack_in_lds && a.om_in_lds) {      // layout 2 is built for "both" or "neither"

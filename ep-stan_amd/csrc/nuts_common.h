@@ -31,15 +31,18 @@ __device__ inline double elemU(const Vec<NV> &x, int e) {
 // b[e]): for the vectors of the tree bookkeeping that change once per subtree or per transition.  `b`
 // is wave-uniform, so every access is `saddr + lane * 8 + immediate`.
 struct GRef {
-    double *p;
-    __device__ operator double() const { return *p; }
-    __device__ const GRef &operator=(double x) const { *p = x; return *this; }
-    __device__ const GRef &operator=(const GRef &o) const { const double x = *o.p; *p = x; return *this; }
-    __device__ const GRef &operator+=(double x) const { *p = *p + x; return *this; }
+    double *p; bool ok;       // elements beyond the vector's length are 0 and not stored (fewer cache lines per vector)
+    __device__ operator double() const { return ok ? *p : 0.0; }
+    __device__ const GRef &operator=(double x) const { if (ok) *p = x; return *this; }
+    __device__ const GRef &operator=(const GRef &o) const { const double x = o; if (ok) *p = x; return *this; }
+    __device__ const GRef &operator+=(double x) const { if (ok) *p = *p + x; return *this; }
 };
-struct GIdx { double *b; int lane; __device__ GRef operator[](int i) const { return GRef{b + (lane + 64 * i)}; } };
+struct GIdx {
+    double *b; int lane, len;
+    __device__ GRef operator[](int i) const { return GRef{b + (lane + 64 * i), lane + 64 * i < len}; }
+};
 struct GVec { GIdx v; };
-enum { GV_QS, GV_GS, GV_PQ, GV_PP, GV_PG, GV_MQ, GV_MP, GV_MG, GV_RHO, GV_PSP, GV_PSM, GV_WMEAN, GV_WM2, GV_COUNT };
+enum { GV_QS, GV_GS, GV_PQ, GV_PP, GV_PG, GV_MQ, GV_MP, GV_MG, GV_RHO, GV_PSP, GV_PSM, GV_WMEAN, GV_WM2, GV_BQ, GV_BG, GV_COUNT };
 
 __device__ inline double *uniform_ptr(double *p) {
     const unsigned long long u = (unsigned long long)p;

@@ -80,7 +80,7 @@ k_nuts_duo(NutsArgs a) {
     constexpr int LOG = Log2<DP>::v;
     constexpr int SPR = DP / 2;                       // 16-B slots per row
     constexpr int RPL = DP >= 32 ? 1 : 32 / DP;       // rows per 256-B bank line
-    constexpr int SREC = 4 * NV * 64 + 2;             // per-level stack record (doubles)
+    constexpr int SREC = nuts_stack_record(NV);       // per-level stack record (doubles)
     constexpr int RES = DP + 2;                       // result of a row wave: X'g (DP), sum g, log-lik
     constexpr int JOB = RW == 1 ? 0 : DP + 2;         // job (alpha, beta): its own slot, or (RW == 1) the result's
 
@@ -246,17 +246,18 @@ k_nuts_duo(NutsArgs a) {
     // at two registers per vector they are 52 VGPRs that the state wave spilled to scratch
     using CV = typename std::conditional<COLD, GVec, V>::type;
     V mu, inv_e, zq, zp, zg;
-    CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;
+    CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, bq, bg;
     double *cold = COLD ? stk_g + g_stack : nullptr;
     auto bind = [&](CV &x, int which, int ln) {
-        if constexpr (COLD) { x.v.b = cold + (size_t)which * NV * 64; x.v.lane = ln; }
+        if constexpr (COLD) { x.v.b = cold + (size_t)which * NV * 64; x.v.lane = ln; x.v.len = P; }
     };
 #define EPX_BIND_COLD(ln)                                                                              \
     bind(qs, GV_QS, ln); bind(gs, GV_GS, ln); bind(pq, GV_PQ, ln); bind(pp, GV_PP, ln); bind(pg, GV_PG, ln); \
     bind(mq, GV_MQ, ln); bind(mp, GV_MP, ln); bind(mg, GV_MG, ln); bind(rho, GV_RHO, ln);                 \
-    bind(psp, GV_PSP, ln); bind(psm, GV_PSM, ln); bind(wmean, GV_WMEAN, ln); bind(wm2, GV_WM2, ln)
+    bind(psp, GV_PSP, ln); bind(psm, GV_PSM, ln); bind(wmean, GV_WMEAN, ln); bind(wm2, GV_WM2, ln); \
+    bind(bq, GV_BQ, ln); bind(bg, GV_BG, ln)
     EPX_BIND_COLD(lane);
-    double lps = 0, zlp = 0, plp = 0, mlp = 0;
+    double lps = 0, zlp = 0, plp = 0, mlp = 0, b_key = 0, b_plp = 0;
     FORV {
         const int e = lane + 64 * i;
         mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
@@ -443,8 +444,7 @@ k_nuts_duo(NutsArgs a) {
             const double kin = 0.5 * f_ks;
             const int fwd_was = fwd;
             ngrad += 1.0;
-            V n_rho, n_psl, n_pq, n_pg, psr;
-            double n_key = 0, n_plp = 0;
+            V n_rho, n_psl, psr;
             int leave = 0, parked = 1;
             do {
 #define EPX_CHAIN_EXIT { leave = 1; parked = 0; break; }
@@ -672,7 +672,7 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     off = (off + 15) & ~(size_t)15;
     a.om_in_lds = 1;
     const size_t cap = 160 * 1024;
-    const size_t stack = (size_t)cpb * a.max_depth * (4 * nv * 64 + 2) * 8;
+    const size_t stack = (size_t)cpb * a.max_depth * nuts_stack_record(nv) * 8;
     a.stack_in_lds = 0; a.off_stack = (int)off;
     if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
     a.lds_bytes = (int)off;
@@ -681,7 +681,7 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
 
 // doubles of global memory per chain of the resident layouts: tree stack + cold store (NutsArgs::stack)
 size_t nuts_resident_chain_doubles(int nv, int max_depth) {
-    return (size_t)max_depth * (4 * nv * 64 + 2) + (size_t)GV_COUNT * nv * 64;
+    return (size_t)max_depth * nuts_stack_record(nv) + (size_t)GV_COUNT * nv * 64;
 }
 
 template <int NV, int DP, int CPB, int RW>

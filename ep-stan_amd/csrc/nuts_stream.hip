@@ -55,7 +55,7 @@ struct ColdRef {
 // b is wave-uniform (scalar registers), so every access is `saddr + lane*8 + immediate`
 struct ColdIdx { double *b; int lane; __device__ ColdRef operator[](int i) const { return ColdRef{b + (lane + 64 * i)}; } };
 struct ColdV { ColdIdx v; };
-enum { CV_QS, CV_GS, CV_PQ, CV_PP, CV_PG, CV_MQ, CV_MP, CV_MG, CV_RHO, CV_PSP, CV_PSM, CV_WMEAN, CV_WM2, CV_COUNT };
+enum { CV_QS, CV_GS, CV_PQ, CV_PP, CV_PG, CV_MQ, CV_MP, CV_MG, CV_RHO, CV_PSP, CV_PSM, CV_WMEAN, CV_WM2, CV_BQ, CV_BG, CV_COUNT };
 
 enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 #define MODE_INIT SMODE_INIT
@@ -73,7 +73,7 @@ k_nuts_stream(NutsArgs a) {
     constexpr int NT = RES ? 256 : STREAM_THREADS;
     // register vectors when they fit (NV <= 2: 23 x 4 VGPRs), cold store otherwise
     using CV = typename std::conditional<(RES && NV <= 2), VecS<NV>, ColdV>::type;
-    constexpr int SREC = 4 * NV * 64 + 2;       // per-level stack record (doubles)
+    constexpr int SREC = nuts_stack_record(NV); // per-level stack record (doubles)
     constexpr int PMAX = 64 * NV;
 
     const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
@@ -175,16 +175,17 @@ k_nuts_stream(NutsArgs a) {
 
     // ------------------------------------------------------------- state (as in k_nuts)
     V inv_e, zq, zp, zg;                                                // registers, live across leapfrogs
-    CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2;       // cold store (or registers, see CV)
+    CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, bq, bg;   // cold store (or registers, see CV)
     auto bind = [&](CV &x, int which, int ln) {
         if constexpr (std::is_same<CV, ColdV>::value) { x.v.b = cold + which * PMAX; x.v.lane = ln; }
     };
 #define EPX_BIND_COLD(ln)                                                                              \
     bind(qs, CV_QS, ln); bind(gs, CV_GS, ln); bind(pq, CV_PQ, ln); bind(pp, CV_PP, ln); bind(pg, CV_PG, ln); \
     bind(mq, CV_MQ, ln); bind(mp, CV_MP, ln); bind(mg, CV_MG, ln); bind(rho, CV_RHO, ln);                 \
-    bind(psp, CV_PSP, ln); bind(psm, CV_PSM, ln); bind(wmean, CV_WMEAN, ln); bind(wm2, CV_WM2, ln)
+    bind(psp, CV_PSP, ln); bind(psm, CV_PSM, ln); bind(wmean, CV_WMEAN, ln); bind(wm2, CV_WM2, ln); \
+    bind(bq, CV_BQ, ln); bind(bg, CV_BG, ln)
     EPX_BIND_COLD(lane0);
-    double lps = 0, zlp = 0, plp = 0, mlp = 0;
+    double lps = 0, zlp = 0, plp = 0, mlp = 0, b_key = 0, b_plp = 0;
     FORV {
         inv_e.v[i] = 1.0;
         zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0;
@@ -483,8 +484,7 @@ k_nuts_stream(NutsArgs a) {
 
         // the new-subtree vectors never outlive one iteration (a leaf is merged, then parked on
         // the stack or consumed), so they are iteration-local: nothing to keep across the row pass
-        V n_rho, n_psl, n_pq, n_pg, psr;
-        double n_key = 0, n_plp = 0;
+        V n_rho, n_psl, psr;
 #define EPX_CHAIN_EXIT { finished = 1; eps_l = 0.0; continue; }
 #define EPX_DBG_EXIT { finished = 1; eps_l = 0.0; continue; }
 #define STAMP_LEAF STAMP(6)
@@ -539,7 +539,7 @@ size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int n
 }
 // doubles of global memory per chain: tree stack + cold store
 size_t nuts_stream_chain_doubles(int nv, int max_depth) {
-    return (size_t)max_depth * (4 * (size_t)nv * 64 + 2) + (size_t)CV_COUNT * 64 * nv;
+    return (size_t)max_depth * nuts_stack_record(nv) + (size_t)CV_COUNT * 64 * nv;
 }
 
 template <int NV, int DPB, bool RES>
