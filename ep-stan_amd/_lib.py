@@ -15,6 +15,8 @@ c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
 c_int_p = ctypes.POINTER(ctypes.c_int)
 COMM_ID_BYTES = 128          # EPX_COMM_ID_BYTES
 OP_SUM, OP_MIN, OP_MAX = 0, 1, 2
+# epx_host_allreduce_fn (include/epx.h): int fn(double *buf, long long n, int op, void *user)
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_double_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p)
 
 
 class SamplerOpts(ctypes.Structure):
@@ -86,6 +88,7 @@ SIGNATURES = {
                                       c_double_p]),
     'epx_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'epx_comm_init_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, HOST_ALLREDUCE_FN, ctypes.c_void_p]),
     'epx_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_size': (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_int_p]),
     'epx_comm_allreduce': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int]),

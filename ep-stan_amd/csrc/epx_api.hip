@@ -260,7 +260,7 @@ static int ctx_create(int device, int model, int K_local, int D, const int64_t *
 int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    if (c->comm) (void)epx_comm_destroy(c);
+    if (c->comm || c->comm_ext) (void)epx_comm_destroy(c);
     void *ptrs[] = {c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
@@ -1004,7 +1004,8 @@ int epx_update_trial(epx_ctx *c, double df, int reduce_sums, int site_base, doub
                      int64_t *first_bad, double *S, double *m) {
     CTX(c);
     if (n_sum < 0 || n_sum > STAT_CAP || n_max < 0 || n_max > STAT_CAP) return fail("at most %d statistics of a kind", STAT_CAP);
-    const int nr = c->comm ? c->comm_size : 1, rank = c->comm ? c->comm_rank : 0;
+    const bool bound = c->comm || c->comm_ext;
+    const int nr = bound ? c->comm_size : 1, rank = bound ? c->comm_rank : 0;
     const int len = 2 * (c->d * c->d + c->d);
     const int next = n_sum + n_max * nr;
     if (next + 3 > PACKED_EXTRA) return fail("too many ranks (%d) for the statistics block", nr);

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <vector>
 
 #include "epx_ctx.h"
 
@@ -91,8 +92,28 @@ int epx_comm_init(epx_ctx *c, const void *id, int rank, int nranks) {
     return 0;
 }
 
+int epx_comm_init_host(epx_ctx *c, int rank, int nranks, epx_host_allreduce_fn fn, void *user) {
+    CTX(c);
+    if (c->comm || c->comm_ext) return fail("the context already has a communicator");
+    if (!fn || nranks < 1 || rank < 0 || rank >= nranks) return fail("bad communicator arguments (rank %d of %d)", rank, nranks);
+    c->comm_ext = fn; c->comm_ext_user = user; c->comm_rank = rank; c->comm_size = nranks;
+    return 0;
+}
+
+// all-reduce through the caller's host transport: device -> pinned-less host copy, callback, back; in stream order
+static int host_allreduce_dev(epx_ctx *c, double *buf, size_t n, int op) {
+    std::vector<double> h(n);
+    HIPCHK(hipMemcpyAsync(h.data(), buf, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->comm_ext(h.data(), (long long)n, op, c->comm_ext_user)) return fail("the host transport of the communicator failed");
+    HIPCHK(hipMemcpyAsync(buf, h.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));        // `h` goes away
+    return 0;
+}
+
 int epx_comm_destroy(epx_ctx *c) {
     if (!c) return fail("null context");
+    if (c->comm_ext) { c->comm_ext = nullptr; c->comm_ext_user = nullptr; c->comm_size = 0; c->comm_rank = 0; return 0; }
     if (!c->comm) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -106,13 +127,15 @@ int epx_comm_size(epx_ctx *c, int *rank, int *nranks) {
     if (!c) return fail("null context");
     int n = 1;
     if (c->comm) NCCLCHK(g_rccl.CommCount(static_cast<ncclComm_t>(c->comm), &n));
-    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    if (c->comm_ext) n = c->comm_size;
+    if (rank) *rank = (c->comm || c->comm_ext) ? c->comm_rank : 0;
     if (nranks) *nranks = n;
     return 0;
 }
 
 // used by epx_api.hip: all-reduce of a device buffer in stream order (no synchronisation)
 int epx_comm_allreduce_dev(epx_ctx *c, double *buf, size_t n, int op) {
+    if (c->comm_ext) return host_allreduce_dev(c, buf, n, op);
     if (!c->comm) return 0;
     const ncclRedOp_t ops[] = {ncclSum, ncclMin, ncclMax};
     NCCLCHK(g_rccl.AllReduce(buf, buf, n, ncclDouble, ops[op], static_cast<ncclComm_t>(c->comm), c->stream));
@@ -123,6 +146,10 @@ int epx_comm_allreduce(epx_ctx *c, double *buf, int n, int op) {
     CTX(c);
     if (!buf || n < 1) return fail("bad buffer");
     if (op < EPX_OP_SUM || op > EPX_OP_MAX) return fail("unknown reduction %d", op);
+    if (c->comm_ext) {
+        if (c->comm_ext(buf, n, op, c->comm_ext_user)) return fail("the host transport of the communicator failed");
+        return 0;
+    }
     if (!c->comm) return 0;                         // one rank: identity
     if (stage(c, (size_t)n)) return -1;
     const ncclRedOp_t ops[] = {ncclSum, ncclMin, ncclMax};
@@ -137,6 +164,13 @@ int epx_comm_allreduce(epx_ctx *c, double *buf, int n, int op) {
 int epx_comm_allgather(epx_ctx *c, const double *in, int n, double *out) {
     CTX(c);
     if (!in || !out || n < 1) return fail("bad buffer");
+    if (c->comm_ext) {
+        // every rank's block in its own slot, zeros elsewhere: the sum over the ranks is the gather
+        memset(out, 0, (size_t)n * c->comm_size * 8);
+        memcpy(out + (size_t)n * c->comm_rank, in, (size_t)n * 8);
+        if (c->comm_ext(out, (long long)n * c->comm_size, EPX_OP_SUM, c->comm_ext_user)) return fail("the host transport of the communicator failed");
+        return 0;
+    }
     if (!c->comm) { memcpy(out, in, (size_t)n * 8); return 0; }
     const size_t tot = (size_t)n * (1 + c->comm_size);
     if (stage(c, tot)) return -1;

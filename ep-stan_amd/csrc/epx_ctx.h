@@ -89,6 +89,8 @@ struct epx_ctx {
     // in-library RCCL binding (epx_comm.hip); comm == nullptr: single rank
     void *comm;               // ncclComm_t
     int comm_rank, comm_size;
+    int (*comm_ext)(double *, long long, int, void *);   // host transport given by the caller (epx_comm_init_host) ...
+    void *comm_ext_user;                                 // ... used instead of RCCL when set
     double *comm_stage;       // device staging of the small host-side collectives
     size_t comm_stage_n;
     int *err_flag;            // device word the sampler kernels set when a hand-off spin gives up

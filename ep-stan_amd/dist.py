@@ -171,6 +171,41 @@ class EpxComm(object):
         self._reduce(np.zeros(1), _lib.OP_SUM)
 
 
+class HostComm(EpxComm):
+    """The library's collectives over a HOST transport (epx_comm_init_host): `Master` runs exactly the code of
+    the RCCL case -- the fused update with its per-rank statistics slots, site offsets and flag reductions -- and
+    every reduction is handed to `transport`, a TorchComm (gloo, MPI-backed groups, ...) or any object with
+    `rank`, `world` and `reduce(array, op)` reducing a float64 array in place.  For nodes whose GPUs have no
+    RCCL peer path, and for the world-size-2 tests on one GPU."""
+
+    def __init__(self, transport):
+        self.transport = transport
+        self.rank, self.world = int(transport.rank), int(transport.world)
+        self.engine = None
+        self._cb = None
+
+    def bind(self, engine):
+        import ctypes
+        lib = _lib.load()
+        if not hasattr(engine, 'ctx'):
+            raise TypeError('HostComm needs the HIP engine (a context of libepx.so)')
+        tr = self.transport
+
+        def reduce_cb(buf, n, op, _user):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(int(n),))
+                tr.reduce(a, int(op))
+                return 0
+            except Exception:                      # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _lib.HOST_ALLREDUCE_FN(reduce_cb)          # keep the thunk alive as long as the context
+        _lib.check(lib.epx_comm_init_host(engine.ctx, self.rank, self.world, self._cb, None))
+        self.engine = engine
+        return self
+
+
 def _recv_exact(conn, n):
     buf = b''
     while len(buf) < n:
@@ -228,3 +263,10 @@ class TorchComm(object):
 
     def barrier(self):
         self.dist.barrier(group=self.group)
+
+    def reduce(self, a, op):
+        """In-place reduction of a float64 array (the transport interface of HostComm)."""
+        t = self._small(a)
+        ops = {_lib.OP_SUM: self.dist.ReduceOp.SUM, _lib.OP_MIN: self.dist.ReduceOp.MIN, _lib.OP_MAX: self.dist.ReduceOp.MAX}
+        self.dist.all_reduce(t, op=ops[op], group=self.group)
+        a[...] = t.cpu().numpy()

@@ -253,6 +253,12 @@ int epx_mix_sums(epx_ctx *ctx, double *out);
 enum epx_op { EPX_OP_SUM = 0, EPX_OP_MIN = 1, EPX_OP_MAX = 2 };
 int epx_comm_unique_id(void *id_out);
 int epx_comm_init(epx_ctx *ctx, const void *id, int rank, int nranks);
+/* The same binding over a transport of the caller's (an MPI / gloo / socket all-reduce on HOST memory) for nodes
+ * without RCCL peer access and for tests: `fn(buf, n, op, user)` reduces buf[n] over the ranks in place (op: enum
+ * epx_op) and returns 0.  Every library collective then stages through the host: same results, one extra
+ * synchronisation per collective. */
+typedef int (*epx_host_allreduce_fn)(double *buf, long long n, int op, void *user);
+int epx_comm_init_host(epx_ctx *ctx, int rank, int nranks, epx_host_allreduce_fn fn, void *user);
 int epx_comm_destroy(epx_ctx *ctx);
 /* rank and number of ranks of the context's communicator as RCCL reports them (0 of 1 without one) */
 int epx_comm_size(epx_ctx *ctx, int *rank, int *nranks);

@@ -5,6 +5,9 @@ and the host-buffer transport (dist.TorchComm over gloo) in front of the HIP eng
     stream order and must leave every result bit-equal to the single-process path;
   * two ranks SHARING device 0 over gloo drive HipEngine's host-buffer branch (RCCL itself
     refuses two ranks on one device);
+  * the same two ranks with dist.HostComm: the library's OWN multi-rank code (epx_update_trial with its
+    per-rank statistics slots, site offsets and flag reductions -- what runs over RCCL on 8 GPUs) with every
+    collective handed to gloo through epx_comm_init_host;
   * two ranks over RCCL need two devices: skipped on a 1-GPU box.
 References: /root/reference/epstan/method.py:1073-1074 (the reduction), :1145 (the flags)."""
 
@@ -101,10 +104,13 @@ def _worker(rank, world, port, mode, outdir, transport):
             sys.path.insert(0, p)
     from epstan_amd import dist, models
     from epstan_amd.method import Master
-    if transport == 'gloo':
+    if transport in ('gloo', 'host'):
         import torch.distributed as tdist
         tdist.init_process_group('gloo', rank=rank, world_size=world)
         comm = dist.TorchComm()
+        if transport == 'host':
+            # the library's own multi-rank code (fused update, per-rank slots, site offsets) over gloo
+            comm = dist.HostComm(comm)
         device = 0                                     # both ranks share the one GPU
     else:
         comm = dist.EpxComm(rank=rank, world=world, port=port)
@@ -129,12 +135,14 @@ def _worker(rank, world, port, mode, outdir, transport):
         info, (m_s, S_s), an = M.run(1, verbose=False, return_analytics=True, seed=3)
         np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
                  klo=M.k_lo, khi=M.k_hi, msteps=an[1], mrhats=an[2])
+    if transport == 'host':
+        assert M._fused and comm.size() == (rank, world)
     comm.barrier()
-    if transport == 'gloo':
+    if transport != 'gloo':
+        comm.close()
+    if transport in ('gloo', 'host'):
         import torch.distributed as tdist
         tdist.destroy_process_group()
-    else:
-        comm.close()
 
 
 def _spawn(mode, tmp_path, transport, world=2):
@@ -146,7 +154,7 @@ def _spawn(mode, tmp_path, transport, world=2):
 
 def _transports():
     from epstan_amd import _lib
-    out = [pytest.param('gloo', id='gloo-shared-gpu')]
+    out = [pytest.param('gloo', id='gloo-shared-gpu'), pytest.param('host', id='library-collectives-over-gloo-shared-gpu')]
     two = _lib.device_count() >= 2
     out.append(pytest.param('rccl', id='rccl-2gpu',
                             marks=pytest.mark.skipif(not two, reason='RCCL needs one device per rank')))
