@@ -528,10 +528,12 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // site (up to 4 chains), the default for batches that fill the chip; 6 = one workgroup per chain with 4 row waves
     if (!lock && !c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
         (layout == 5 || layout == 6 || (layout == 0 && many))) {
-        const int cpb = layout == 6 ? 1 : 4, rw = layout == 6 ? 4 : 1;
+        const int cpb = layout == 6 ? 1 : 4, rw = layout == 6 ? 2 : 1;
         NutsArgs t = a;
         const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
-        const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP && (c->n_max + 64 * rw - 1) / (64 * rw) <= 64;
+        // (layout 6: one chain per workgroup, the bookkeeping wave's stack lives in LDS or the layout is not used)
+        const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP && (c->n_max + 64 * rw - 1) / (64 * rw) <= 64 &&
+                          (layout != 6 || t.stack_in_lds);
         if (fits) {
             a = t;
             a.err = c->err_flag;

@@ -37,12 +37,22 @@ namespace epx {
 #define EPX_PRIO_S_BG 0
 #define EPX_PRIO_S_CRIT 2
 #endif
-enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23 };
+enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23, DUO_NO_MORE = 1 << 30 };
+enum { DUO_RESTART = 1, DUO_LEAVE = 2 };          // commands of the bookkeeping wave (CPB == 1)
 
 __device__ inline int duo_wait(const volatile int *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
         const int v = __builtin_amdgcn_readfirstlane(*flag);
         if (v == want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return DUO_TIMEOUT;
+}
+// for counters that only grow (acknowledgements, generations)
+__device__ inline int duo_wait_ge(const volatile int *flag, int want) {
+    for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+        const int v = __builtin_amdgcn_readfirstlane(*flag);
+        if (v >= want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
         __builtin_amdgcn_s_sleep(1);
     }
     return DUO_TIMEOUT;
@@ -73,7 +83,7 @@ __device__ inline void duo_publish(volatile int *flag, int v) {
 #endif
 
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
-__global__ void __launch_bounds__(64 * CPB * (1 + RW))
+__global__ void __launch_bounds__(64 * (CPB * (1 + RW) + (CPB == 1 ? 1 : 0)))
 k_nuts_duo(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     using V = Vec<NV>;
@@ -83,12 +93,21 @@ k_nuts_duo(NutsArgs a) {
     constexpr int SREC = nuts_stack_record(NV);       // per-level stack record (doubles)
     constexpr int RES = DP + 2;                       // result of a row wave: X'g (DP), sum g, log-lik
     constexpr int JOB = RW == 1 ? 0 : DP + 2;         // job (alpha, beta): its own slot, or (RW == 1) the result's
+    // One chain per workgroup (CPB == 1): the tree bookkeeping gets a wave of its own (BK), as in k_nuts_spec --
+    // the state wave integrates on speculatively and hands every finished state over through a two-entry mailbox;
+    // BK answers with a control record only when the trajectory continues elsewhere (other tree end, new
+    // transition, step-size trial): generation-numbered, states of an old generation are dropped.
+    constexpr bool BKW = CPB == 1;
+    constexpr int MREC = 3 * NV * 64 + 4 + 64;        // mailbox entry: q, p, grad, ll, -, generation, -, per-lane lp terms
+    constexpr int CREC = 4 * NV * 64 + 4;             // control record: q, p, grad, metric, eps_l, command
+    constexpr int NFLAG = 1 + RW + (BKW ? 3 : 0);     // per chain: job, results, (mail, acknowledged, control generation)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // waves 0..CPB-1: state wave of chain c; then the row waves.  A workgroup's waves go to the SIMDs
     // round robin, so wave w and w + 4 share one: the row waves of chain c sit CPB waves behind the
     // state wave of chain c + 1 -- a chain that is the last one running keeps its two roles on different SIMDs
     const bool is_state = wave < CPB;
+    const bool is_bk = BKW && wave == CPB * (1 + RW);
     const int team = is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB;
     const int wr = is_state ? 0 : (wave - CPB) % RW;
     const int bps = (a.chains + CPB - 1) / CPB;
@@ -108,8 +127,12 @@ k_nuts_duo(NutsArgs a) {
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);        // [(pair p, row e)] -> (Om[e][2p], Om[e][2p+1])
     double *Ots = reinterpret_cast<double *>(smem + a.off_tail);      // [row r - 64][column], stride tstride
     double *slot = reinterpret_cast<double *>(smem + a.off_slot) + (size_t)team * a.slot_doubles;
-    volatile int *flags = reinterpret_cast<volatile int *>(smem + a.off_flag) + team * (1 + RW);
+    volatile int *flags = reinterpret_cast<volatile int *>(smem + a.off_flag) + team * NFLAG;
     volatile int *f_job = flags, *f_res = flags + 1;
+    volatile int *f_mail = flags + 1 + RW, *f_ack = f_mail + 1, *f_ctl = f_mail + 2;
+    double *mbox = reinterpret_cast<double *>(smem + a.off_spec);     // BKW: 2 x MREC, then 2 x CREC
+    double *ctrl = mbox + 2 * MREC;
+    (void)f_mail; (void)f_ack; (void)f_ctl; (void)mbox; (void)ctrl;
 
     // ---- stage the site: rows HBM -> LDS once per site update (as k_nuts), cavity precision re-laid
     {
@@ -140,12 +163,12 @@ k_nuts_duo(NutsArgs a) {
                 Ots[idx] = (r < tr && j < d) ? Om_g[(size_t)j * d + dm + r] : 0.0;
             }
         }
-        if (tid < CPB * (1 + RW)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
+        if (tid < CPB * NFLAG) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
     }
     __syncthreads();                                   // the only workgroup barrier of the kernel
     if (chain >= a.chains) return;
 
-    if (!is_state) {
+    if (!is_state && !is_bk) {
         // ================================================================= row wave
         // responses of this lane's rows as a bit mask (row of iteration `it`: wr*64 + lane + it*64*RW)
         unsigned long long ybits = 0;
@@ -336,6 +359,67 @@ k_nuts_duo(NutsArgs a) {
         sum_metro += me;
     };
 
+    int bail = 0;
+    if constexpr (BKW) {
+        if (is_bk) {
+            // ============================================================= bookkeeping wave (owns the chain)
+            V sent_e, in_q, in_p, in_g;
+            double sent_eps = 0.0;
+            int gen = 0;
+            // the integration state the state wave has to continue from; generation = number of records so far
+            auto post = [&](int cmd) {
+                double *cr = ctrl + ((gen + 1) & 1) * CREC;
+                FORV {
+                    cr[(0 * NV + i) * 64 + lane] = zq.v[i]; cr[(1 * NV + i) * 64 + lane] = zp.v[i];
+                    cr[(2 * NV + i) * 64 + lane] = zg.v[i]; cr[(3 * NV + i) * 64 + lane] = inv_e.v[i];
+                    sent_e.v[i] = inv_e.v[i];
+                }
+                if (lane == 0) { cr[4 * NV * 64] = eps_l; cr[4 * NV * 64 + 1] = (double)cmd; }
+                sent_eps = eps_l;
+                ++gen;
+                duo_publish(f_ctl, gen);
+            };
+            post(DUO_RESTART);                      // the initial point, eps_l = 0: the first "leapfrog" is its gradient
+            for (int mexp = 1;; ++mexp) {
+                const int got = duo_wait_ge(f_mail, mexp);
+                if (got < 0) { bail = 1; post(DUO_LEAVE); break; }       // the state wave gave up, or the wait timed out
+                const double *m = mbox + (mexp & 1) * MREC;
+                const int gen_m = (int)m[3 * NV * 64 + 2];
+                FORV {
+                    in_q.v[i] = m[(0 * NV + i) * 64 + lane]; in_p.v[i] = m[(1 * NV + i) * 64 + lane];
+                    in_g.v[i] = m[(2 * NV + i) * 64 + lane];
+                }
+                double lpt = m[3 * NV * 64 + 4 + lane];
+                const double ll_m = m[3 * NV * 64];
+                duo_publish(f_ack, mexp);           // the entry is in registers: the state wave may reuse it
+                if (gen_m != gen) continue;         // integrated past a change of state: dropped
+                FORV { zq.v[i] = in_q.v[i]; zp.v[i] = in_p.v[i]; zg.v[i] = in_g.v[i]; }
+                double ks = 0.0;
+                FORV ks += inv_e.v[i] * zp.v[i] * zp.v[i];
+                wave_sum2(lpt, ks);
+                zlp = lpt + ll_m;
+                const double kin = 0.5 * ks;
+                ngrad += 1.0;
+                V n_rho, n_psl, psr;
+#define EPX_CHAIN_EXIT { post(DUO_LEAVE); break; }
+#define EPX_DBG_EXIT { post(DUO_LEAVE); bail = 4; break; }
+#define STAMP_LEAF do { } while (0)
+#include "nuts_state_machine.inc"
+#undef STAMP_LEAF
+#undef EPX_CHAIN_EXIT
+#undef EPX_DBG_EXIT
+                // the state wave keeps integrating from the state it handed over; tell it only if that is no
+                // longer where (or how) the trajectory continues
+                int moved = (eps_l != sent_eps) ? 1 : 0;
+                FORV {
+                    moved |= (zq.v[i] != in_q.v[i]) | (zp.v[i] != in_p.v[i]) | (zg.v[i] != in_g.v[i]) | (inv_e.v[i] != sent_e.v[i]);
+                }
+                if (__any(moved)) post(DUO_RESTART);
+            }
+            *f_ack = DUO_NO_MORE;                   // whatever the state wave still hands over needs no answer
+        }
+    }
+
     // per element: column of X'g its chain-rule term reads, clamped into the slot
     int jdx[NV];
     FORV {
@@ -361,7 +445,8 @@ k_nuts_duo(NutsArgs a) {
     // (zq, zp, zg) holds the last finished leapfrog state; `pending`: its bookkeeping is still to run
     double f_lpt = 0.0, f_ks = 0.0, f_ll = 0.0;     // its log density / kinetic energy, not yet summed over the lanes
     bool pending = false;
-    int seq = 0, bail = 0;
+    int seq = 0, gen = 0, mseq = 0;
+    (void)gen; (void)mseq;
     const int lane0 = lane;
     // ---- the critical-path shortcut (m4b / m5b, one row wave).  (alpha, beta) of the NEXT position depend on
     // 3 (D + 1) of the P coordinates only, and the hierarchical structure is the same for every one of them:
@@ -374,7 +459,7 @@ k_nuts_duo(NutsArgs a) {
     // the job goes out, THEN the full vectors are brought up to date (same operations on the same values: the
     // view and the vectors agree bit for bit, and so do the draws with layout 1).
     constexpr int LA = 32;                              // the lane that carries alpha's triple (D <= 32)
-    const bool fast_ok = RW == 1 && model >= 3;
+    const bool fast_ok = model >= 3;
     const bool v_lane = lane0 < D || lane0 == LA;
     const int ve1 = !v_lane ? 0 : (lane0 == LA ? 0 : 2 + lane0);            // location:  mu_a | mu_b[j]
     const int ve2 = !v_lane ? 0 : (lane0 == LA ? d : d + 1 + lane0);        // raw:       eta  | etb[j]
@@ -384,13 +469,37 @@ k_nuts_duo(NutsArgs a) {
     double job_eps = 0.0;
     STAMP_INIT;
 
-    for (;;) {
+    for (; !is_bk;) {
         // `lane` is re-derived through an opaque move every leapfrog, otherwise the per-element index
         // arithmetic below is hoisted out of the loop and spilled (as in k_nuts_spec)
         int lane_v = lane0;
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
         EPX_BIND_COLD(lane);
+        if constexpr (BKW) {
+            // ---- the bookkeeping wave's word: a record of a new generation means "continue from here instead"
+            const int ctl = gen == 0 ? duo_wait_ge(f_ctl, 1) : __builtin_amdgcn_readfirstlane(*f_ctl);
+            if (ctl < 0) { bail = 1; break; }
+            if (ctl != gen) {
+                if (fast_pub) {                    // the job in flight continues a trajectory nobody wants: let it land
+                    for (int w = 0; w < RW; ++w) {
+                        const int got = duo_wait(f_res + w, seq);
+                        if (got != seq) bail = 1;
+                    }
+                    if (bail) break;
+                }
+                const double *cr = ctrl + (ctl & 1) * CREC;
+                FORV {
+                    zq.v[i] = cr[(0 * NV + i) * 64 + lane]; zp.v[i] = cr[(1 * NV + i) * 64 + lane];
+                    zg.v[i] = cr[(2 * NV + i) * 64 + lane]; inv_e.v[i] = cr[(3 * NV + i) * 64 + lane];
+                }
+                eps_l = cr[4 * NV * 64];
+                const int cmd = (int)cr[4 * NV * 64 + 1];
+                gen = ctl;
+                if (cmd == DUO_LEAVE) break;
+                fast_pub = false;
+            }
+        }
         // ---- first half of the leapfrog from (zq, zp, zg): speculative while `pending`.  When the shortcut has
         // already sent the job of this position, the full vectors are only needed AFTER the bookkeeping below
         // (which leaves (zq, zp, zg) alone unless it restarts the trajectory): computing them there keeps
@@ -437,7 +546,7 @@ k_nuts_duo(NutsArgs a) {
         STAMP(0);
 
         // ---- while they sweep the rows: the bookkeeping of the leapfrog that finished before this one
-        if (pending) {
+        if (!BKW && pending) {
             pending = false;
             wave_sum2(f_lpt, f_ks);                 // the two reductions only the bookkeeping needs: off the critical path
             zlp = f_lpt + f_ll;
@@ -534,7 +643,7 @@ k_nuts_duo(NutsArgs a) {
         }
         FORV dbf[i] = xtg(jdx[i]);                  // (the shortcut reuses the slot for the next job: fetch first)
         if (fast_ok) {
-            const double t = slot[lane == LA ? DP : (lane < DP ? lane : 0)];
+            const double t = xtg(lane == LA ? DP : (lane < DP ? lane : 0));     // lane LA: sum g (as `da` above)
             const double pr2 = laplace ? (double)((vq2 > 0) - (vq2 < 0)) : vq2;
             const double g1 = -vo1 + t, g2 = t * vex3 - pr2, g3 = -vo3 + t * vq2 * vex3;
             // second half of this leapfrog, first half of the next one (the loop top's formulas, element by element)
@@ -616,17 +725,46 @@ k_nuts_duo(NutsArgs a) {
         FORV { zq.v[i] = sq.v[i]; zp.v[i] = sp.v[i]; zg.v[i] = sg.v[i]; }
         f_lpt = lpt; f_ks = ks; f_ll = ll;
         pending = true;
+        if constexpr (BKW) {
+            // ---- hand the finished state to the bookkeeping wave (it is at most two states behind)
+            STAMP(4);
+            ++mseq;
+            if (mseq > 2) {
+                const int got = duo_wait_ge(f_ack, mseq - 2);
+                if (got < 0) { bail = 1; break; }
+            }
+            double *m = mbox + (mseq & 1) * MREC;
+            FORV {
+                m[(0 * NV + i) * 64 + lane] = sq.v[i]; m[(1 * NV + i) * 64 + lane] = sp.v[i];
+                m[(2 * NV + i) * 64 + lane] = sg.v[i];
+            }
+            m[3 * NV * 64 + 4 + lane] = lpt;
+            if (lane == 0) { m[3 * NV * 64] = ll; m[3 * NV * 64 + 2] = (double)gen; }
+            duo_publish(f_mail, mseq);
+            STAMP(1);                               // (diagnostic build: the hand-over is booked on the bookkeeping slot)
+        }
         STAMP(4);
     }
 #ifdef EPX_STAMPS
-    if (a.stamps && team == 0 && lane == 0) {
+    if (a.stamps && team == 0 && lane == 0 && is_state) {
         for (int i = 0; i < 5; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
         a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)seq;
     }
 #endif
+    if constexpr (BKW) {
+        if (is_state) {
+            // the state wave is done when the bookkeeping wave says so (or a hand-off failed): release the others
+            *f_job = DUO_EXIT;
+            if (bail & 1) {
+                if (lane == 0) atomicOr(a.err, 2);
+                *f_mail = DUO_EXIT;
+            }
+            return;
+        }
+    }
 
     // ------------------------------------------------------------- epilogue (the state wave owns the chain)
-    *f_job = DUO_EXIT;                                 // the row waves leave
+    if constexpr (!BKW) *f_job = DUO_EXIT;             // the row waves leave
     if (bail & 1) {
         if (lane == 0) atomicOr(a.err, 2);
         failed = 2;
@@ -668,8 +806,11 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     off = (off + 15) & ~(size_t)15;
     a.slot_doubles = rw == 1 ? dp + 2 : (1 + rw) * (dp + 2);
     a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
-    a.off_flag = (int)off; off += (size_t)cpb * (1 + rw) * 4;
+    const bool bkw = cpb == 1;                                                        // as the kernel (BKW)
+    a.off_flag = (int)off; off += (size_t)cpb * (1 + rw + (bkw ? 3 : 0)) * 4;
     off = (off + 15) & ~(size_t)15;
+    a.off_spec = 0;
+    if (bkw) { a.off_spec = (int)off; off += (size_t)2 * ((3 * nv * 64 + 4 + 64) + (4 * nv * 64 + 4)) * 8; }
     a.om_in_lds = 1;
     const size_t cap = 160 * 1024;
     const size_t stack = (size_t)cpb * a.max_depth * nuts_stack_record(nv) * 8;
@@ -690,7 +831,7 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * CPB * (1 + RW)), a.lds_bytes, stream, a);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (CPB * (1 + RW) + (CPB == 1 ? 1 : 0))), a.lds_bytes, stream, a);
         return (int)hipGetLastError();
     };
     constexpr bool COLD = NV >= 2 || CPB > 1;
@@ -700,12 +841,12 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 template <int NV, int DP>
 static int launch_duo_shape(const NutsArgs &a, int nblocks, int cpb, int rw, hipStream_t stream) {
     if (cpb == 4 && rw == 1) return launch_duo_one<NV, DP, 4, 1>(a, nblocks, stream);
-    if (cpb == 1 && rw == 4) return launch_duo_one<NV, DP, 1, 4>(a, nblocks, stream);
+    if (cpb == 1 && rw == 2) return launch_duo_one<NV, DP, 1, 2>(a, nblocks, stream);
     return -1;
 }
 
 bool nuts_duo_has(int cpb, int rw, int dp, int nv) {
-    return ((cpb == 4 && rw == 1) || (cpb == 1 && rw == 4)) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
+    return ((cpb == 4 && rw == 1) || (cpb == 1 && rw == 2)) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
 }
 
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream) {

@@ -1,6 +1,6 @@
 """Diagnostic: cycle shares of one leapfrog at the C3 site size (D=32, n_j=500, m4b) in the
 steady state of EP (tight cavities, deep trees).  Needs the stamped build:
-EPX_LIB=variants/libepx_stamps.so python3 scripts/stamps_c3.py [sites] [ep_iters] [layout]"""
+EPX_LIB=variants/libepx_stamps.so python3 scripts/stamps_c3.py [sites] [ep_iters] [layout] [D] [n]"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,7 +15,9 @@ def main():
     J = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nit = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     layout = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    mod = models.m4b(J, 32, 500)
+    D = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    n = int(sys.argv[5]) if len(sys.argv) > 5 else 500
+    mod = models.m4b(J, D, n)
     data = mod.simulate_data(Sigma_x='rand', rng=100)
     _, _, Q0, r0 = mod.get_prior()
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
@@ -30,7 +32,7 @@ def main():
     per = st[:, :7] / st[:, 7:8]
     med = np.median(per, axis=0)
     lf = eng.get_chain_stats(4)[:, :, 3]
-    print('C3 site size, J=%d, layout %d, info %d, EP iteration %d: sampling launches (ms) %s'
+    print('site size D=%d n=%d, J=%d,' % (D, n, J)); print('J=%d, layout %d, info %d, EP iteration %d: sampling launches (ms) %s'
           % (J, eng.last_layout(), info, nit, np.round(M.sampling_ms, 1)))
     print('leapfrogs per chain: mean %.0f max %.0f; per transition %.0f' % (lf.mean(), lf.max(), lf.mean() / 200))
     print('cycles per leapfrog (median over %d blocks), total %.0f' % (nb, med.sum()))

@@ -59,8 +59,10 @@ def test_row_and_state_waves_give_the_draws_of_one_wave_per_chain(model, D, n, c
 @pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m4b_sg', 32, 500), ('m1b_sg', 32, 300), ('m5b_sg', 21, 333),
                                        ('m3b_sg', 11, 64), ('m2b_sg', 32, 100)])
 def test_duo_gradients_match_oracle(model, D, n):
-    """Every layout evaluates the density with its own gradient code: 5 (one row wave) and 6 (four
-    row waves, partial sums added by the state wave) against the C restatement."""
+    """Every layout evaluates the density with its own gradient code: 5 (one row wave) and 6 (two row
+    waves, partial sums added by the state wave; the bookkeeping on a wave of its own) against the C
+    restatement.  Layout 6 keeps tree stack and mailbox in LDS: at the C3 site size the rows leave no room
+    and the request falls back to layout 2."""
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 100 + D)
     eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     rng = np.random.RandomState(8)
@@ -70,7 +72,7 @@ def test_duo_gradients_match_oracle(model, D, n):
         lp_o, g_o = no.logdensity_grad(model, X[lo:hi], y[lo:hi], mu_dev[k], Om_dev[k], theta)
         for layout in (5, 6):
             lp, g = eng.logdensity_grad(k, theta, layout=layout)
-            assert eng.last_layout() == layout
+            assert eng.last_layout() == (2 if layout == 6 and (D, n) == (32, 500) else layout)
             assert abs(lp - lp_o) <= 1e-11 * max(1.0, abs(lp_o))
             np.testing.assert_allclose(g, g_o, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g_o).max()))
 
@@ -98,7 +100,7 @@ def test_duo_chain_counts_thinning_partial_batches(chains, it, thin, init):
 
 @pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m4b_sg', 32, 120)])
 def test_layout_6_follows_the_oracle_run(model, D, n):
-    """One workgroup per chain with four row waves: whole site updates against the C restatement,
+    """One workgroup per chain -- state wave, two row waves, bookkeeping wave: whole site updates against the C restatement,
     chain by chain until rounding differences are amplified past a decision (as for layouts 1, 2)."""
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=3, tight=1000.)
     eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
