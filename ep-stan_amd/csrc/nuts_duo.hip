@@ -233,8 +233,7 @@ k_nuts_duo(NutsArgs a) {
                 }
                 const double fa = fa0 + fa1, fb = fb0 + fb1;
                 double la, wa, ga, lb, wb, gb;
-                logistic_split(fa, (double)(yb & 1ull), la, wa, ga);
-                logistic_split(fb, (double)((yb >> 1) & 1ull), lb, wb, gb);
+                logistic_split2(fa, fb, (double)(yb & 1ull), (double)((yb >> 1) & 1ull), la, lb, wa, wb, ga, gb);
                 yb >>= 2;
                 lb = two ? lb : 0.0; wb = two ? wb : 1.0; gb = two ? gb : 0.0;
                 ll += la; wprod *= wa; da += ga;
