@@ -133,6 +133,15 @@ __device__ inline double readlane_d(double v, int lane) {
     return x.d;
 }
 
+// value of lane addr4 / 4 in every lane through the LDS crossbar (all lanes active; addr4 = 4 x lane, uniform)
+__device__ inline double bcast_lds(double v, int addr4) {
+    union { double d; int u[2]; } x;
+    x.d = v;
+    x.u[0] = __builtin_amdgcn_ds_bpermute(addr4, x.u[0]);
+    x.u[1] = __builtin_amdgcn_ds_bpermute(addr4, x.u[1]);
+    return x.d;
+}
+
 // value of the lane whose index differs from this lane's ONLY in bit B (B >= 2):
 // a true xor partner, needed by all-reduce stages that must not mix the low bits.
 //   B=2: row_ror:4 and B=3: row_ror:8 rotate within a row of 16 and keep the low bits

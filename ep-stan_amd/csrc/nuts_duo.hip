@@ -588,6 +588,8 @@ k_nuts_duo(NutsArgs a) {
         // ---- cavity term Ov = Omega (phi - mu) of the position in flight ...
         V vv, Ov;
         FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? sq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
+        int bzero = 0;
+        asm volatile("" : "+v"(bzero));               // a register holding 0 the compiler cannot fold: address base
         {
             // OU column pairs per round, loads first: the LDS latency is paid once per round.  The padding
             // pairs (and absent tail rows) hold zeros, so they add nothing and the sums keep order and value
@@ -595,6 +597,7 @@ k_nuts_duo(NutsArgs a) {
             const double2 *Op = reinterpret_cast<const double2 *>(Oms) + e0;
             const double2 *Tp = reinterpret_cast<const double2 *>(Ots + (size_t)rc * tstride);
             for (int p0 = 0; p0 < npad; p0 += OU) {
+                const int pb = bzero + 8 * (p0 & 31);                // byte address (4 x lane) of v[2 p0] for ds_bpermute
                 double2 o[OU], tt[OU];
 #pragma unroll
                 for (int u = 0; u < OU; ++u) {
@@ -604,7 +607,10 @@ k_nuts_duo(NutsArgs a) {
 #pragma unroll
                 for (int u = 0; u < OU; ++u) {
                     const int p = p0 + u;
-                    const double v0 = readlane_d(vv.v[0], (2 * p) & 63), v1 = readlane_d(vv.v[0], (2 * p + 1) & 63);
+                    // v[2p], v[2p+1] to every lane through the LDS crossbar (ds_bpermute with a uniform address:
+                    // `zero` + immediate), not through v_readlane: the vector pipe is what this kernel runs out of
+                    const double v0 = bcast_lds(vv.v[0], pb + 8 * u), v1 = bcast_lds(vv.v[0], pb + 8 * u + 4);
+                    (void)p;
                     Ov.v[0] = fma(o[u].x, v0, Ov.v[0]);
                     Ov.v[0] = fma(o[u].y, v1, Ov.v[0]);
                     if constexpr (NV > 1) {

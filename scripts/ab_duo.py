@@ -12,4 +12,4 @@ _, _, Q0, r0 = mod.get_prior()
 M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
            df0=models.default_df0(J), layout=5, sync_sites=False)
 M.run(3, verbose=False, seed=1)
-print(os.environ.get('EPX_LIB', 'default'), 'launch ms', np.round(M.sampling_ms, 1), 'gradients %.4g' % M.ngrad_log[-1])
+print(os.environ.get('EPX_LIB', 'default'), 'launch ms', np.round(M.sampling_ms, 1), 'gradients', ['%.4g' % g for g in M.ngrad_log])
