@@ -38,7 +38,12 @@ namespace epx {
 #define EPX_PRIO_S_CRIT 2
 #endif
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23, DUO_NO_MORE = 1 << 30 };
-enum { DUO_RESTART = 1, DUO_LEAVE = 2 };          // commands of the bookkeeping wave (CPB == 1)
+enum { DUO_RESTART = 1, DUO_LEAVE = 2 };
+// what a chain carries from one piece of a segmented launch to the next, besides the cold store (lane, variable)
+#define EPX_CK_LIST(X)                                                                                        \
+    X(0, lps) X(1, eps) X(2, da_mu) X(3, s_bar) X(4, x_bar) X(5, da_count) X(6, va_n) X(7, eps_sum) X(8, acc_sum)  \
+    X(9, depth_sum) X(10, nleap_tot) X(11, ngrad) X(12, t) X(13, va_counter) X(14, va_wsize) X(15, va_next)       \
+    X(16, ndiv) X(17, npost) X(18, kept) X(19, failed)          // commands of the bookkeeping wave (CPB == 1)
 
 __device__ inline int duo_wait(const volatile int *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -56,6 +61,16 @@ __device__ inline int duo_wait_ge(const volatile int *flag, int want) {
         __builtin_amdgcn_s_sleep(1);
     }
     return DUO_TIMEOUT;
+}
+// A checkpoint travels between CUs of DIFFERENT XCDs, whose L2s do not see each other's lines: it is written and
+// read with agent-scope accesses (write-through / L2-bypassing), so no L2 write-back or invalidation is needed
+__device__ inline void ck_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double ck_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
 }
 // everything this wave wrote to LDS is visible before the flag that follows
 __device__ inline void duo_publish(volatile int *flag, int v) {
@@ -110,8 +125,77 @@ k_nuts_duo(NutsArgs a) {
     const bool is_bk = BKW && wave == CPB * (1 + RW);
     const int team = is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB;
     const int wr = is_state ? 0 : (wave - CPB) % RW;
+    // Segmented launch (NutsArgs::seg_off, layout 5): a workgroup runs a LIST of (site, transitions [t0, t1)) pieces
+    // one after the other -- the host cuts the sites so that every CU gets the same predicted work (McNaughton's
+    // wrap-around rule: at most one cut per CU, the first piece of a cut site is the first piece of the next CU).
+    // A piece that ends before the last transition leaves a checkpoint in the chain's cold store; the piece that
+    // continues it waits for the chain's flag, restores, re-evaluates the gradient at the current sample (the same
+    // arithmetic on the same position: the same bits) and goes on.  Same draws as the unsegmented run.
+    //   Piece QUEUE (NutsArgs::dyn_prog; what Master uses): no lists -- a workgroup that is free claims the site with
+    // the largest predicted REMAINING work (transitions left x predicted leapfrogs per transition) among the sites
+    // nobody holds, runs dyn_len transitions of it, puts it back, and claims again (longest remaining processing
+    // time first: the preemptive schedule that ends every site at about the same time, and it adapts to what the
+    // sites really cost).  A claim is a compare-and-swap on the site's `busy` word; nobody ever waits for a piece.
+    const bool queued = a.dyn_prog != nullptr;
+    const bool segmented = queued || a.seg_off != nullptr;
+    const int sg0 = (segmented && !queued) ? a.seg_off[blockIdx.x] : 0;
+    const int sg1 = queued ? (1 << 30) : (segmented ? a.seg_off[blockIdx.x + 1] : 1);
+    for (int sg = sg0; sg < sg1; ++sg) {
+    int q_site = -1, q_t0 = 0;
+    if (queued) {
+        // ---- claim: every thread scores the sites tid, tid + 512, ...; wave maxima through LDS; thread 0 tries the
+        // compare-and-swap and everybody reads the outcome (the LDS holds no site at this point)
+        volatile double *sc = reinterpret_cast<volatile double *>(smem);
+        volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
+        for (int attempt = 0; attempt < (1 << 16) && q_site < 0; ++attempt) {
+            double best = -1.0; int arg = -1;
+            for (int s = tid; s < a.dyn_count; s += blockDim.x) {
+                const int pr = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int bz = __hip_atomic_load(a.dyn_busy + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bz == 0 && pr < a.iter) {
+                    // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
+                    // remaining site would get it one at a time)
+                    unsigned hsh = (unsigned)s * 2654435761u ^ ((unsigned)blockIdx.x * 40503u + (unsigned)attempt * 97u + (unsigned)sg) * 2246822519u;
+                    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+                    const double jit = 0.88 + 0.24 * (double)(hsh & 0xFFFF) * (1.0 / 65536.0);
+                    const double sc_s = (double)(a.iter - pr) * (a.dyn_rate ? a.dyn_rate[s] : 1.0) * jit;
+                    if (sc_s > best) { best = sc_s; arg = s; }
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
+                if (ob > best || (ob == best && oa >= 0 && (arg < 0 || oa < arg))) { best = ob; arg = oa; }
+            }
+            if (lane == 0) { sc[wave] = best; si[wave] = arg; }
+            __syncthreads();
+            if (tid == 0) {
+                double b = -1.0; int g = -1;
+                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
+                int got = -2;                                  // -2: nothing left to claim
+                if (g >= 0) {
+                    int expect = 0;
+                    const bool ok = __hip_atomic_compare_exchange_strong(a.dyn_busy + g, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT);
+                    got = ok ? g : -1;                         // -1: somebody was faster, look again
+                }
+                si[16] = got;
+                if (got >= 0) si[17] = __hip_atomic_load(a.dyn_prog + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            const int got = si[16];
+            if (got >= 0) { q_site = got; q_t0 = si[17]; }
+            __syncthreads();
+            if (got == -2) break;
+        }
+        if (q_site < 0) break;                                 // every unfinished site has its workgroup: done
+    }
+    {
     const int bps = (a.chains + CPB - 1) / CPB;
-    const int sb = a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps), cb = blockIdx.x % bps;
+    const int sb = queued ? q_site : (segmented ? a.seg_site[sg] : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps)));
+    const int cb = segmented ? 0 : blockIdx.x % bps;
+    const int t_begin = queued ? q_t0 : (segmented ? a.seg_t0[sg] : 0);
+    const int t_end = queued ? (q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter) : (segmented ? a.seg_t1[sg] : a.iter);
+    const bool resume = t_begin > 0;
     const int k = a.k0 + sb;
     const int chain = cb * CPB + team;
     const int D = a.D, d = a.d, P = a.P, model = a.model;
@@ -122,6 +206,21 @@ k_nuts_duo(NutsArgs a) {
     const int tr = d - dm;                            // ... and the rows beyond (0..2 for D <= 32)
     const int npair = (dm + 1) / 2, npad = (npair + OU - 1) / OU * OU;       // pairs, zero padded to whole rounds
     const int tstride = 2 * npad + 2;                 // tail rows: [2 rows (zero when absent)][column], NV > 1 only
+
+    // a piece that continues an earlier one: the piece that ran the transitions before t_begin (on another CU, maybe
+    // another XCD) has left its checkpoint when the chain's flag says so.  Every wave of the chain waits here (a
+    // row wave must not run into its hand-off time-out while the state wave waits), then the staging barrier
+    int seg_seen = 0;
+    if (queued) seg_seen = t_begin;
+    if (resume && !queued && chain < a.chains) {
+        for (int spin = 0; spin < (1 << 24); ++spin) {
+            seg_seen = __hip_atomic_load(a.seg_flag + (size_t)sb * a.chains + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seg_seen = __builtin_amdgcn_readfirstlane(seg_seen);
+            if (seg_seen == t_begin || seg_seen < 0) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        asm volatile("" ::: "memory");
+    }
 
     double *Xs = reinterpret_cast<double *>(smem);
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);        // [(pair p, row e)] -> (Om[e][2p], Om[e][2p+1])
@@ -165,11 +264,12 @@ k_nuts_duo(NutsArgs a) {
         }
         if (tid < CPB * NFLAG) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
     }
-    __syncthreads();                                   // the only workgroup barrier of the kernel
-    if (chain >= a.chains) return;
+    __syncthreads();                                   // the only workgroup barrier of a piece
+    if (chain >= a.chains) goto seg_done;
 
     if (!is_state && !is_bk) {
         // ================================================================= row wave
+        if (resume && seg_seen != t_begin) goto seg_done;      // nothing to do for this chain (its state wave reports why)
         // responses of this lane's rows as a bit mask (row of iteration `it`: wr*64 + lane + it*64*RW)
         unsigned long long ybits = 0;
         {
@@ -189,7 +289,7 @@ k_nuts_duo(NutsArgs a) {
 #ifdef EPX_STAMPS
                 if (a.stamps && team == 0 && wr == 0 && lane == 0) { a.stamps[(size_t)blockIdx.x * 8 + 5] = tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] = tacc[6]; }
 #endif
-                return;
+                goto seg_done;
             }
             const double *job = slot + JOB;
             const double alpha = job[0];
@@ -257,7 +357,10 @@ k_nuts_duo(NutsArgs a) {
     // global memory of the chain: the tree stack (unless it is in LDS), then the cold store (COLD)
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
     const size_t g_stack = (size_t)a.max_depth * SREC;                 // the cold store sits behind the stack's place
-    double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)sb * a.chains + chain) * a.stack_stride);
+    // (pieced launches: the tree stack and the cold store belong to the persistent WORKGROUP, so no line of them is ever
+    // cached by two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
+    double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
+    double *ckp = segmented ? a.ckpt + ((size_t)sb * a.chains + chain) * (size_t)(4 * NV + 1) * 64 : nullptr;
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
@@ -284,11 +387,23 @@ k_nuts_duo(NutsArgs a) {
         const int e = lane + 64 * i;
         mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
         inv_e.v[i] = 1.0;
-        wmean.v[i] = 0.0; wm2.v[i] = 0.0;
-        gs.v[i] = 0; zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
+        zq.v[i] = 0; zp.v[i] = 0; zg.v[i] = 0;
+    }
+    FORV {
+        gs.v[i] = 0; pq.v[i] = 0; pp.v[i] = 0; pg.v[i] = 0;
         mq.v[i] = 0; mp.v[i] = 0; mg.v[i] = 0; rho.v[i] = 0; psp.v[i] = 0; psm.v[i] = 0;
     }
-    {
+    if (resume) {
+        // the sample and the Welford sums of the piece before this one (checkpoint record: qs, wmean, wm2, metric, scalars)
+        FORV {
+            qs.v[i] = ck_load(ckp + (0 * NV + i) * 64 + lane);
+            wmean.v[i] = ck_load(ckp + (1 * NV + i) * 64 + lane);
+            wm2.v[i] = ck_load(ckp + (2 * NV + i) * 64 + lane);
+        }
+    } else {
+        FORV { wmean.v[i] = 0.0; wm2.v[i] = 0.0; }
+    }
+    if (!resume) {
         const double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV {
             const int e = lane + 64 * i;
@@ -323,6 +438,14 @@ k_nuts_duo(NutsArgs a) {
     double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;
     double u_dir = 0.0, gum = 0.0;
     double dhb = 0.0, lw_m = -INFINITY, lw_s = 0.0;
+    int bail = 0;
+    if (resume) {
+        if (seg_seen < 0) {                            // the chain failed in its first piece: everything is written
+            *f_job = DUO_EXIT;
+            goto seg_done;
+        }
+        if (seg_seen != t_begin) bail = 1;            // timed out: reported through NutsArgs::err below
+    }
     FORV { zq.v[i] = qs.v[i]; }
     const bool teacher = a.eps_in != nullptr;       // fixed step size / metric (test hook)
     if (teacher) {
@@ -339,6 +462,20 @@ k_nuts_duo(NutsArgs a) {
         da_mu = log(10.0 * eps);
         const double *cm = a.carry_metric + (size_t)k * P;
         FORV { const int e = lane + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
+    }
+    if constexpr (COLD) {
+        if (resume) {
+            FORV inv_e.v[i] = ck_load(ckp + (3 * NV + i) * 64 + lane);
+            const double ckv = ck_load(ckp + 4 * NV * 64 + lane);
+#define EPX_CK_GET(idx, x) x = (decltype(x))readlane_d(ckv, idx);
+            EPX_CK_LIST(EPX_CK_GET)
+#undef EPX_CK_GET
+            ngrad -= 1.0;                             // the gradient at the restored sample is evaluated once more
+            if (failed) {                             // it failed in its first piece, where everything was written
+                *f_job = DUO_EXIT;
+                goto seg_done;
+            }
+        }
     }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
     auto flush_dh = [&](int cnt) {
@@ -358,7 +495,6 @@ k_nuts_duo(NutsArgs a) {
         sum_metro += me;
     };
 
-    int bail = 0;
     if constexpr (BKW) {
         if (is_bk) {
             // ============================================================= bookkeeping wave (owns the chain)
@@ -468,7 +604,7 @@ k_nuts_duo(NutsArgs a) {
     double job_eps = 0.0;
     STAMP_INIT;
 
-    for (; !is_bk;) {
+    for (; !is_bk && !bail;) {
         // `lane` is re-derived through an opaque move every leapfrog, otherwise the per-element index
         // arithmetic below is hoisted out of the loop and spilled (as in k_nuts_spec)
         int lane_v = lane0;
@@ -558,7 +694,11 @@ k_nuts_duo(NutsArgs a) {
 #define EPX_CHAIN_EXIT { leave = 1; parked = 0; break; }
 #define EPX_DBG_EXIT { leave = 2; parked = 0; break; }
 #define STAMP_LEAF do { } while (0)
+#define EPX_RESUME resume
+#define EPX_T_END t_end
 #include "nuts_state_machine.inc"
+#undef EPX_RESUME
+#undef EPX_T_END
 #undef STAMP_LEAF
 #undef EPX_CHAIN_EXIT
 #undef EPX_DBG_EXIT
@@ -764,7 +904,7 @@ k_nuts_duo(NutsArgs a) {
                 if (lane == 0) atomicOr(a.err, 2);
                 *f_mail = DUO_EXIT;
             }
-            return;
+            goto seg_done;
         }
     }
 
@@ -774,7 +914,29 @@ k_nuts_duo(NutsArgs a) {
         if (lane == 0) atomicOr(a.err, 2);
         failed = 2;
     }
-    if (bail & 4) return;                              // test hook (a.dbg): lp and gradient are written
+    if (bail & 4) goto seg_done;                       // test hook (a.dbg): lp and gradient are written
+    if constexpr (COLD) {
+        if (segmented) {
+            // ---- checkpoint at the transition boundary: the sample, the Welford sums, the metric and the scalars of
+            // EPX_CK_LIST (the gradient at the sample is re-evaluated by the piece that continues)
+            FORV {
+                ck_store(ckp + (0 * NV + i) * 64 + lane, qs.v[i]);
+                ck_store(ckp + (1 * NV + i) * 64 + lane, wmean.v[i]);
+                ck_store(ckp + (2 * NV + i) * 64 + lane, wm2.v[i]);
+                ck_store(ckp + (3 * NV + i) * 64 + lane, inv_e.v[i]);
+            }
+            double ckv = 0.0;
+#define EPX_CK_PUT(idx, x) ckv = lane == (idx) ? (double)(x) : ckv;
+            EPX_CK_LIST(EPX_CK_PUT)
+#undef EPX_CK_PUT
+            ck_store(ckp + 4 * NV * 64 + lane, ckv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record is out before anybody is told
+            if (lane == 0 && !queued)
+                __hip_atomic_store(a.seg_flag + (size_t)sb * a.chains + chain, failed ? -1 : t, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!failed && t < a.iter) goto seg_done;          // suspended at the end of a piece: no final record yet
     {
         double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
@@ -795,6 +957,20 @@ k_nuts_duo(NutsArgs a) {
             st[ST_DEPTH_MEAN] = npost ? depth_sum / npost : 0.0;
             st[ST_FAIL] = failed;
         }
+    }
+    }                                                  // (scope of one piece)
+seg_done:
+    if (sg + 1 < sg1) __syncthreads();                 // every wave is done with the LDS image of this site
+    if (queued) {
+        // the site goes back to the pool: progress first, then the claim word (release: the checkpoints are out);
+        // the barrier makes this workgroup's next claim see its own site again
+        if (tid == 0) {
+            __hip_atomic_store(a.dyn_prog + q_site, q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.dyn_busy + q_site, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     }
 }
 
@@ -856,7 +1032,7 @@ bool nuts_duo_has(int cpb, int rw, int dp, int nv) {
 
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream) {
     if (!nuts_duo_has(cpb, rw, dp, nv)) return -1;
-    const int nblocks = count * ((a.chains + cpb - 1) / cpb);
+    const int nblocks = (a.seg_off || a.dyn_prog) ? a.seg_nwg : count * ((a.chains + cpb - 1) / cpb);
     if (nv == 1) return dp == 16 ? launch_duo_shape<1, 16>(a, nblocks, cpb, rw, stream) : launch_duo_shape<1, 32>(a, nblocks, cpb, rw, stream);
     return dp == 16 ? launch_duo_shape<2, 16>(a, nblocks, cpb, rw, stream) : launch_duo_shape<2, 32>(a, nblocks, cpb, rw, stream);
 }
