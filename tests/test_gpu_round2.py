@@ -465,3 +465,105 @@ def test_named_parameter_draws_from_the_device():
     with pytest.raises(ValueError, match='not defined'):
         w.cavity(M.Q, M.r, M.Qi[:, :, 1], M.ri[:, 1])
         w.tilted(dQ, dr, save_samples=['gamma'], seed=3)
+
+
+# ---------------------------------------------------------------------------------------------
+# pieced launches of layout 5: a chain stops at a transition boundary, leaves a checkpoint record and goes on
+# in another workgroup -- the draws must be those of the uncut run, bit for bit
+def _pieced_problem(D, n, it, J=6):
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=it)
+    return M, M.engine, np.arange(J) + 11
+
+
+def _run(eng, seeds, opts, J):
+    stats, ms = eng.sample_batch(seeds, opts)
+    return _all_draws(eng, J), eng.get_chain_stats(4).copy(), stats.copy()
+
+
+@pytest.mark.parametrize('D,n', [(16, 200), (32, 500), (12, 90)])
+def test_listed_pieces_give_the_draws_of_the_uncut_launch(D, n):
+    """epx_set_segments: sites cut once, twice, continued in the same and in another workgroup, with warm-up
+    windows and metric updates on either side of a cut (it = 60: windows end at transitions 13 and 26)."""
+    it = 60
+    M, eng, seeds = _pieced_problem(D, n, it)
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=5)
+    ref = _run(eng, seeds, opts, 6)
+    assert eng.last_layout() == 5 and eng.last_segments() == 0
+    pieces = [[(0, 0, it)],
+              [(1, 0, 13), (2, 0, it)],
+              [(3, 0, 27), (1, 13, it)],
+              [(4, 0, 1), (3, 27, it)],
+              [(5, 0, it), (4, 1, 30), (4, 30, 59), (4, 59, it)]]
+    eng.set_segments(pieces)
+    got = _run(eng, seeds, opts, 6)
+    assert eng.last_segments() == 11
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    # a warm start from these draws continues identically, and a different `iter` ignores the stale lists
+    eng.set_segments(None)
+    w_ref = _run(eng, seeds + 1, HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=5), 6)
+    eng.set_segments(pieces)
+    _run(eng, seeds, opts, 6)
+    w_got = _run(eng, seeds + 1, HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=5), 6)
+    np.testing.assert_array_equal(w_ref[0], w_got[0])
+    _run(eng, seeds, HipEngine.sampler_opts(chains=4, iter=it // 2, init='random', layout=5), 6)
+    assert eng.last_segments() == 0
+    eng.set_segments(None)
+
+
+def test_piece_lists_are_validated():
+    M, eng, seeds = _pieced_problem(12, 90, 20)
+    for bad, msg in (([[(0, 0, 20)], [(1, 0, 20)]], 'cover'),
+                     ([[(k, 0, 20)] for k in range(5)] + [[(5, 0, 10)], [(5, 11, 20)]], 'do not meet'),
+                     ([[(k, 0, 20)] for k in range(5)] + [[(0, 0, 0)]], 'empty range'),
+                     ([[(k, 0, 20) for k in range(4)], [(4, 0, 20), (5, 0, 9)], [(5, 9, 20)]], 'neither earlier'),
+                     ([[(k, 0, 20)] for k in range(5)] + [[(5, 0, 19)]], 'ends at')):
+        with pytest.raises(_lib.EpxError, match=msg):
+            eng.set_segments(bad)
+
+
+@pytest.mark.parametrize('piece_len,rate', [(7, None), (1, 'skewed'), (25, 'skewed'), (500, None)])
+def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate):
+    """epx_set_piece_queue: persistent workgroups claim sites by largest remaining predicted work and run them
+    piece_len transitions at a time; whatever the claims, the draws are those of one workgroup per site."""
+    it = 50
+    M, eng, seeds = _pieced_problem(16, 120, it, J=9)
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=5)
+    ref = _run(eng, seeds, opts, 9)
+    r = None if rate is None else np.array([9.0, 1.0, 1.0, 5.0, 1.0, 1.0, 2.0, 1.0, 30.0])
+    eng.set_piece_queue(piece_len, r)
+    got = _run(eng, seeds, opts, 9)
+    assert eng.last_segments() == -((it + piece_len - 1) // piece_len)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    eng.set_piece_queue(0)
+    _run(eng, seeds, opts, 9)
+    assert eng.last_segments() == 0
+    with pytest.raises(_lib.EpxError, match='not positive'):
+        eng.set_piece_queue(5, np.zeros(9))
+
+
+def test_ep_with_the_piece_queue_equals_ep_without(monkeypatch):
+    """Master at a site size that fills the LDS and more sites than CUs runs its launches from the piece queue: the
+    whole EP trajectory equals the one-workgroup-per-site run (the dispatch does not touch a single draw)."""
+    J = 300
+    monkeypatch.setattr(Master, 'LEAD_FRACTION', 2.0)      # no lead sites: a split launch would take the queue's place
+    mod = models.m4b(J, 20, 340)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    out = []
+    for queue in (True, False):
+        M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=64,
+                   df0=models.default_df0(J), sync_sites=False)
+        assert M._one_workgroup_per_cu()
+        if not queue:
+            M.engine.set_piece_queue = lambda *a, **k: None
+        info = M.run(3, verbose=False, calc_moments=False, seed=5)
+        out.append((M.Q.copy(), M.r.copy(), M.engine.last_segments(), M.engine.last_layout(), info))
+    assert out[0][3] == out[1][3] == 5 and out[0][4] == out[1][4] == 0
+    assert out[0][2] == -8 and out[1][2] == 0
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
