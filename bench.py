@@ -311,9 +311,12 @@ def main():
     # the launch ends with its slowest chain (one workgroup per chain) / slowest site (chains in lock step):
     # how far that is from the average, last launch of this rank
     lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
+    out['launch_ms_timed'] = [round(float(x), 1) for x in ms]
     out['launch_tail'] = {'slowest_chain_leapfrogs': float(lf.max()), 'mean_chain_leapfrogs': float(lf.mean()),
                           'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(layout),
-                          'lead_sites_of_a_split_launch': int(M.engine.last_split())}
+                          'lead_sites_of_a_split_launch': int(M.engine.last_split()),
+                          # < 0: the launch ran from the piece queue (persistent workgroups), -pieces per site
+                          'pieces': int(M.engine.last_segments()) if hasattr(M.engine, 'last_segments') else 0}
     if args.cpu_sites > 0:
         try:
             out['cpu_baseline'] = cpu_baseline(M, mod, data, args.chains, args.siter, args.cpu_sites,

@@ -262,7 +262,7 @@ int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->comm || c->comm_ext) (void)epx_comm_destroy(c);
-    void *ptrs[] = {c->ckpt, c->dyn_rate, c->dyn_words, c->seg_buf, c->seg_flag, c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    void *ptrs[] = {c->ckpt, c->dyn_rate, c->dyn_words, c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -616,38 +616,33 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     const bool want_carry = (o.reserved & 2) != 0 && !eps_dev;
     if (want_carry) { a.carry_eps = c->carry_eps; a.carry_metric = c->carry_metric; }
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
-    // Segmented launch (epx_set_segments): persistent workgroups, each with its list of (site, transitions) pieces
-    const bool use_seg = c->seg_nwg > 0 && layout == 5 && k0 == 0 && count == c->K && o.chains <= a.cpb &&
-                         c->seg_iter == o.iter && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == 5);
     c->last_segments = 0;
-    if (use_seg) {
-        const size_t nf = (size_t)count * o.chains;
-        if (c->seg_flag_n < nf) {
-            if (c->seg_flag) (void)hipFree(c->seg_flag);
-            c->seg_flag = nullptr; c->seg_flag_n = 0;
-            HIPCHK(dalloc(&c->seg_flag, nf));
-            c->seg_flag_n = nf;
-        }
-        HIPCHK(hipMemsetAsync(c->seg_flag, 0, nf * sizeof(int), c->stream));
-        a.seg_off = c->seg_buf; a.seg_site = c->seg_buf + (c->seg_nwg + 1);
-        a.seg_t0 = a.seg_site + c->seg_nseg; a.seg_t1 = a.seg_t0 + c->seg_nseg;
-        a.seg_flag = c->seg_flag; a.seg_nwg = c->seg_nwg;
-        a.order = nullptr;
-        c->last_segments = c->seg_nseg;
-    }
-    // Piece queue (epx_set_piece_queue): persistent workgroups claim sites and run them a few transitions at a time
-    const bool use_queue = !use_seg && c->dyn_len > 0 && layout == 5 && k0 == 0 && count == c->K &&
+    // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
+    const bool use_queue = c->dyn_len > 0 && layout == 5 && k0 == 0 && count == c->K &&
                            o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == 5);
     if (use_queue) {
         HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));
         a.dyn_prog = c->dyn_words; a.dyn_busy = c->dyn_words + count;
         a.dyn_rate = c->dyn_has_rate ? c->dyn_rate : nullptr;
         a.dyn_len = c->dyn_len; a.dyn_count = count;
-        a.seg_nwg = c->n_cu < count ? c->n_cu : count;
+        const int npieces = (o.iter + c->dyn_len - 1) / c->dyn_len;
+        a.seg_nwg = count * npieces;
+        {
+            // tree stack + cold store are private to a WORKGROUP of a pieced launch (no line of them is ever shared by
+            // the L2s of two XCDs): one region per piece
+            const size_t need = (size_t)a.seg_nwg * o.chains * a.stack_stride;
+            if (c->stack_elems < need) {
+                if (c->stack) (void)hipFree(c->stack);
+                c->stack = nullptr; c->stack_elems = 0;
+                HIPCHK(dalloc(&c->stack, need));
+                c->stack_elems = need;
+            }
+            a.stack = c->stack;
+        }
         a.order = nullptr;
-        c->last_segments = -((o.iter + c->dyn_len - 1) / c->dyn_len);        // (negative: pieces per site of a queued launch)
+        c->last_segments = -npieces;                 // (negative: pieces per site of a queued launch)
     }
-    if (use_seg || use_queue) {
+    if (use_queue) {
         const size_t need = (size_t)count * o.chains * (size_t)(4 * nv + 1) * 64;
         if (c->ckpt_n < need) {
             if (c->ckpt) (void)hipFree(c->ckpt);
@@ -663,7 +658,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // The launch ends with its slowest chain; this takes that chain at the faster tick.
     NutsArgs a2;
     int wpc2 = 0, dp2 = 0, nv2 = 0, n_lead = 0;
-    if (!use_seg && !use_queue && o.layout == 0 && (layout == 1 || layout == 5) && a.order && c->split_n > 0 && !eps_dev) {
+    if (!use_queue && o.layout == 0 && (layout == 1 || layout == 5) && a.order && c->split_n > 0 && !eps_dev) {
         n_lead = c->split_n < count ? c->split_n : count - 1;
         const int cap = c->n_cu / (2 * o.chains);          // at most half of the CUs for the lead sites
         if (n_lead > cap) n_lead = cap;
@@ -887,60 +882,6 @@ int epx_set_site_order(epx_ctx *c, const int32_t *order, int count) {
     if (!c->order_d) HIPCHK(dalloc(&c->order_d, (size_t)c->K));
     HIPCHK(hipMemcpy(c->order_d, order, (size_t)count * sizeof(int), hipMemcpyHostToDevice));
     c->order_n = count;
-    return 0;
-}
-
-int epx_set_segments(epx_ctx *c, int n_wg, const int32_t *wg_off, const int32_t *site, const int32_t *t0, const int32_t *t1) {
-    CTX(c);
-    if (n_wg <= 0 || !wg_off) { c->seg_nwg = 0; c->seg_nseg = 0; return 0; }
-    if (!site || !t0 || !t1) return fail("null segment arrays");
-    if (wg_off[0] != 0) return fail("wg_off[0] must be 0");
-    for (int w = 0; w < n_wg; ++w)
-        if (wg_off[w + 1] < wg_off[w]) return fail("wg_off is not monotone at workgroup %d", w);
-    const int ns = wg_off[n_wg];
-    if (ns < c->K) return fail("%d pieces cannot cover %d sites", ns, c->K);
-    // every site: its pieces tile [0, T) with the same T; a piece that continues another one must find it either
-    // earlier in its own workgroup or at the head of another workgroup (a head never waits: no cycle of waits)
-    std::vector<int> pos_in_wg((size_t)ns), wg_of((size_t)ns);
-    for (int w = 0; w < n_wg; ++w)
-        for (int s = wg_off[w]; s < wg_off[w + 1]; ++s) { pos_in_wg[s] = s - wg_off[w]; wg_of[s] = w; }
-    std::vector<std::vector<int>> by_site((size_t)c->K);
-    for (int s = 0; s < ns; ++s) {
-        if (site[s] < 0 || site[s] >= c->K) return fail("piece %d: site %d outside 0..%d", s, site[s], c->K - 1);
-        if (t0[s] < 0 || t1[s] <= t0[s]) return fail("piece %d: empty range [%d, %d)", s, t0[s], t1[s]);
-        by_site[site[s]].push_back(s);
-    }
-    int T = -1;
-    for (int k = 0; k < c->K; ++k) {
-        std::vector<int> &v = by_site[k];
-        if (v.empty()) return fail("site %d has no piece", k);
-        std::sort(v.begin(), v.end(), [&](int x, int y) { return t0[x] < t0[y]; });
-        if (t0[v[0]] != 0) return fail("site %d: the first piece starts at %d", k, t0[v[0]]);
-        for (size_t i = 1; i < v.size(); ++i) {
-            const int prev = v[i - 1], cur = v[i];
-            if (t0[cur] != t1[prev]) return fail("site %d: pieces [%d, %d) and [%d, %d) do not meet", k, t0[prev], t1[prev], t0[cur], t1[cur]);
-            const bool same_wg_earlier = wg_of[prev] == wg_of[cur] && pos_in_wg[prev] < pos_in_wg[cur];
-            if (!same_wg_earlier && pos_in_wg[prev] != 0)
-                return fail("site %d: the piece before [%d, %d) is neither earlier in the same workgroup nor the first of its own", k, t0[cur], t1[cur]);
-        }
-        const int Tk = t1[v.back()];
-        if (T < 0) T = Tk;
-        if (Tk != T) return fail("site %d ends at transition %d, site 0 at %d", k, Tk, T);
-    }
-    const size_t need = (size_t)(n_wg + 1) + 3 * (size_t)ns;
-    if (c->seg_buf_n < need) {
-        if (c->seg_buf) (void)hipFree(c->seg_buf);
-        c->seg_buf = nullptr; c->seg_buf_n = 0;
-        HIPCHK(dalloc(&c->seg_buf, need));
-        c->seg_buf_n = need;
-    }
-    std::vector<int> h(need);
-    memcpy(h.data(), wg_off, (size_t)(n_wg + 1) * sizeof(int));
-    memcpy(h.data() + (n_wg + 1), site, (size_t)ns * sizeof(int));
-    memcpy(h.data() + (n_wg + 1) + ns, t0, (size_t)ns * sizeof(int));
-    memcpy(h.data() + (n_wg + 1) + 2 * (size_t)ns, t1, (size_t)ns * sizeof(int));
-    HIPCHK(hipMemcpy(c->seg_buf, h.data(), need * sizeof(int), hipMemcpyHostToDevice));
-    c->seg_nwg = n_wg; c->seg_nseg = ns; c->seg_iter = T;
     return 0;
 }
 

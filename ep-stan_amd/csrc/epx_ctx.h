@@ -81,12 +81,7 @@ struct epx_ctx {
     int last_layout;
     int *order_d;
     int order_n;
-    // segmented launch of the sampler (epx_set_segments): [wg offsets (nwg + 1) | site | t0 | t1] on the device
-    int *seg_buf;
-    size_t seg_buf_n;
-    int seg_nwg, seg_nseg, seg_iter, last_segments;
-    int *seg_flag;
-    size_t seg_flag_n;
+    int last_segments;
     double *ckpt;
     size_t ckpt_n;
     // piece queue (epx_set_piece_queue): transitions per claim (0: off), predicted work per transition of the sites

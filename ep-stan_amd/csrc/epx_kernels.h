@@ -158,16 +158,13 @@ struct NutsArgs {
     int off_slot;                 // per chain: job / result slots
     int off_flag;                 // per chain: hand-off sequence numbers
     int slot_doubles;             // doubles of one chain's slots
+    int off_piece;                // 16 B: (site, first transition) of the piece a persistent workgroup is running
     int *err;                     // device word: set when a hand-off spin gives up (never in a healthy run)
-    // segmented launch (layout 5; epx_set_segments): workgroup w runs the pieces seg_off[w] .. seg_off[w+1]-1, piece s =
-    // transitions [seg_t0[s], seg_t1[s]) of site seg_site[s] of the batch; seg_flag[(site, chain)] = transition a
-    // finished piece stopped at (-1: the chain failed).  NULL = one workgroup per site, all transitions
-    const int *seg_off, *seg_site, *seg_t0, *seg_t1;
-    int *seg_flag;
+    // pieced launch (layout 5; epx_set_piece_queue): seg_nwg workgroups, one per piece
     int seg_nwg;
     double *ckpt;                 // pieced launches: per (site, chain) a record of (4 NV + 1) x 64 doubles (sample, Welford sums, metric, scalars)
-    // piece queue (epx_set_piece_queue): seg_nwg persistent workgroups claim sites by largest remaining predicted work
-    // and run dyn_len transitions per claim; dyn_prog[site] = transitions done, dyn_busy[site] = claimed
+    // piece queue (epx_set_piece_queue): every workgroup claims a site by largest remaining predicted work and runs
+    // dyn_len transitions of it; dyn_prog[site] = transitions done, dyn_busy[site] = claimed
     int *dyn_prog, *dyn_busy;
     const double *dyn_rate;       // predicted work per transition of every site of the batch, or NULL (all equal)
     int dyn_len, dyn_count;

@@ -42,7 +42,24 @@ struct GIdx {
     __device__ GRef operator[](int i) const { return GRef{b + (lane + 64 * i), lane + 64 * i < len}; }
 };
 struct GVec { GIdx v; };
-enum { GV_QS, GV_GS, GV_PQ, GV_PP, GV_PG, GV_MQ, GV_MP, GV_MG, GV_RHO, GV_PSP, GV_PSM, GV_WMEAN, GV_WM2, GV_BQ, GV_BG, GV_COUNT };
+// A wave-uniform scalar of the bookkeeping kept in the chain's global store: the adaptation state and the run's
+// statistics are touched once per transition -- as registers they would be live through every leapfrog
+struct GScal {
+    double *p;
+    __device__ operator double() const { return *p; }
+    __device__ const GScal &operator=(double x) const { *p = x; return *this; }
+    __device__ const GScal &operator=(const GScal &o) const { const double x = *o.p; *p = x; return *this; }
+    __device__ const GScal &operator+=(double x) const { *p = *p + x; return *this; }
+};
+struct RScal {            // the same interface on a register
+    double x;
+    __device__ operator double() const { return x; }
+    __device__ RScal &operator=(double v) { x = v; return *this; }
+    __device__ RScal &operator+=(double v) { x += v; return *this; }
+};
+enum { GV_QS, GV_GS, GV_PQ, GV_PP, GV_PG, GV_MQ, GV_MP, GV_MG, GV_RHO, GV_PSP, GV_PSM, GV_WMEAN, GV_WM2, GV_BQ, GV_BG,
+       GV_SCAL,                 // one vector's worth of scalars (GScal)
+       GV_COUNT };
 
 __device__ inline double *uniform_ptr(double *p) {
     const unsigned long long u = (unsigned long long)p;

@@ -72,6 +72,9 @@ __device__ inline double ck_load(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
+template <typename T> __device__ inline void ck_assign(T &x, double v) { x = (T)v; }
+__device__ inline void ck_assign(GScal &x, double v) { x = v; }
+__device__ inline void ck_assign(RScal &x, double v) { x = v; }
 // everything this wave wrote to LDS is visible before the flag that follows
 __device__ inline void duo_publish(volatile int *flag, int v) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -97,10 +100,16 @@ __device__ inline void duo_publish(volatile int *flag, int v) {
 #define STAMP_INIT do { } while (0)
 #endif
 
-template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
-__global__ void __launch_bounds__(64 * (CPB * (1 + RW) + (CPB == 1 ? 1 : 0)))
-k_nuts_duo(NutsArgs a) {
+typedef const __attribute__((address_space(4))) NutsArgs DuoArgsK;       // the kernel arguments where they are: kernarg segment
+
+// One piece of a chain's run: transitions [t_begin, t_end) of one site by the waves of one workgroup (the whole run
+// in a plain launch).  PIECED is a template parameter because the piece loop around this body costs it its register
+// allocation (76 -> 500 B of scratch per lane, 15 % of the time): the plain launch keeps the kernel without the loop.
+template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
+__device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queued, int q_site, int q_t0) {
     extern __shared__ __align__(16) unsigned char smem[];
+    DuoArgsK &a_piece = *kargs_p;
+#define a a_piece
     using V = Vec<NV>;
     constexpr int LOG = Log2<DP>::v;
     constexpr int SPR = DP / 2;                       // 16-B slots per row
@@ -117,110 +126,35 @@ k_nuts_duo(NutsArgs a) {
     constexpr int CREC = 4 * NV * 64 + 4;             // control record: q, p, grad, metric, eps_l, command
     constexpr int NFLAG = 1 + RW + (BKW ? 3 : 0);     // per chain: job, results, (mail, acknowledged, control generation)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // waves 0..CPB-1: state wave of chain c; then the row waves.  A workgroup's waves go to the SIMDs
     // round robin, so wave w and w + 4 share one: the row waves of chain c sit CPB waves behind the
     // state wave of chain c + 1 -- a chain that is the last one running keeps its two roles on different SIMDs
+    // A piece that ends before the chain's last transition (pieced launch) leaves a checkpoint record; the piece that
+    // continues it restores, re-evaluates the gradient at the current sample (the same arithmetic on the same position:
+    // the same bits) and goes on.  Same draws as the plain launch.
     const bool is_state = wave < CPB;
     const bool is_bk = BKW && wave == CPB * (1 + RW);
     const int team = is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB;
     const int wr = is_state ? 0 : (wave - CPB) % RW;
-    // Segmented launch (NutsArgs::seg_off, layout 5): a workgroup runs a LIST of (site, transitions [t0, t1)) pieces
-    // one after the other -- the host cuts the sites so that every CU gets the same predicted work (McNaughton's
-    // wrap-around rule: at most one cut per CU, the first piece of a cut site is the first piece of the next CU).
-    // A piece that ends before the last transition leaves a checkpoint in the chain's cold store; the piece that
-    // continues it waits for the chain's flag, restores, re-evaluates the gradient at the current sample (the same
-    // arithmetic on the same position: the same bits) and goes on.  Same draws as the unsegmented run.
-    //   Piece QUEUE (NutsArgs::dyn_prog; what Master uses): no lists -- a workgroup that is free claims the site with
-    // the largest predicted REMAINING work (transitions left x predicted leapfrogs per transition) among the sites
-    // nobody holds, runs dyn_len transitions of it, puts it back, and claims again (longest remaining processing
-    // time first: the preemptive schedule that ends every site at about the same time, and it adapts to what the
-    // sites really cost).  A claim is a compare-and-swap on the site's `busy` word; nobody ever waits for a piece.
-    const bool queued = a.dyn_prog != nullptr;
-    const bool segmented = queued || a.seg_off != nullptr;
-    const int sg0 = (segmented && !queued) ? a.seg_off[blockIdx.x] : 0;
-    const int sg1 = queued ? (1 << 30) : (segmented ? a.seg_off[blockIdx.x + 1] : 1);
-    for (int sg = sg0; sg < sg1; ++sg) {
-    int q_site = -1, q_t0 = 0;
-    if (queued) {
-        // ---- claim: every thread scores the sites tid, tid + 512, ...; wave maxima through LDS; thread 0 tries the
-        // compare-and-swap and everybody reads the outcome (the LDS holds no site at this point)
-        volatile double *sc = reinterpret_cast<volatile double *>(smem);
-        volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
-        for (int attempt = 0; attempt < (1 << 16) && q_site < 0; ++attempt) {
-            double best = -1.0; int arg = -1;
-            for (int s = tid; s < a.dyn_count; s += blockDim.x) {
-                const int pr = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int bz = __hip_atomic_load(a.dyn_busy + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bz == 0 && pr < a.iter) {
-                    // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
-                    // remaining site would get it one at a time)
-                    unsigned hsh = (unsigned)s * 2654435761u ^ ((unsigned)blockIdx.x * 40503u + (unsigned)attempt * 97u + (unsigned)sg) * 2246822519u;
-                    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
-                    const double jit = 0.88 + 0.24 * (double)(hsh & 0xFFFF) * (1.0 / 65536.0);
-                    const double sc_s = (double)(a.iter - pr) * (a.dyn_rate ? a.dyn_rate[s] : 1.0) * jit;
-                    if (sc_s > best) { best = sc_s; arg = s; }
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
-                if (ob > best || (ob == best && oa >= 0 && (arg < 0 || oa < arg))) { best = ob; arg = oa; }
-            }
-            if (lane == 0) { sc[wave] = best; si[wave] = arg; }
-            __syncthreads();
-            if (tid == 0) {
-                double b = -1.0; int g = -1;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
-                int got = -2;                                  // -2: nothing left to claim
-                if (g >= 0) {
-                    int expect = 0;
-                    const bool ok = __hip_atomic_compare_exchange_strong(a.dyn_busy + g, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_AGENT);
-                    got = ok ? g : -1;                         // -1: somebody was faster, look again
-                }
-                si[16] = got;
-                if (got >= 0) si[17] = __hip_atomic_load(a.dyn_prog + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            const int got = si[16];
-            if (got >= 0) { q_site = got; q_t0 = si[17]; }
-            __syncthreads();
-            if (got == -2) break;
-        }
-        if (q_site < 0) break;                                 // every unfinished site has its workgroup: done
-    }
-    {
     const int bps = (a.chains + CPB - 1) / CPB;
-    const int sb = queued ? q_site : (segmented ? a.seg_site[sg] : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps)));
-    const int cb = segmented ? 0 : blockIdx.x % bps;
-    const int t_begin = queued ? q_t0 : (segmented ? a.seg_t0[sg] : 0);
-    const int t_end = queued ? (q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter) : (segmented ? a.seg_t1[sg] : a.iter);
+    const bool segmented = queued;
+    const int sb = queued ? q_site : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps));
+    const int cb = queued ? 0 : blockIdx.x % bps;
+    const int t_begin = queued ? q_t0 : 0;
+    const int t_end = queued ? (q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter) : a.iter;
     const bool resume = t_begin > 0;
     const int k = a.k0 + sb;
     const int chain = cb * CPB + team;
     const int D = a.D, d = a.d, P = a.P, model = a.model;
     const int64_t row0 = a.k_lim[k];
     const int n = (int)(a.k_lim[k + 1] - row0);
-    constexpr int OU = NV > 1 ? 4 : 8;                // column pairs of the cavity precision per round of the mat-vec
+    constexpr int OUP = NV > 1 ? 4 : 8;               // the cavity precision is zero padded to whole groups of OUP column pairs
+    constexpr int OU = OUP;                           // column pairs per round of the mat-vec
     const int dm = d < 64 ? d : 64;                   // cavity precision: rows / columns held pair-interleaved
     const int tr = d - dm;                            // ... and the rows beyond (0..2 for D <= 32)
-    const int npair = (dm + 1) / 2, npad = (npair + OU - 1) / OU * OU;       // pairs, zero padded to whole rounds
+    const int npair = (dm + 1) / 2, npad = (npair + OUP - 1) / OUP * OUP;    // pairs, zero padded to whole groups
     const int tstride = 2 * npad + 2;                 // tail rows: [2 rows (zero when absent)][column], NV > 1 only
-
-    // a piece that continues an earlier one: the piece that ran the transitions before t_begin (on another CU, maybe
-    // another XCD) has left its checkpoint when the chain's flag says so.  Every wave of the chain waits here (a
-    // row wave must not run into its hand-off time-out while the state wave waits), then the staging barrier
-    int seg_seen = 0;
-    if (queued) seg_seen = t_begin;
-    if (resume && !queued && chain < a.chains) {
-        for (int spin = 0; spin < (1 << 24); ++spin) {
-            seg_seen = __hip_atomic_load(a.seg_flag + (size_t)sb * a.chains + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seg_seen = __builtin_amdgcn_readfirstlane(seg_seen);
-            if (seg_seen == t_begin || seg_seen < 0) break;
-            __builtin_amdgcn_s_sleep(32);
-        }
-        asm volatile("" ::: "memory");
-    }
 
     double *Xs = reinterpret_cast<double *>(smem);
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);        // [(pair p, row e)] -> (Om[e][2p], Om[e][2p+1])
@@ -265,11 +199,10 @@ k_nuts_duo(NutsArgs a) {
         if (tid < CPB * NFLAG) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
     }
     __syncthreads();                                   // the only workgroup barrier of a piece
-    if (chain >= a.chains) goto seg_done;
+    if (chain >= a.chains) return;
 
     if (!is_state && !is_bk) {
         // ================================================================= row wave
-        if (resume && seg_seen != t_begin) goto seg_done;      // nothing to do for this chain (its state wave reports why)
         // responses of this lane's rows as a bit mask (row of iteration `it`: wr*64 + lane + it*64*RW)
         unsigned long long ybits = 0;
         {
@@ -289,7 +222,7 @@ k_nuts_duo(NutsArgs a) {
 #ifdef EPX_STAMPS
                 if (a.stamps && team == 0 && wr == 0 && lane == 0) { a.stamps[(size_t)blockIdx.x * 8 + 5] = tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] = tacc[6]; }
 #endif
-                goto seg_done;
+                return;
             }
             const double *job = slot + JOB;
             const double alpha = job[0];
@@ -360,7 +293,8 @@ k_nuts_duo(NutsArgs a) {
     // (pieced launches: the tree stack and the cold store belong to the persistent WORKGROUP, so no line of them is ever
     // cached by two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
     double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
-    double *ckp = segmented ? a.ckpt + ((size_t)sb * a.chains + chain) * (size_t)(4 * NV + 1) * 64 : nullptr;
+    // (the checkpoint record's address is formed where it is used: nothing of a pieced launch stays live through the loops)
+    auto ck_rec = [&]() -> double * { return a.ckpt + ((size_t)sb * a.chains + chain) * (size_t)(4 * NV + 1) * 64; };
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
@@ -382,7 +316,18 @@ k_nuts_duo(NutsArgs a) {
     bind(psp, GV_PSP, ln); bind(psm, GV_PSM, ln); bind(wmean, GV_WMEAN, ln); bind(wm2, GV_WM2, ln); \
     bind(bq, GV_BQ, ln); bind(bg, GV_BG, ln)
     EPX_BIND_COLD(lane);
-    double lps = 0, zlp = 0, plp = 0, mlp = 0, b_key = 0, b_plp = 0;
+    // the scalars that are touched once per transition (COLD: in the chain's global store, see GScal)
+    using CS = typename std::conditional<COLD, GScal, RScal>::type;
+    CS lps, da_mu, s_bar, x_bar, da_count, va_n, eps_sum, acc_sum, depth_sum, nleap_tot, plp, mlp, b_plp, lsw, t_end_c;
+    if constexpr (COLD) {
+        double *sc0 = cold + (size_t)GV_SCAL * NV * 64;
+        lps.p = sc0; da_mu.p = sc0 + 1; s_bar.p = sc0 + 2; x_bar.p = sc0 + 3; da_count.p = sc0 + 4; va_n.p = sc0 + 5;
+        eps_sum.p = sc0 + 6; acc_sum.p = sc0 + 7; depth_sum.p = sc0 + 8; nleap_tot.p = sc0 + 9;
+        plp.p = sc0 + 10; mlp.p = sc0 + 11; b_plp.p = sc0 + 12; lsw.p = sc0 + 13; t_end_c.p = sc0 + 14;
+    }
+    lps = 0.0; plp = 0.0; mlp = 0.0; b_plp = 0.0; lsw = 0.0;
+    t_end_c = (double)t_end;                      // (read once per transition)
+    double zlp = 0, b_key = 0;
     FORV {
         const int e = lane + 64 * i;
         mu.v[i] = e < d ? a.cav_mu[(size_t)k * d + e] : 0.0;
@@ -395,6 +340,7 @@ k_nuts_duo(NutsArgs a) {
     }
     if (resume) {
         // the sample and the Welford sums of the piece before this one (checkpoint record: qs, wmean, wm2, metric, scalars)
+        double *ckp = ck_rec();
         FORV {
             qs.v[i] = ck_load(ckp + (0 * NV + i) * 64 + lane);
             wmean.v[i] = ck_load(ckp + (1 * NV + i) * 64 + lane);
@@ -421,7 +367,8 @@ k_nuts_duo(NutsArgs a) {
     }
     // adaptation state (stepsize_adaptation.hpp / windowed_adaptation.hpp @ Stan 2.17)
     const double DELTA = 0.8, GAMMA = 0.05, T0 = 10.0, KAPPA = 0.75, LOG08 = -0.2231435513142097558;
-    double eps = 1.0, da_mu = log(10.0), s_bar = 0, x_bar = 0, da_count = 0;
+    double eps = 1.0;
+    da_mu = log(10.0); s_bar = 0.0; x_bar = 0.0; da_count = 0.0;
     int va_init_buf = 75, va_term = 50, va_base = 25;
     if (va_init_buf + va_base + va_term > a.warmup && a.warmup >= 20) {
         va_init_buf = (int)(0.15 * a.warmup);
@@ -429,23 +376,17 @@ k_nuts_duo(NutsArgs a) {
         va_base = a.warmup - (va_init_buf + va_term);
     }
     int va_counter = 0, va_wsize = va_base, va_next = va_init_buf + va_base - 1;
-    double va_n = 0;
-    double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
+    va_n = 0.0;
+    eps_sum = 0.0; acc_sum = 0.0; depth_sum = 0.0; nleap_tot = 0.0;
+    double ngrad = 0;
     int ndiv = 0, npost = 0, kept = 0, failed = 0;
     int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
     int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
     uint32_t ss_t = 0;
-    double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;
+    double H0 = 0, sum_metro = 0, eps_l = 0;
     double u_dir = 0.0, gum = 0.0;
     double dhb = 0.0, lw_m = -INFINITY, lw_s = 0.0;
     int bail = 0;
-    if (resume) {
-        if (seg_seen < 0) {                            // the chain failed in its first piece: everything is written
-            *f_job = DUO_EXIT;
-            goto seg_done;
-        }
-        if (seg_seen != t_begin) bail = 1;            // timed out: reported through NutsArgs::err below
-    }
     FORV { zq.v[i] = qs.v[i]; }
     const bool teacher = a.eps_in != nullptr;       // fixed step size / metric (test hook)
     if (teacher) {
@@ -465,15 +406,16 @@ k_nuts_duo(NutsArgs a) {
     }
     if constexpr (COLD) {
         if (resume) {
+            double *ckp = ck_rec();
             FORV inv_e.v[i] = ck_load(ckp + (3 * NV + i) * 64 + lane);
             const double ckv = ck_load(ckp + 4 * NV * 64 + lane);
-#define EPX_CK_GET(idx, x) x = (decltype(x))readlane_d(ckv, idx);
+#define EPX_CK_GET(idx, x) ck_assign(x, readlane_d(ckv, idx));
             EPX_CK_LIST(EPX_CK_GET)
 #undef EPX_CK_GET
             ngrad -= 1.0;                             // the gradient at the restored sample is evaluated once more
             if (failed) {                             // it failed in its first piece, where everything was written
                 *f_job = DUO_EXIT;
-                goto seg_done;
+                return;
             }
         }
     }
@@ -695,7 +637,7 @@ k_nuts_duo(NutsArgs a) {
 #define EPX_DBG_EXIT { leave = 2; parked = 0; break; }
 #define STAMP_LEAF do { } while (0)
 #define EPX_RESUME resume
-#define EPX_T_END t_end
+#define EPX_T_END (int)(double)t_end_c
 #include "nuts_state_machine.inc"
 #undef EPX_RESUME
 #undef EPX_T_END
@@ -904,7 +846,7 @@ k_nuts_duo(NutsArgs a) {
                 if (lane == 0) atomicOr(a.err, 2);
                 *f_mail = DUO_EXIT;
             }
-            goto seg_done;
+            return;
         }
     }
 
@@ -914,11 +856,12 @@ k_nuts_duo(NutsArgs a) {
         if (lane == 0) atomicOr(a.err, 2);
         failed = 2;
     }
-    if (bail & 4) goto seg_done;                       // test hook (a.dbg): lp and gradient are written
+    if (bail & 4) return;                       // test hook (a.dbg): lp and gradient are written
     if constexpr (COLD) {
         if (segmented) {
             // ---- checkpoint at the transition boundary: the sample, the Welford sums, the metric and the scalars of
             // EPX_CK_LIST (the gradient at the sample is re-evaluated by the piece that continues)
+            double *ckp = ck_rec();
             FORV {
                 ck_store(ckp + (0 * NV + i) * 64 + lane, qs.v[i]);
                 ck_store(ckp + (1 * NV + i) * 64 + lane, wmean.v[i]);
@@ -930,13 +873,10 @@ k_nuts_duo(NutsArgs a) {
             EPX_CK_LIST(EPX_CK_PUT)
 #undef EPX_CK_PUT
             ck_store(ckp + 4 * NV * 64 + lane, ckv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record is out before anybody is told
-            if (lane == 0 && !queued)
-                __hip_atomic_store(a.seg_flag + (size_t)sb * a.chains + chain, failed ? -1 : t, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record is out before the site is put back
         }
     }
-    if (!failed && t < a.iter) goto seg_done;          // suspended at the end of a piece: no final record yet
+    if (!failed && t < a.iter) return;          // suspended at the end of a piece: no final record yet
     {
         double *lastp = a.last + ((size_t)k * a.chains + chain) * P;
         FORV { const int e = lane + 64 * i; if (e < P) lastp[e] = qs.v[i]; }
@@ -958,21 +898,100 @@ k_nuts_duo(NutsArgs a) {
             st[ST_FAIL] = failed;
         }
     }
-    }                                                  // (scope of one piece)
-seg_done:
-    if (sg + 1 < sg1) __syncthreads();                 // every wave is done with the LDS image of this site
-    if (queued) {
-        // the site goes back to the pool: progress first, then the claim word (release: the checkpoints are out);
-        // the barrier makes this workgroup's next claim see its own site again
-        if (tid == 0) {
-            __hip_atomic_store(a.dyn_prog + q_site, q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(a.dyn_busy + q_site, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
+}
+#undef a
+
+template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
+__global__ void __launch_bounds__(64 * (CPB * (1 + RW) + (CPB == 1 ? 1 : 0)))
+k_nuts_duo(NutsArgs a_by_value) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    (void)a_by_value;
+    DuoArgsK *kargs_p = (DuoArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    DuoArgsK &a_piece = *kargs_p;
+#define a a_piece
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (!PIECED) {
+        duo_piece<NV, DP, CPB, RW, STL, COLD, false>(kargs_p, tid, false, -1, 0);
+        return;
     }
+    // Piece queue (NutsArgs::dyn_prog; what Master uses at the C3 site size).  The launch has one workgroup per PIECE
+    // (sites x pieces per site); the hardware's dispatcher is the loop: a workgroup claims the site with the largest
+    // predicted REMAINING work (transitions left x predicted leapfrogs per transition) among the sites nobody holds,
+    // runs dyn_len transitions of it, puts it back and ends -- longest remaining processing time first, the
+    // preemptive schedule that ends all sites at about the same time, and it adapts to what the sites really cost.
+    // (A loop over pieces INSIDE the kernel does the same with 256 persistent workgroups, and costs the body its
+    // register allocation: everything is then live around a loop that contains both roles' inner loops, 68 -> 500 B
+    // of scratch per lane and 20 % of the time.  So there is no loop.)
+    // A claim is a compare-and-swap on the site's `busy` word.  There are exactly as many workgroups as pieces, so a
+    // workgroup that finds every unfinished site held waits for one to come back; the holders never wait.
+    int q_site = -1, q_t0 = 0;
+    {
+        // every thread scores the sites tid, tid + 512, ...; wave maxima through LDS; thread 0 tries the
+        // compare-and-swap and everybody reads the outcome (the LDS holds no site at this point)
+        volatile double *sc = reinterpret_cast<volatile double *>(smem);
+        volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
+        for (int attempt = 0; attempt < (1 << 24) && q_site < 0; ++attempt) {
+            double best = -1.0; int arg = -1;
+            for (int s = tid; s < a.dyn_count; s += blockDim.x) {
+                const int pr = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int bz = __hip_atomic_load(a.dyn_busy + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bz == 0 && pr < a.iter) {
+                    // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
+                    // remaining site would get it one at a time)
+                    unsigned hsh = (unsigned)s * 2654435761u ^ ((unsigned)blockIdx.x * 40503u + (unsigned)attempt * 97u) * 2246822519u;
+                    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+                    const double jit = 0.88 + 0.24 * (double)(hsh & 0xFFFF) * (1.0 / 65536.0);
+                    const double sc_s = (double)(a.iter - pr) * (a.dyn_rate ? a.dyn_rate[s] : 1.0) * jit;
+                    if (sc_s > best) { best = sc_s; arg = s; }
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
+                if (ob > best || (ob == best && oa >= 0 && (arg < 0 || oa < arg))) { best = ob; arg = oa; }
+            }
+            if (lane == 0) { sc[wave] = best; si[wave] = arg; }
+            __syncthreads();
+            if (tid == 0) {
+                double b = -1.0; int g = -1;
+                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
+                int got = -2;                                  // -2: every unfinished site is held right now
+                if (g >= 0) {
+                    int expect = 0;
+                    const bool ok = __hip_atomic_compare_exchange_strong(a.dyn_busy + g, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT);
+                    got = ok ? g : -1;                         // -1: somebody was faster, look again
+                }
+                si[16] = got;
+                if (got >= 0) {
+                    si[17] = __hip_atomic_load(a.dyn_prog + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);      // (kept for the release below)
+                    pz[0] = got; pz[1] = si[17];
+                }
+            }
+            __syncthreads();
+            const int got = __builtin_amdgcn_readfirstlane(si[16]);         // (wave-uniform for the compiler, too)
+            if (got >= 0) { q_site = got; q_t0 = __builtin_amdgcn_readfirstlane(si[17]); }
+            __syncthreads();
+            if (got == -2) __builtin_amdgcn_s_sleep(127);          // a piece takes tens of milliseconds: no hurry
+        }
+    }
+    if (q_site < 0) {                                              // (2^24 looks without a site: reported, never seen)
+        if (tid == 0) atomicOr(a.err, 4);
+        return;
+    }
+    duo_piece<NV, DP, CPB, RW, STL, COLD, true>(kargs_p, tid, true, q_site, q_t0);
+    __syncthreads();
+    // the site goes back to the pool: progress first, then the claim word (the checkpoint records are out)
+    if (threadIdx.x == 0) {
+        volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
+        const int r_site = pz[0], r_t0 = pz[1];
+        __hip_atomic_store(a.dyn_prog + r_site, r_t0 + a.dyn_len < a.iter ? r_t0 + a.dyn_len : a.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.dyn_busy + r_site, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+#undef a
 
 // ---------------------------------------------------------------------------
 // host side: LDS layout + dispatch over the instantiated shapes
@@ -997,6 +1016,7 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     const size_t stack = (size_t)cpb * a.max_depth * nuts_stack_record(nv) * 8;
     a.stack_in_lds = 0; a.off_stack = (int)off;
     if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
+    a.off_piece = (int)off; off += 16;
     a.lds_bytes = (int)off;
     return off;
 }
@@ -1016,7 +1036,11 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
         return (int)hipGetLastError();
     };
     constexpr bool COLD = NV >= 2 || CPB > 1;
-    return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true, COLD>) : go(k_nuts_duo<NV, DP, CPB, RW, false, COLD>);
+    if constexpr (COLD && CPB > 1) {
+        if (a.dyn_prog)
+            return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true, COLD, true>) : go(k_nuts_duo<NV, DP, CPB, RW, false, COLD, true>);
+    }
+    return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true, COLD, false>) : go(k_nuts_duo<NV, DP, CPB, RW, false, COLD, false>);
 }
 
 template <int NV, int DP>
@@ -1032,7 +1056,7 @@ bool nuts_duo_has(int cpb, int rw, int dp, int nv) {
 
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream) {
     if (!nuts_duo_has(cpb, rw, dp, nv)) return -1;
-    const int nblocks = (a.seg_off || a.dyn_prog) ? a.seg_nwg : count * ((a.chains + cpb - 1) / cpb);
+    const int nblocks = a.dyn_prog ? a.seg_nwg : count * ((a.chains + cpb - 1) / cpb);
     if (nv == 1) return dp == 16 ? launch_duo_shape<1, 16>(a, nblocks, cpb, rw, stream) : launch_duo_shape<1, 32>(a, nblocks, cpb, rw, stream);
     return dp == 16 ? launch_duo_shape<2, 16>(a, nblocks, cpb, rw, stream) : launch_duo_shape<2, 32>(a, nblocks, cpb, rw, stream);
 }

@@ -285,21 +285,9 @@ class HipEngine(object):
     def last_split(self):
         return int(self.lib.epx_last_split(self.ctx))
 
-    def set_segments(self, pieces=None):
-        """Segmented launch of the resident sampler (include/epx.h: epx_set_segments).  `pieces`: one list per
-        persistent workgroup of (site, t0, t1) -- transitions [t0, t1) of that site, run in list order; None clears."""
-        if not pieces:
-            check(self.lib.epx_set_segments(self.ctx, 0, None, None, None, None))
-            return
-        off = np.zeros(len(pieces) + 1, dtype=np.int32)
-        off[1:] = np.cumsum([len(p) for p in pieces])
-        flat = np.asarray([q for p in pieces for q in p], dtype=np.int32).reshape(-1, 3)
-        site, t0, t1 = (np.ascontiguousarray(flat[:, i]) for i in range(3))
-        check(self.lib.epx_set_segments(self.ctx, len(pieces), off.ctypes.data, site.ctypes.data, t0.ctypes.data, t1.ctypes.data))
-
     def set_piece_queue(self, piece_len=0, rate=None):
-        """Piece queue of the resident sampler (include/epx.h: epx_set_piece_queue): persistent workgroups claim the
-        site with the largest remaining predicted work and run `piece_len` transitions per claim; `rate`: predicted
+        """Piece queue of the resident sampler (include/epx.h: epx_set_piece_queue): one workgroup per piece of
+        `piece_len` transitions, each claiming the site with the largest remaining predicted work; `rate`: predicted
         leapfrogs per transition of every site (None: all equal); piece_len 0 clears."""
         if rate is not None:
             rate = np.ascontiguousarray(rate, dtype=np.float64)

@@ -674,45 +674,6 @@ class Master(object):
         dp = 16 if self.D <= 16 else 32
         return self.D <= 32 and n_max * dp * 8 > 80 * 1024
 
-    @staticmethod
-    def _piece_schedule(work, n_wg, T):
-        """Pieces of a segmented sampling launch (engine.set_segments): `n_wg` persistent workgroups -- one per CU
-        when a site fills the LDS -- with equal predicted work.  McNaughton's wrap-around rule for preemptive
-        scheduling on identical machines: fill the workgroups one after the other up to
-        cap = max(max work, total / n_wg); the site that overflows a workgroup is cut at a transition boundary, its
-        LATE transitions end that workgroup's list and its EARLY transitions head the next one's (they run at time
-        0 there, so the late part never waits long).  At most one cut per workgroup; optimal when the prediction
-        `work` (leapfrogs of the site's slowest chain in the previous EP iteration, spread evenly over its `T`
-        transitions) holds.  Returns None when nothing is gained (fewer sites than workgroups)."""
-        work = np.maximum(np.asarray(work, dtype=np.float64), 1.0)
-        K = work.size
-        if K <= n_wg or T < 2:
-            return None
-        cap = max(work.max(), work.sum() / n_wg) * (1.0 + 1e-9)
-        pieces = [[] for _ in range(n_wg)]
-        w, used = 0, 0.0
-        for k in np.argsort(-work, kind='stable'):
-            wk = work[k]
-            room = cap - used
-            t_cut = 0
-            if wk > room and w + 1 < n_wg:
-                # late part [t_cut, T) here, early part [0, t_cut) at the head of the next workgroup
-                t_cut = T - int(np.rint(T * room / wk))      # (to the nearest transition: the rounding errors cancel)
-                if t_cut >= T:                          # less than one transition fits here: the whole site moves on
-                    w, used, t_cut = w + 1, 0.0, 0
-                elif t_cut <= 0:
-                    t_cut = 0
-                else:
-                    pieces[w].append((int(k), t_cut, T))
-                    w, used = w + 1, 0.0
-            if t_cut > 0:
-                pieces[w].insert(0, (int(k), 0, t_cut))
-                used += wk * t_cut / T
-            else:
-                pieces[w].append((int(k), 0, T))
-                used += wk
-        return [p for p in pieces if p]
-
     def _site_groups(self):
         """Group structure of the sites from `A_k['J']` and `A_n['j_ind']` (the data the
         reference hands to m*b.stan): groups per site and the row limits of all groups.  The
@@ -851,8 +812,8 @@ class Master(object):
                     eng.set_site_split(n_lead)
                     if hasattr(eng, 'set_piece_queue'):
                         # when a site fills the LDS (one workgroup per CU) and there are more sites than CUs: run the
-                        # sampler from a piece queue -- persistent workgroups, sites in pieces of PIECE_LEN transitions,
-                        # largest predicted remaining work first (same draws; only the dispatch changes)
+                        # sampler from a piece queue -- one workgroup per piece of a site's transitions, the site with
+                        # the largest predicted remaining work first (same draws; only the dispatch changes)
                         if eng.last_layout() == 5 and n_lead == 0 and self._one_workgroup_per_cu():
                             it_s = w0.stan_params['iter']
                             lf = eng.get_chain_stats(w0.stan_params['chains'])[:, :, 3]

@@ -317,23 +317,15 @@ int epx_set_site_order(epx_ctx *ctx, const int32_t *order, int count);
  * No reference counterpart. */
 int epx_set_site_split(epx_ctx *ctx, int n_lead);
 int epx_last_split(epx_ctx *ctx);
-/* Segmented launch of the resident sampler (layout 5): the next epx_tilted_batch / epx_sample_batch calls over ALL
- * sites with `iter` == T run n_wg persistent workgroups; workgroup w runs the pieces wg_off[w] .. wg_off[w+1]-1 in
- * order, piece s = transitions [t0[s], t1[s]) of site site[s].  The pieces of a site tile [0, T); a piece that
- * continues another one finds it earlier in its own workgroup or at the HEAD of another one.  A site cut this way
- * gives exactly the draws of the uncut run (checkpoint at a transition boundary); the host uses it to give every CU
- * the same predicted work (Master: McNaughton's wrap-around rule on the previous iteration's leapfrog counts).
- * n_wg <= 0 clears.  No counterpart in the reference (scheduling only). */
-int epx_set_segments(epx_ctx *ctx, int n_wg, const int32_t *wg_off, const int32_t *site, const int32_t *t0, const int32_t *t1);
-/* The same mechanism without lists: with a piece queue set, a sampling call of layout 5 over all sites (more sites
- * than CUs) runs one persistent workgroup per CU; a free workgroup claims the site with the largest predicted
+/* Pieced launch of the resident sampler (layout 5): with a piece queue set, a sampling call over ALL sites runs one
+ * workgroup per PIECE (piece_len transitions of one site); a workgroup claims the site with the largest predicted
  * remaining work (transitions left x rate[site], rate = predicted leapfrogs per transition, NULL = all equal) that
- * nobody holds, runs piece_len transitions of it, puts it back and claims again -- longest remaining processing time
- * first, which ends all sites at about the same time whatever they really cost.  Same draws as the plain launch.
+ * nobody holds, runs its next piece, leaves a checkpoint at the transition boundary and puts the site back -- longest
+ * remaining processing time first, which ends all sites at about the same time whatever they really cost (a launch
+ * of one workgroup per site ends with the CU that drew two heavy sites).  Exactly the draws of the plain launch.
  * piece_len <= 0 clears.  No counterpart in the reference (scheduling only). */
 int epx_set_piece_queue(epx_ctx *ctx, int piece_len, const double *rate);
-/* pieces of the last sampling call: > 0 pieces of a listed launch, < 0 minus the pieces per site of a queued
- * launch, 0: it ran one workgroup per site */
+/* minus the pieces per site of the last sampling call if it ran from the piece queue, 0: one workgroup per site */
 int epx_last_segments(epx_ctx *ctx);
 /* Compute units of the context's device (the host-side scheduling heuristics size themselves by it). */
 int epx_cu_count(epx_ctx *ctx);

@@ -11,7 +11,7 @@ data = mod.simulate_data(Sigma_x='rand', rng=100)
 _, _, Q0, r0 = mod.get_prior()
 M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
            df0=models.default_df0(J), sync_sites=False)
-M._piece_schedule = lambda *a, **k: None
+M.engine.set_piece_queue = lambda *a, **k: None
 hist = []
 orig = M.engine.tilted_batch
 def wrapped(*a, **k):

@@ -1,4 +1,4 @@
-"""Bring-up check of the segmented launch (epx_set_segments): cut sites give the draws of the uncut run."""
+"""Bring-up check of the pieced launch (epx_set_piece_queue): cut sites give the draws of the uncut run."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,18 +15,13 @@ def run(J, D, n, it, pieces):
     seeds = np.arange(J) + 11
     opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=5)
     out = []
-    for p in (None, pieces, None, 'queue'):
-        if p == 'queue':
-            eng.set_segments(None)
-            eng.lib.epx_set_piece_queue.restype = int
-            eng.set_piece_queue(max(1, it // 5), None)
-        else:
-            eng.set_segments(p)
+    for p in (None, 'queue', None, 'queue'):
+        eng.set_piece_queue(max(1, it // 5) if p == 'queue' else 0, None)
         stats, ms = eng.sample_batch(seeds, opts)
         dr = np.stack([eng.get_draws(k, all_params=True) for k in range(J)])
         out.append((dr, eng.get_chain_stats(4).copy(), stats.copy(), ms, eng.last_segments(), eng.last_layout()))
     a, b = out[0], out[1]
-    print('J=%d D=%d n=%d it=%d: plain %.1f ms (layout %d), segmented %.1f ms (%d pieces): draws identical %s, chain stats identical %s, site stats identical %s; third run plain again identical %s'
+    print('J=%d D=%d n=%d it=%d: plain %.1f ms (layout %d), from the piece queue %.1f ms (%d): draws identical %s, chain stats identical %s, site stats identical %s; third run plain again identical %s'
           % (J, D, n, it, a[3], a[5], b[3], b[4], np.array_equal(a[0], b[0]), np.array_equal(a[1], b[1]), np.array_equal(a[2], b[2]),
              np.array_equal(out[2][0], a[0])))
     q = out[3]

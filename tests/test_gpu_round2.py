@@ -483,54 +483,15 @@ def _run(eng, seeds, opts, J):
     return _all_draws(eng, J), eng.get_chain_stats(4).copy(), stats.copy()
 
 
-@pytest.mark.parametrize('D,n', [(16, 200), (32, 500), (12, 90)])
-def test_listed_pieces_give_the_draws_of_the_uncut_launch(D, n):
-    """epx_set_segments: sites cut once, twice, continued in the same and in another workgroup, with warm-up
-    windows and metric updates on either side of a cut (it = 60: windows end at transitions 13 and 26)."""
-    it = 60
-    M, eng, seeds = _pieced_problem(D, n, it)
-    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=5)
-    ref = _run(eng, seeds, opts, 6)
-    assert eng.last_layout() == 5 and eng.last_segments() == 0
-    pieces = [[(0, 0, it)],
-              [(1, 0, 13), (2, 0, it)],
-              [(3, 0, 27), (1, 13, it)],
-              [(4, 0, 1), (3, 27, it)],
-              [(5, 0, it), (4, 1, 30), (4, 30, 59), (4, 59, it)]]
-    eng.set_segments(pieces)
-    got = _run(eng, seeds, opts, 6)
-    assert eng.last_segments() == 11
-    for a, b in zip(ref, got):
-        np.testing.assert_array_equal(a, b)
-    # a warm start from these draws continues identically, and a different `iter` ignores the stale lists
-    eng.set_segments(None)
-    w_ref = _run(eng, seeds + 1, HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=5), 6)
-    eng.set_segments(pieces)
-    _run(eng, seeds, opts, 6)
-    w_got = _run(eng, seeds + 1, HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=5), 6)
-    np.testing.assert_array_equal(w_ref[0], w_got[0])
-    _run(eng, seeds, HipEngine.sampler_opts(chains=4, iter=it // 2, init='random', layout=5), 6)
-    assert eng.last_segments() == 0
-    eng.set_segments(None)
-
-
-def test_piece_lists_are_validated():
-    M, eng, seeds = _pieced_problem(12, 90, 20)
-    for bad, msg in (([[(0, 0, 20)], [(1, 0, 20)]], 'cover'),
-                     ([[(k, 0, 20)] for k in range(5)] + [[(5, 0, 10)], [(5, 11, 20)]], 'do not meet'),
-                     ([[(k, 0, 20)] for k in range(5)] + [[(0, 0, 0)]], 'empty range'),
-                     ([[(k, 0, 20) for k in range(4)], [(4, 0, 20), (5, 0, 9)], [(5, 9, 20)]], 'neither earlier'),
-                     ([[(k, 0, 20)] for k in range(5)] + [[(5, 0, 19)]], 'ends at')):
-        with pytest.raises(_lib.EpxError, match=msg):
-            eng.set_segments(bad)
-
-
-@pytest.mark.parametrize('piece_len,rate', [(7, None), (1, 'skewed'), (25, 'skewed'), (500, None)])
-def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate):
-    """epx_set_piece_queue: persistent workgroups claim sites by largest remaining predicted work and run them
-    piece_len transitions at a time; whatever the claims, the draws are those of one workgroup per site."""
+@pytest.mark.parametrize('piece_len,rate,D,n', [(7, None, 16, 120), (1, 'skewed', 16, 120), (25, 'skewed', 12, 90),
+                                                 (500, None, 16, 120), (13, 'skewed', 32, 500), (26, None, 32, 500)])
+def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate, D, n):
+    """epx_set_piece_queue: one workgroup per piece claims a site by largest remaining predicted work, runs piece_len
+    transitions of it from the checkpoint the piece before left (warm-up windows and metric updates on either side of
+    a cut: it = 50, windows end at transitions 11 and 22), and puts it back; whatever the claims, the draws, the
+    chain and the site statistics are those of one workgroup per site -- also of a warm start from them."""
     it = 50
-    M, eng, seeds = _pieced_problem(16, 120, it, J=9)
+    M, eng, seeds = _pieced_problem(D, n, it, J=9)
     opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=5)
     ref = _run(eng, seeds, opts, 9)
     r = None if rate is None else np.array([9.0, 1.0, 1.0, 5.0, 1.0, 1.0, 2.0, 1.0, 30.0])
@@ -539,9 +500,13 @@ def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate):
     assert eng.last_segments() == -((it + piece_len - 1) // piece_len)
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a, b)
+    warm = HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=5)
+    w_got = _run(eng, seeds + 1, warm, 9)
     eng.set_piece_queue(0)
     _run(eng, seeds, opts, 9)
     assert eng.last_segments() == 0
+    w_ref = _run(eng, seeds + 1, warm, 9)
+    np.testing.assert_array_equal(w_ref[0], w_got[0])
     with pytest.raises(_lib.EpxError, match='not positive'):
         eng.set_piece_queue(5, np.zeros(9))
 

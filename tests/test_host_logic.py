@@ -566,32 +566,3 @@ def test_named_draws_restates_the_transformed_parameters():
     np.testing.assert_allclose(og['beta'][:, 1, :], thg[:, 2:2 + D] + thg[:, 2 * D + 2 + ng + D:] * np.exp(thg[:, 2 + D:2 + 2 * D]))
     with pytest.raises(ValueError):
         sp.named_draws(0, D, 1, False, True, th1, ['etb'])
-
-
-def test_piece_schedule_tiles_every_site_and_never_builds_a_cycle_of_waits():
-    """Master._piece_schedule (McNaughton's wrap-around rule for epx_set_segments): every site's pieces tile its
-    transitions, a continued piece finds its predecessor at the head of another workgroup (or earlier in its own),
-    and the predicted load of a workgroup stays within one transition's worth of the optimum."""
-    from epstan_amd.method import Master
-    rng = np.random.RandomState(3)
-    for trial in range(120):
-        K, n_wg, T = rng.randint(2, 700), rng.randint(1, 300), rng.randint(2, 300)
-        work = rng.gamma(2.0, 1000.0, size=K) + 1.0
-        pieces = Master._piece_schedule(work, n_wg, T)
-        if pieces is None:
-            assert K <= n_wg
-            continue
-        assert len(pieces) <= n_wg
-        seen = {}
-        for w, plist in enumerate(pieces):
-            for i, (k, t0, t1) in enumerate(plist):
-                seen.setdefault(k, []).append((t0, t1, w, i))
-        assert sorted(seen) == list(range(K))
-        for k, v in seen.items():
-            v.sort()
-            assert v[0][0] == 0 and v[-1][1] == T and len(v) <= 2
-            for a, b in zip(v, v[1:]):
-                assert a[1] == b[0] and ((a[2] == b[2] and a[3] < b[3]) or a[3] == 0)
-        load = np.array([sum(work[k] * (t1 - t0) / T for k, t0, t1 in p) for p in pieces])
-        opt = max(work.max(), work.sum() / n_wg)
-        assert load.max() <= opt + 1.5 * work.max() / T + 1e-6 * opt or len(pieces) == n_wg
