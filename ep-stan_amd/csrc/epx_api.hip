@@ -579,6 +579,8 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         a.cpb = 4; wpc = 1;
         a.stack_in_lds = 0; a.om_in_lds = 0;
         a.lds_bytes = (int)nuts_stream_lds_bytes(nv, dp, c->d, c->ng_max, c->nt_max, 0, c->gauss);
+        a.off_piece = a.lds_bytes; a.lds_bytes += 16;       // (site, first transition) of a pieced launch's workgroup
+        a.err = c->err_flag;
         if ((size_t)a.lds_bytes > LDS_CAP) return fail("streaming sampler needs %d B of LDS", a.lds_bytes);
     }
     if (!a.stack_in_lds) {
@@ -618,8 +620,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
     c->last_segments = 0;
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
-    const bool use_queue = c->dyn_len > 0 && layout == 5 && k0 == 0 && count == c->K &&
-                           o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == 5);
+    const bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 3) && k0 == 0 && count == c->K &&
+                           o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
     if (use_queue) {
         HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));
         a.dyn_prog = c->dyn_words; a.dyn_busy = c->dyn_words + count;
@@ -724,7 +726,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     c->last_layout = layout;
     c->nsamp = o.chains * nkeep;
     int herr = 0;
-    if (layout == 5 || layout == 6) HIPCHK(hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (layout == 5 || layout == 6 || use_queue) HIPCHK(hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (herr) {
         HIPCHK(hipMemset(c->err_flag, 0, sizeof(int)));

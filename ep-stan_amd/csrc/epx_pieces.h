@@ -1,0 +1,104 @@
+// Pieced sampler launches (epx_set_piece_queue): what the resident (nuts_duo.hip) and the streaming
+// (nuts_stream.hip) kernels share -- the claim of a site, its release, and the checkpoint record's accessors.
+//
+// The launch has one workgroup per PIECE (dyn_len transitions of one site); the hardware's dispatcher is the loop.
+// A workgroup claims -- compare-and-swap on the site's `busy` word -- the site with the largest predicted REMAINING
+// work (transitions left x predicted leapfrogs per transition) among the sites nobody holds, runs its next piece from
+// the checkpoint the piece before left, writes its own checkpoint, puts the site back and ends: longest remaining
+// processing time first, the preemptive schedule that ends all sites at about the same time, and it adapts to what
+// the sites really cost.  There are exactly as many workgroups as pieces, so a workgroup that finds every unfinished
+// site held waits for one to come back; the holders never wait.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace epx {
+
+// what a chain carries from one piece to the next besides the sample, the Welford sums and the metric (lane, variable)
+#define EPX_CK_LIST(X)                                                                                        \
+    X(0, lps) X(1, eps) X(2, da_mu) X(3, s_bar) X(4, x_bar) X(5, da_count) X(6, va_n) X(7, eps_sum) X(8, acc_sum)  \
+    X(9, depth_sum) X(10, nleap_tot) X(11, ngrad) X(12, t) X(13, va_counter) X(14, va_wsize) X(15, va_next)       \
+    X(16, ndiv) X(17, npost) X(18, kept) X(19, failed)
+
+// A checkpoint travels between CUs of DIFFERENT XCDs, whose L2s do not see each other's lines: it is written and
+// read with agent-scope accesses (write-through / L2-bypassing), so no L2 write-back or invalidation is needed
+__device__ inline void ck_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double ck_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+template <typename T> __device__ inline void ck_assign(T &x, double v) { x = (T)v; }
+
+// doubles of one chain's checkpoint record: sample, Welford mean and sum of squares, metric (nv x 64 each), scalars (64)
+__host__ __device__ constexpr size_t piece_record_doubles(int nv) { return (size_t)(4 * nv + 1) * 64; }
+
+// Claim a site (all threads of the workgroup; the LDS must not hold anything yet: smem[0..1100) is scratch, and
+// (site, first transition) stay at smem + off_piece for piece_release).  Returns false after 2^24 looks without one
+// (never seen; the caller reports it).
+template <class Args>
+__device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int tid, int &q_site, int &q_t0) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    volatile double *sc = reinterpret_cast<volatile double *>(smem);
+    volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
+    q_site = -1; q_t0 = 0;
+    for (int attempt = 0; attempt < (1 << 24) && q_site < 0; ++attempt) {
+        double best = -1.0; int arg = -1;
+        for (int s = tid; s < a.dyn_count; s += blockDim.x) {
+            const int pr = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int bz = __hip_atomic_load(a.dyn_busy + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bz == 0 && pr < a.iter) {
+                // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
+                // remaining site would get it one at a time)
+                unsigned hsh = (unsigned)s * 2654435761u ^ ((unsigned)blockIdx.x * 40503u + (unsigned)attempt * 97u) * 2246822519u;
+                hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+                const double jit = 0.88 + 0.24 * (double)(hsh & 0xFFFF) * (1.0 / 65536.0);
+                const double sc_s = (double)(a.iter - pr) * (a.dyn_rate ? a.dyn_rate[s] : 1.0) * jit;
+                if (sc_s > best) { best = sc_s; arg = s; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
+            if (ob > best || (ob == best && oa >= 0 && (arg < 0 || oa < arg))) { best = ob; arg = oa; }
+        }
+        if (lane == 0) { sc[wave] = best; si[wave] = arg; }
+        __syncthreads();
+        if (tid == 0) {
+            double b = -1.0; int g = -1;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
+            int got = -2;                                  // -2: every unfinished site is held right now
+            if (g >= 0) {
+                int expect = 0;
+                const bool ok = __hip_atomic_compare_exchange_strong(a.dyn_busy + g, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT);
+                got = ok ? g : -1;                         // -1: somebody was faster, look again
+            }
+            si[32] = got;
+            if (got >= 0) {
+                si[33] = __hip_atomic_load(a.dyn_prog + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);      // (kept for the release)
+                pz[0] = got; pz[1] = si[33];
+            }
+        }
+        __syncthreads();
+        const int got = __builtin_amdgcn_readfirstlane(si[32]);         // (wave-uniform for the compiler, too)
+        if (got >= 0) { q_site = got; q_t0 = __builtin_amdgcn_readfirstlane(si[33]); }
+        __syncthreads();
+        if (got == -2) __builtin_amdgcn_s_sleep(127);          // a piece takes tens of milliseconds: no hurry
+    }
+    return q_site >= 0;
+}
+
+// The site goes back to the pool (thread 0, after a workgroup barrier behind the chains' checkpoint stores and their
+// s_waitcnt vmcnt(0)): progress first, then the claim word
+template <class Args>
+__device__ __forceinline__ void piece_release(Args &a, unsigned char *smem) {
+    volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
+    const int r_site = pz[0], r_t0 = pz[1];
+    __hip_atomic_store(a.dyn_prog + r_site, r_t0 + a.dyn_len < a.iter ? r_t0 + a.dyn_len : a.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(a.dyn_busy + r_site, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace epx

@@ -25,6 +25,7 @@
 // Every spin is bounded; a spin that gives up raises NutsArgs::err and ends the chain (the host
 // reports it) instead of hanging the GPU.
 #include "nuts_common.h"
+#include "epx_pieces.h"
 
 #include <type_traits>
 
@@ -39,11 +40,6 @@ namespace epx {
 #endif
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23, DUO_NO_MORE = 1 << 30 };
 enum { DUO_RESTART = 1, DUO_LEAVE = 2 };
-// what a chain carries from one piece of a segmented launch to the next, besides the cold store (lane, variable)
-#define EPX_CK_LIST(X)                                                                                        \
-    X(0, lps) X(1, eps) X(2, da_mu) X(3, s_bar) X(4, x_bar) X(5, da_count) X(6, va_n) X(7, eps_sum) X(8, acc_sum)  \
-    X(9, depth_sum) X(10, nleap_tot) X(11, ngrad) X(12, t) X(13, va_counter) X(14, va_wsize) X(15, va_next)       \
-    X(16, ndiv) X(17, npost) X(18, kept) X(19, failed)          // commands of the bookkeeping wave (CPB == 1)
 
 __device__ inline int duo_wait(const volatile int *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -62,17 +58,6 @@ __device__ inline int duo_wait_ge(const volatile int *flag, int want) {
     }
     return DUO_TIMEOUT;
 }
-// A checkpoint travels between CUs of DIFFERENT XCDs, whose L2s do not see each other's lines: it is written and
-// read with agent-scope accesses (write-through / L2-bypassing), so no L2 write-back or invalidation is needed
-__device__ inline void ck_store(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline double ck_load(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
-}
-template <typename T> __device__ inline void ck_assign(T &x, double v) { x = (T)v; }
 __device__ inline void ck_assign(GScal &x, double v) { x = v; }
 __device__ inline void ck_assign(RScal &x, double v) { x = v; }
 // everything this wave wrote to LDS is visible before the flag that follows
@@ -294,7 +279,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // cached by two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
     double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
     // (the checkpoint record's address is formed where it is used: nothing of a pieced launch stays live through the loops)
-    auto ck_rec = [&]() -> double * { return a.ckpt + ((size_t)sb * a.chains + chain) * (size_t)(4 * NV + 1) * 64; };
+    auto ck_rec = [&]() -> double * { return a.ckpt + ((size_t)sb * a.chains + chain) * piece_record_doubles(NV); };
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
@@ -909,7 +894,7 @@ k_nuts_duo(NutsArgs a_by_value) {
     DuoArgsK *kargs_p = (DuoArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
     DuoArgsK &a_piece = *kargs_p;
 #define a a_piece
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
     if constexpr (!PIECED) {
         duo_piece<NV, DP, CPB, RW, STL, COLD, false>(kargs_p, tid, false, -1, 0);
         return;
@@ -924,71 +909,14 @@ k_nuts_duo(NutsArgs a_by_value) {
     // of scratch per lane and 20 % of the time.  So there is no loop.)
     // A claim is a compare-and-swap on the site's `busy` word.  There are exactly as many workgroups as pieces, so a
     // workgroup that finds every unfinished site held waits for one to come back; the holders never wait.
-    int q_site = -1, q_t0 = 0;
-    {
-        // every thread scores the sites tid, tid + 512, ...; wave maxima through LDS; thread 0 tries the
-        // compare-and-swap and everybody reads the outcome (the LDS holds no site at this point)
-        volatile double *sc = reinterpret_cast<volatile double *>(smem);
-        volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
-        for (int attempt = 0; attempt < (1 << 24) && q_site < 0; ++attempt) {
-            double best = -1.0; int arg = -1;
-            for (int s = tid; s < a.dyn_count; s += blockDim.x) {
-                const int pr = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int bz = __hip_atomic_load(a.dyn_busy + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bz == 0 && pr < a.iter) {
-                    // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
-                    // remaining site would get it one at a time)
-                    unsigned hsh = (unsigned)s * 2654435761u ^ ((unsigned)blockIdx.x * 40503u + (unsigned)attempt * 97u) * 2246822519u;
-                    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
-                    const double jit = 0.88 + 0.24 * (double)(hsh & 0xFFFF) * (1.0 / 65536.0);
-                    const double sc_s = (double)(a.iter - pr) * (a.dyn_rate ? a.dyn_rate[s] : 1.0) * jit;
-                    if (sc_s > best) { best = sc_s; arg = s; }
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
-                if (ob > best || (ob == best && oa >= 0 && (arg < 0 || oa < arg))) { best = ob; arg = oa; }
-            }
-            if (lane == 0) { sc[wave] = best; si[wave] = arg; }
-            __syncthreads();
-            if (tid == 0) {
-                double b = -1.0; int g = -1;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
-                int got = -2;                                  // -2: every unfinished site is held right now
-                if (g >= 0) {
-                    int expect = 0;
-                    const bool ok = __hip_atomic_compare_exchange_strong(a.dyn_busy + g, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_AGENT);
-                    got = ok ? g : -1;                         // -1: somebody was faster, look again
-                }
-                si[16] = got;
-                if (got >= 0) {
-                    si[17] = __hip_atomic_load(a.dyn_prog + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);      // (kept for the release below)
-                    pz[0] = got; pz[1] = si[17];
-                }
-            }
-            __syncthreads();
-            const int got = __builtin_amdgcn_readfirstlane(si[16]);         // (wave-uniform for the compiler, too)
-            if (got >= 0) { q_site = got; q_t0 = __builtin_amdgcn_readfirstlane(si[17]); }
-            __syncthreads();
-            if (got == -2) __builtin_amdgcn_s_sleep(127);          // a piece takes tens of milliseconds: no hurry
-        }
-    }
-    if (q_site < 0) {                                              // (2^24 looks without a site: reported, never seen)
+    int q_site, q_t0;
+    if (!piece_claim(a, smem, tid, q_site, q_t0)) {                // (2^24 looks without a site: reported, never seen)
         if (tid == 0) atomicOr(a.err, 4);
         return;
     }
     duo_piece<NV, DP, CPB, RW, STL, COLD, true>(kargs_p, tid, true, q_site, q_t0);
     __syncthreads();
-    // the site goes back to the pool: progress first, then the claim word (the checkpoint records are out)
-    if (threadIdx.x == 0) {
-        volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
-        const int r_site = pz[0], r_t0 = pz[1];
-        __hip_atomic_store(a.dyn_prog + r_site, r_t0 + a.dyn_len < a.iter ? r_t0 + a.dyn_len : a.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.dyn_busy + r_site, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) piece_release(a, smem);    // the checkpoint records are out: the site goes back to the pool
 }
 
 #undef a

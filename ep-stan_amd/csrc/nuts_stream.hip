@@ -23,6 +23,7 @@
 #include "epx_device.h"
 #include "epx_kernels.h"
 #include "epx_stream_tile.h"
+#include "epx_pieces.h"
 #include <type_traits>
 
 namespace epx {
@@ -65,10 +66,23 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 constexpr int OM_UNROLL = 16;   // columns of Omega in flight per thread
 
 // RES: the resident variant (rows in LDS for the whole site update, 4 chain waves only, D <= 32)
-template <int NV, int DPB, bool RES>
+// PIECED: the launch has one workgroup per piece of a site's transitions (epx_pieces.h); a template parameter so that
+// the plain kernel stays what it was
+template <int NV, int DPB, bool RES, bool PIECED>
 __global__ void __launch_bounds__(RES ? 256 : STREAM_THREADS)
 k_nuts_stream(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
+    int q_site = -1, q_t0 = 0;
+    if constexpr (PIECED) {
+        if (!piece_claim(a, smem, (int)threadIdx.x, q_site, q_t0)) {
+            if (threadIdx.x == 0) atomicOr(a.err, 4);
+            return;
+        }
+    }
+    const bool queued = PIECED;
+    const int t_begin = queued ? q_t0 : 0;
+    const int t_end = queued ? (q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter) : a.iter;
+    const bool resume = t_begin > 0;
     using V = VecS<NV>;
     constexpr int NT = RES ? 256 : STREAM_THREADS;
     // register vectors when they fit (NV <= 2: 23 x 4 VGPRs), cold store otherwise
@@ -80,7 +94,8 @@ k_nuts_stream(NutsArgs a) {
     const int wt = 0;                           // one wave per chain
     const bool is_chain = wave < NCH;
     const int bps = (a.chains + NCH - 1) / NCH;
-    const int sb = a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps), cb = blockIdx.x % bps;
+    const int sb = queued ? q_site : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps));
+    const int cb = queued ? 0 : blockIdx.x % bps;
     const int k = a.k0 + sb;
     const int chain = cb * NCH + (is_chain ? wave : 0);
     const bool active = is_chain && chain < a.chains;
@@ -157,7 +172,10 @@ k_nuts_stream(NutsArgs a) {
     if constexpr (RES) {
         if (a.om_in_lds) { for (int i = tid; i < d * d; i += NT) Om_s[i] = Om_g[i]; }
     }
-    const size_t chain_slot = (size_t)sb * a.chains + (active ? chain : 0);
+    // (pieced launches: tree stack and cold store belong to the WORKGROUP, so that no line of them is ever cached by the
+    // L2s of two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
+    const size_t chain_slot = (size_t)(queued ? (int)blockIdx.x : sb) * a.chains + (active ? chain : 0);
+    double *ckp = queued ? a.ckpt + ((size_t)sb * a.chains + (active ? chain : 0)) * piece_record_doubles(NV) : nullptr;
     // wave-uniform base pointers (held in scalar registers; lanes add lane*8)
     auto uniform_ptr = [](double *p) -> double * {
         const unsigned long long u = (unsigned long long)p;
@@ -203,8 +221,16 @@ k_nuts_stream(NutsArgs a) {
                     q0 = -2.0 + 4.0 * ((e & 1) ? u2 : u1);
                 }
             }
+            if (resume) {
+                // the sample and the Welford sums of the piece before this one
+                q0 = ck_load(ckp + (0 * NV + i) * 64 + lane0);
+                wmean.v[i] = ck_load(ckp + (1 * NV + i) * 64 + lane0);
+                wm2.v[i] = ck_load(ckp + (2 * NV + i) * 64 + lane0);
+            } else {
+                wmean.v[i] = 0.0; wm2.v[i] = 0.0;
+            }
             zq.v[i] = q0;
-            qs.v[i] = q0; wmean.v[i] = 0.0; wm2.v[i] = 0.0;
+            qs.v[i] = q0;
         }
     }
     const double DELTA = 0.8, GAMMA = 0.05, T0 = 10.0, KAPPA = 0.75, LOG08 = -0.2231435513142097558;
@@ -242,6 +268,17 @@ k_nuts_stream(NutsArgs a) {
         const double *cm = a.carry_metric + (size_t)k * a.P;
         FORV { const int e = lane0 + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
     }
+    int finished = active ? 0 : 1;
+    if (resume && active) {
+        FORV inv_e.v[i] = ck_load(ckp + (3 * NV + i) * 64 + lane0);
+        const double ckv = ck_load(ckp + 4 * NV * 64 + lane0);
+#define EPX_CK_GET(idx, x) ck_assign(x, readlane_d(ckv, idx));
+        EPX_CK_LIST(EPX_CK_GET)
+#undef EPX_CK_GET
+        ngrad -= 1.0;                                 // the gradient at the restored sample is evaluated once more
+        if (failed) finished = 1;                     // it failed in its first piece, where everything was written
+    }
+    const bool was_failed = resume && failed != 0;
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
 
     auto flush_dh = [&](int cnt) {
@@ -261,7 +298,7 @@ k_nuts_stream(NutsArgs a) {
         sum_metro += me;
     };
 
-    int finished = active ? 0 : 1, counted = is_chain ? 0 : 1;
+    int counted = is_chain ? 0 : 1;
 #ifdef EPX_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -488,7 +525,11 @@ k_nuts_stream(NutsArgs a) {
 #define EPX_CHAIN_EXIT { finished = 1; eps_l = 0.0; continue; }
 #define EPX_DBG_EXIT { finished = 1; eps_l = 0.0; continue; }
 #define STAMP_LEAF STAMP(6)
+#define EPX_RESUME resume
+#define EPX_T_END t_end
 #include "nuts_state_machine.inc"
+#undef EPX_RESUME
+#undef EPX_T_END
 #undef STAMP_LEAF
 #undef EPX_CHAIN_EXIT
 #undef EPX_DBG_EXIT
@@ -502,7 +543,27 @@ k_nuts_stream(NutsArgs a) {
     }
 #endif
     // ------------------------------------------------------------- epilogue
-    if (active && !a.dbg) {
+    if constexpr (PIECED) {
+        if (active && !a.dbg && !was_failed) {
+            // checkpoint at the transition boundary: the sample, the Welford sums, the metric and the scalars of
+            // EPX_CK_LIST (the gradient at the sample is re-evaluated by the piece that continues)
+            FORV {
+                ck_store(ckp + (0 * NV + i) * 64 + lane0, qs.v[i]);
+                ck_store(ckp + (1 * NV + i) * 64 + lane0, wmean.v[i]);
+                ck_store(ckp + (2 * NV + i) * 64 + lane0, wm2.v[i]);
+                ck_store(ckp + (3 * NV + i) * 64 + lane0, inv_e.v[i]);
+            }
+            double ckv = 0.0;
+#define EPX_CK_PUT(idx, x) ckv = lane0 == (idx) ? (double)(x) : ckv;
+            EPX_CK_LIST(EPX_CK_PUT)
+#undef EPX_CK_PUT
+            ck_store(ckp + 4 * NV * 64 + lane0, ckv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record is out before the site is put back
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) piece_release(a, smem);
+    }
+    if (active && !a.dbg && !was_failed && (failed || t >= a.iter)) {
         double *lastp = a.last + ((size_t)k * a.chains + chain) * a.P;
         FORV { const int e = lane0 + 64 * i; if (e < a.P) lastp[e] = qs.v[i]; }
         if (failed) {
@@ -544,7 +605,8 @@ size_t nuts_stream_chain_doubles(int nv, int max_depth) {
 
 template <int NV, int DPB, bool RES>
 static int launch_stream_one(const NutsArgs &a, int nblocks, size_t lds, hipStream_t stream) {
-    auto kern = k_nuts_stream<NV, DPB, RES>;
+    auto kern = k_nuts_stream<NV, DPB, RES, false>;
+    if constexpr (!RES) { if (a.dyn_prog) { kern = k_nuts_stream<NV, DPB, RES, true>; nblocks = a.seg_nwg; } }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -571,8 +633,7 @@ static int launch_stream_nv(const NutsArgs &a, int nblocks, int nv, size_t lds, 
 int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_t stream) {
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
-    const bool res = dpb <= 32;
-    const size_t lds = res ? (size_t)a.lds_bytes : nuts_stream_lds_bytes(nv, dpb, a.d, a.ngmax, a.ntmax, 0, a.gauss);
+    const size_t lds = (size_t)a.lds_bytes;          // (the host laid it out: nuts_stream_lds_bytes + the piece words)
     if (dpb == 16) return launch_stream_nv<16, true>(a, nblocks, nv, lds, stream);
     if (dpb == 32) return launch_stream_nv<32, true>(a, nblocks, nv, lds, stream);
     if (dpb == 64) return launch_stream_nv<64, false>(a, nblocks, nv, lds, stream);

@@ -669,10 +669,12 @@ class Master(object):
 
     def _one_workgroup_per_cu(self):
         """The resident sampler keeps a site's rows (padded to 16 / 32 columns) in LDS: above half of the 160 KB
-        only one workgroup fits a CU, and a persistent launch of one workgroup per CU loses nothing."""
+        only one workgroup fits a CU; the streaming sampler (D > 32, or rows beyond the LDS) always fills it.  Then
+        a launch of one workgroup per PIECE loses nothing to occupancy."""
         n_max = int(np.max(np.diff(self.k_lim[self.k_lo:self.k_hi + 1])))
-        dp = 16 if self.D <= 16 else 32
-        return self.D <= 32 and n_max * dp * 8 > 80 * 1024
+        if self.D > 32:
+            return True
+        return n_max * (16 if self.D <= 16 else 32) * 8 > 80 * 1024
 
     def _site_groups(self):
         """Group structure of the sites from `A_k['J']` and `A_n['j_ind']` (the data the
@@ -814,7 +816,7 @@ class Master(object):
                         # when a site fills the LDS (one workgroup per CU) and there are more sites than CUs: run the
                         # sampler from a piece queue -- one workgroup per piece of a site's transitions, the site with
                         # the largest predicted remaining work first (same draws; only the dispatch changes)
-                        if eng.last_layout() == 5 and n_lead == 0 and self._one_workgroup_per_cu():
+                        if eng.last_layout() in (5, 3) and n_lead == 0 and self._one_workgroup_per_cu():
                             it_s = w0.stan_params['iter']
                             lf = eng.get_chain_stats(w0.stan_params['chains'])[:, :, 3]
                             eng.set_piece_queue(max(1, it_s // self.PIECES_PER_SITE), np.maximum(lf.max(axis=1), 1.0) / it_s)

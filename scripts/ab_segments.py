@@ -6,8 +6,9 @@ from epstan_amd import models
 from epstan_amd.method import Master
 nit = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 J = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-mod = models.m4b(J, 32, 500)
-data = mod.simulate_data(Sigma_x='rand', rng=100)
+shape = os.environ.get('AB_SHAPE', 'c3')
+mod = models.m4b(J, 32, 500) if shape == 'c3' else models.m4b(J, 128, 2000)
+data = mod.simulate_data(Sigma_x='rand', rng=100) if shape == 'c3' else mod.simulate_data(rng=100)
 _, _, Q0, r0 = mod.get_prior()
 res = {}
 pp = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [8]
@@ -24,4 +25,4 @@ for tag in ['plain'] + ['segmented%d' % x for x in pp]:
     del M
 for x in pp:
     r = res['segmented%d' % x]
-    print('%d pieces per site: same global Q %s, time / plain over iterations 4..: %.3f' % (x, np.array_equal(res['plain'][1], r[1]), r[0][3:].sum() / res['plain'][0][3:].sum()))
+    print('%d pieces per site: same global Q %s, time / plain over iterations 4..: %.3f' % (x, np.array_equal(res['plain'][1], r[1]), r[0][min(3, nit - 1):].sum() / res['plain'][0][min(3, nit - 1):].sum()))

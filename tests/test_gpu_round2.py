@@ -511,6 +511,32 @@ def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate, D, n):
         eng.set_piece_queue(5, np.zeros(9))
 
 
+@pytest.mark.parametrize('model,D,n,piece_len', [('m4b', 40, 260, 9), ('m4b', 70, 150, 50), ('m1b', 40, 300, 1)])
+def test_piece_queue_on_the_streaming_layout(model, D, n, piece_len):
+    """The same mechanism in k_nuts_stream (rows streamed from HBM, the four chains of a site in lock step): a piece
+    ends when every chain of the site has reached the boundary; draws and statistics equal the uncut launch's."""
+    it, J = 36, 7
+    mod = models.MODELS[model](J, D, n)
+    data = mod.simulate_data(rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=it)
+    eng, seeds = M.engine, np.arange(J) + 5
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random')
+    ref = _run(eng, seeds, opts, J)
+    assert eng.last_layout() == 3 and eng.last_segments() == 0
+    eng.set_piece_queue(piece_len, np.linspace(1.0, 3.0, J))
+    got = _run(eng, seeds, opts, J)
+    assert eng.last_layout() == 3 and eng.last_segments() == -((it + piece_len - 1) // piece_len)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    warm = HipEngine.sampler_opts(chains=4, iter=it, init='prev')
+    w_got = _run(eng, seeds + 1, warm, J)
+    eng.set_piece_queue(0)
+    _run(eng, seeds, opts, J)
+    w_ref = _run(eng, seeds + 1, warm, J)
+    np.testing.assert_array_equal(w_ref[0], w_got[0])
+
+
 def test_ep_with_the_piece_queue_equals_ep_without(monkeypatch):
     """Master at a site size that fills the LDS and more sites than CUs runs its launches from the piece queue: the
     whole EP trajectory equals the one-workgroup-per-site run (the dispatch does not touch a single draw)."""
