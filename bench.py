@@ -37,7 +37,7 @@ CONFIGS = {
     # name: (sites per GPU, D, n_j, correlated covariates, default steps, default warm-up)
     'c2': (64, 16, 200, 1, 20, 5),
     'c3': (512, 32, 500, 1, 8, 5),
-    'c5shard': (512, 128, 2000, 0, 1, 1),
+    'c5shard': (512, 128, 2000, 0, 2, 2),
 }
 
 

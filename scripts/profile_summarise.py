@@ -66,7 +66,7 @@ for name in ('c2', 'c3', 'stream'):
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
                                    os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.csv' % (tag, name))])
     warmup, key = {'c2': (1, [64, 16, 200, 'm4b', 4, 200]), 'c3': (5, [512, 32, 500, 'm4b', 4, 200]),
-                   'stream': (1, [512, 128, 2000, 'm4b', 4, 200])}[name]
+                   'stream': (2, [512, 128, 2000, 'm4b', 4, 200])}[name]
     f, f_it, f_ms = pmc_sums(name + '_fetch', warmup)
     w, w_it, w_ms = pmc_sums(name + '_write', warmup)
     for kind in ('fetch', 'write'):

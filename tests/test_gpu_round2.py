@@ -558,3 +558,27 @@ def test_ep_with_the_piece_queue_equals_ep_without(monkeypatch):
     assert out[0][2] == -8 and out[1][2] == 0
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('D,n,layout', [(16, 120, 5), (40, 150, 3)])
+def test_piece_queue_with_a_chain_that_fails_at_its_start(D, n, layout):
+    """A site whose density is not finite at the initial point fails in its FIRST piece, where its draws and its
+    statistics are written; the later pieces of that site find the mark in the checkpoint record and end at once.
+    Everything -- the failed site's record included -- equals the uncut launch."""
+    it, J = 30, 9
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(rng=100)
+    X = data.X.copy()
+    X[int(np.cumsum(data.Nj)[3]) + 2, 1] = np.nan          # one row of site 4
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=it)
+    eng, seeds = M.engine, np.arange(J) + 3
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=layout)
+    ref = _run(eng, seeds, opts, J)
+    assert eng.last_layout() == layout
+    assert np.all(ref[1][4, :, 7] > 0) and np.all(np.delete(ref[1], 4, axis=0)[:, :, 7] == 0)
+    eng.set_piece_queue(7, None)
+    got = _run(eng, seeds, opts, J)
+    assert eng.last_segments() == -5
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
