@@ -85,7 +85,11 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
         const int got = __builtin_amdgcn_readfirstlane(si[32]);         // (wave-uniform for the compiler, too)
         if (got >= 0) { q_site = got; q_t0 = __builtin_amdgcn_readfirstlane(si[33]); }
         __syncthreads();
-        if (got == -2) __builtin_amdgcn_s_sleep(127);          // a piece takes tens of milliseconds: no hurry
+        if (got == -2) {
+            // every unfinished site is held: a piece takes tens of milliseconds, so look again in ~0.2 ms (hundreds of
+            // waiting workgroups polling the site words at full speed would be felt by the pieces that still run)
+            for (int z = 0; z < 64; ++z) __builtin_amdgcn_s_sleep(127);
+        }
     }
     return q_site >= 0;
 }

@@ -64,7 +64,8 @@ typedef struct epx_sampler_opts {
                             chosen automatically when the rows do not fit LDS or D > 32), 4 lock step with
                             the rows resident in LDS (D <= 32; default for multi-group sites), 5 one block per
                             site with a state wave + a row wave per chain (the default for batches that fill
-                            the chip; same draws as 1), 6 one block per chain with a state wave + 4 row waves */
+                            the chip; same draws as 1), 6 one block per chain: state wave, two row waves and
+                            a bookkeeping wave) */
     int32_t reserved;    /* flags; bit 0: layout 2 without the speculative bookkeeping wave (same draws,
                             used for A/B measurements and tests);
                             bit 1: `adapt = carry` -- NOT the reference's behaviour (a fresh model.sampling per site
