@@ -33,6 +33,9 @@ namespace epx {
 
 // s_setprio levels (A/B, scripts/ab_duo.py): with the critical-path shortcut the state wave is the longer of the
 // two, so the row wave must NOT outrank it (row wave 2 / state wave 0: 1 390 ms; all equal: 1 175 ms per launch)
+#ifndef EPX_DUO_SLEEP
+#define EPX_DUO_SLEEP 1
+#endif
 #ifndef EPX_PRIO_R
 #define EPX_PRIO_R 0
 #define EPX_PRIO_S_BG 0
@@ -45,7 +48,7 @@ __device__ inline int duo_wait(const volatile int *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
         const int v = __builtin_amdgcn_readfirstlane(*flag);
         if (v == want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
     }
     return DUO_TIMEOUT;
 }
@@ -54,7 +57,7 @@ __device__ inline int duo_wait_ge(const volatile int *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
         const int v = __builtin_amdgcn_readfirstlane(*flag);
         if (v >= want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
     }
     return DUO_TIMEOUT;
 }
