@@ -33,6 +33,9 @@ namespace epx {
 
 // s_setprio levels (A/B, scripts/ab_duo.py): with the critical-path shortcut the state wave is the longer of the
 // two, so the row wave must NOT outrank it (row wave 2 / state wave 0: 1 390 ms; all equal: 1 175 ms per launch)
+#ifndef EPX_ROW_IMM
+#define EPX_ROW_IMM 0            // 1: full rounds of the row pass by ds_read_b128 with immediate row offsets (A/B)
+#endif
 #ifndef EPX_DUO_SLEEP
 #define EPX_DUO_SLEEP 1
 #endif
@@ -93,6 +96,9 @@ typedef const __attribute__((address_space(4))) NutsArgs DuoArgsK;       // the 
 // One piece of a chain's run: transitions [t_begin, t_end) of one site by the waves of one workgroup (the whole run
 // in a plain launch).  PIECED is a template parameter because the piece loop around this body costs it its register
 // allocation (76 -> 500 B of scratch per lane, 15 % of the time): the plain launch keeps the kernel without the loop.
+typedef double lds_v2f64 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_v2f64 *lds_v2f64_p;
+
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
 __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queued, int q_site, int q_t0) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -198,6 +204,11 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             for (int r = wr * 64 + lane; r < n; r += 64 * RW, ++it)
                 if (a.y[row0 + r]) ybits |= 1ull << it;
         }
+        // LDS byte address of this lane's first row with the row's swizzle in the slot bits: slot jp of the
+        // row sits at xa ^ (jp << 4) (a row starts on a multiple of its size: the slot bits of its base are 0)
+        const unsigned xa = (unsigned)(size_t)Xs + (unsigned)(wr * 64 + lane) * (DP * 8) +
+                            (unsigned)((((wr * 64 + lane) / RPL) & (SPR - 1)) << 4);
+        (void)xa;
         STAMP_INIT;
         // the row pass is the longest link of a leapfrog's critical chain: it wins the SIMD's issue arbitration
         // against the state wave (of another chain) it shares the SIMD with, whose bookkeeping has slack
@@ -227,8 +238,55 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             unsigned long long yb = ybits;
             // two rows per round: their logistic terms (a chain of ~25 dependent FP64 operations each)
             // overlap; the sums still take the rows in order, so every value equals the row-by-row loop's.
-            // A lane whose second row is beyond n re-reads its first row and adds zeros.
-            for (int r = wr * 64 + lane; r < n; r += 2 * 64 * RW) {
+            auto round2 = [&](const double (&x0)[DP], const double (&x1)[DP], bool two) {
+                double fa0 = alpha, fa1 = 0.0, fb0 = alpha, fb1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < DP; j += 2) {
+                    fa0 = fma(x0[j], bs[j], fa0); fa1 = fma(x0[j + 1], bs[j + 1], fa1);
+                    fb0 = fma(x1[j], bs[j], fb0); fb1 = fma(x1[j + 1], bs[j + 1], fb1);
+                }
+                const double fa = fa0 + fa1, fb = fb0 + fb1;
+                double la, wa, ga, lb, wb, gb;
+                logistic_split2(fa, fb, (double)(yb & 1ull), (double)((yb >> 1) & 1ull), la, lb, wa, wb, ga, gb);
+                yb >>= 2;
+                lb = two ? lb : 0.0; wb = two ? wb : 1.0; gb = two ? gb : 0.0;
+                ll += la; wprod *= wa; da += ga;
+                ll += lb; wprod *= wb; da += gb;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) acc[j] = fma(gb, x1[j], fma(ga, x0[j], acc[j]));
+            };
+            int r = wr * 64 + lane;
+            if constexpr (RW == 1 && EPX_ROW_IMM) {
+                // Rounds whose 128 rows all exist: the swizzle of a row depends on r mod 16 only and r advances by
+                // multiples of 64, so slot jp of every row of this lane is `xa ^ (jp << 4)` plus a compile-time
+                // distance: one XOR per slot and round, `ds_read_b128 v, vaddr offset:imm` for both rows.
+                constexpr unsigned ROWB = DP * 8, RNDB = 128 * ROWB, HALF = 64 * ROWB;
+                constexpr int GR = 65536 / RNDB;                 // rounds per 64 KB (2 at DP = 32, 4 at DP = 16)
+                const int nfull = n >> 7;
+                for (int g0 = 0; g0 < nfull; g0 += GR) {
+                    const unsigned adv = (unsigned)g0 * RNDB;
+#pragma unroll
+                    for (int gg = 0; gg < GR; ++gg) {
+                        if (g0 + gg < nfull) {
+                            unsigned ab = xa + adv;
+                            asm volatile("" : "+v"(ab));        // the 16 slot addresses are re-derived per round, not kept
+                            double x0[DP], x1[DP];
+#pragma unroll
+                            for (int jp = 0; jp < SPR; ++jp) {
+                                const uintptr_t t = (uintptr_t)(ab ^ (unsigned)(jp << 4));
+                                const lds_v2f64 v = *reinterpret_cast<const lds_v2f64_p>(t + gg * RNDB);
+                                const lds_v2f64 w = *reinterpret_cast<const lds_v2f64_p>(t + gg * RNDB + HALF);
+                                x0[2 * jp] = v.x; x0[2 * jp + 1] = v.y;
+                                x1[2 * jp] = w.x; x1[2 * jp + 1] = w.y;
+                            }
+                            round2(x0, x1, true);
+                        }
+                    }
+                }
+                r += nfull << 7;
+            }
+            // the other rounds.  A lane whose second row is beyond n re-reads its first row and adds zeros.
+            for (; r < n; r += 2 * 64 * RW) {
                 const int r1 = r + 64 * RW;
                 const bool two = r1 < n;
                 const int r1c = two ? r1 : r;
@@ -246,21 +304,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     const double2 v = row1p[jp ^ sw1];
                     x1[2 * jp] = v.x; x1[2 * jp + 1] = v.y;
                 }
-                double fa0 = alpha, fa1 = 0.0, fb0 = alpha, fb1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < DP; j += 2) {
-                    fa0 = fma(x0[j], bs[j], fa0); fa1 = fma(x0[j + 1], bs[j + 1], fa1);
-                    fb0 = fma(x1[j], bs[j], fb0); fb1 = fma(x1[j + 1], bs[j + 1], fb1);
-                }
-                const double fa = fa0 + fa1, fb = fb0 + fb1;
-                double la, wa, ga, lb, wb, gb;
-                logistic_split2(fa, fb, (double)(yb & 1ull), (double)((yb >> 1) & 1ull), la, lb, wa, wb, ga, gb);
-                yb >>= 2;
-                lb = two ? lb : 0.0; wb = two ? wb : 1.0; gb = two ? gb : 0.0;
-                ll += la; wprod *= wa; da += ga;
-                ll += lb; wprod *= wb; da += gb;
-#pragma unroll
-                for (int j = 0; j < DP; ++j) acc[j] = fma(gb, x1[j], fma(ga, x0[j], acc[j]));
+                round2(x0, x1, two);
             }
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
