@@ -527,18 +527,23 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     if (layout == 4 && !lock) layout = 0;
     // layouts 5 / 6 (nuts_duo.hip): row waves + a state wave per chain, LDS hand-offs.  5 = one workgroup per
     // site (up to 4 chains), the default for batches that fill the chip; 6 = one workgroup per chain with 4 row waves
+    // Few sites, models with per-coefficient scales (m4b / m5b): layout 6 by default -- its state wave runs from the
+    // "view" alone (nuts_duo.hip), 374 against 413 ms per C2 iteration of layout 2; the other models stay on layout 2
+    // (only when every chain has a CU of its own: the regime where a launch is as long as its slowest chain)
+    const bool auto6 = layout == 0 && !many && c->model >= EPX_M4B_SG && count * o.chains <= c->n_cu;
     if (!lock && !c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
-        (layout == 5 || layout == 6 || (layout == 0 && many))) {
-        const int cpb = layout == 6 ? 1 : 4, rw = layout == 6 ? 2 : 1;
+        (layout == 5 || layout == 6 || (layout == 0 && many) || auto6)) {
+        const bool six = layout == 6 || auto6;
+        const int cpb = six ? 1 : 4, rw = six ? 2 : 1;
         NutsArgs t = a;
         const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
         // (layout 6: one chain per workgroup, the bookkeeping wave's stack lives in LDS or the layout is not used)
         const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP && (c->n_max + 64 * rw - 1) / (64 * rw) <= 64 &&
-                          (layout != 6 || t.stack_in_lds);
+                          (!six || t.stack_in_lds);
         if (fits) {
             a = t;
             a.err = c->err_flag;
-            layout = layout == 6 ? 6 : 5;
+            layout = six ? 6 : 5;
             {
                 a.stack_stride = nuts_resident_chain_doubles(nv, o.max_depth);
                 const size_t need = (size_t)stack_sites * o.chains * a.stack_stride;

@@ -20,7 +20,9 @@ namespace epx {
     X(16, ndiv) X(17, npost) X(18, kept) X(19, failed)
 
 // A checkpoint travels between CUs of DIFFERENT XCDs, whose L2s do not see each other's lines: it is written and
-// read with agent-scope accesses (write-through / L2-bypassing), so no L2 write-back or invalidation is needed
+// read with agent-scope accesses, the writer RELEASES at agent scope before the site is put back (piece_checkpoint_out)
+// and the claimer ACQUIRES after the claim (piece_claim): without the acquire a site that comes back to an XCD it has
+// been on earlier in the launch can hit that XCD's L2 copy of its OLDER record (seen as a rare wrong trajectory)
 __device__ inline void ck_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -91,7 +93,14 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
             for (int z = 0; z < 64; ++z) __builtin_amdgcn_s_sleep(127);
         }
     }
+    // acquire at agent scope: this XCD's L2 may hold an older record of the site (from a piece that ran here earlier)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return q_site >= 0;
+}
+
+// After a chain's checkpoint stores (every wave that wrote one): out of this XCD's L2 before anybody is told
+__device__ __forceinline__ void piece_checkpoint_out() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // The site goes back to the pool (thread 0, after a workgroup barrier behind the chains' checkpoint stores and their

@@ -36,6 +36,9 @@ namespace epx {
 #ifndef EPX_ROW_IMM
 #define EPX_ROW_IMM 0            // 1: full rounds of the row pass by ds_read_b128 with immediate row offsets (A/B)
 #endif
+#ifndef EPX_PUBLISH_NOWAIT
+#define EPX_PUBLISH_NOWAIT 0
+#endif
 #ifndef EPX_DUO_SLEEP
 #define EPX_DUO_SLEEP 1
 #endif
@@ -68,7 +71,12 @@ __device__ inline void ck_assign(GScal &x, double v) { x = v; }
 __device__ inline void ck_assign(RScal &x, double v) { x = v; }
 // everything this wave wrote to LDS is visible before the flag that follows
 __device__ inline void duo_publish(volatile int *flag, int v) {
+#if EPX_PUBLISH_NOWAIT
+    // the LDS serves the instructions of one wave in order: the flag's store is performed behind the data's
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     *flag = v;
 }
 
@@ -110,15 +118,19 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     constexpr int RPL = DP >= 32 ? 1 : 32 / DP;       // rows per 256-B bank line
     constexpr int SREC = nuts_stack_record(NV);       // per-level stack record (doubles)
     constexpr int RES = DP + 2;                       // result of a row wave: X'g (DP), sum g, log-lik
-    constexpr int JOB = RW == 1 ? 0 : DP + 2;         // job (alpha, beta): its own slot, or (RW == 1) the result's
+    constexpr int JOB = 0;                            // job (alpha, beta): the head of the chain's slot ...
+    // One chain per workgroup (RW > 1): [job RES | v = phi - mu (NV x 64) | per row wave: X'g, sum g, log-lik (RES) |
+    // Omega v (NV x 64)] -- the cavity term is taken off the state wave, the longest role of this form, by a wave of
+    // its own (O) that works beside the row waves
+    constexpr int VOFF = RES, RREC = RES, RESO = RES + NV * 64, OVOFF = RESO + RW * RREC;
     // One chain per workgroup (CPB == 1): the tree bookkeeping gets a wave of its own (BK), as in k_nuts_spec --
     // the state wave integrates on speculatively and hands every finished state over through a two-entry mailbox;
     // BK answers with a control record only when the trajectory continues elsewhere (other tree end, new
     // transition, step-size trial): generation-numbered, states of an old generation are dropped.
     constexpr bool BKW = CPB == 1;
-    constexpr int MREC = 3 * NV * 64 + 4 + 64;        // mailbox entry: q, p, grad, ll, -, generation, -, per-lane lp terms
+    constexpr int MREC = 4 * NV * 64 + 4;             // mailbox entry: q, p, grad, per-element log-density terms; ll, -, generation, -
     constexpr int CREC = 4 * NV * 64 + 4;             // control record: q, p, grad, metric, eps_l, command
-    constexpr int NFLAG = 1 + RW + (BKW ? 3 : 0);     // per chain: job, results, (mail, acknowledged, control generation)
+    constexpr int NFLAG = 1 + RW + (BKW ? 4 : 0);     // per chain: job, results, (mail, acknowledged, control generation, cavity term)
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // waves 0..CPB-1: state wave of chain c; then the row waves.  A workgroup's waves go to the SIMDs
@@ -127,10 +139,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // A piece that ends before the chain's last transition (pieced launch) leaves a checkpoint record; the piece that
     // continues it restores, re-evaluates the gradient at the current sample (the same arithmetic on the same position:
     // the same bits) and goes on.  Same draws as the plain launch.
-    const bool is_state = wave < CPB;
-    const bool is_bk = BKW && wave == CPB * (1 + RW);
-    const int team = is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB;
-    const int wr = is_state ? 0 : (wave - CPB) % RW;
+    // (one chain per workgroup: wave 0 bookkeeping, 1 state, 2 .. 1 + RW rows, 2 + RW cavity term -- waves w and w + 4
+    // share a SIMD: the bookkeeping and the cavity-term wave; measured against state + cavity term on one: 374 vs 382 ms
+    // per C2 iteration)
+    const bool is_state = BKW ? wave == 1 : wave < CPB;
+    const bool is_bk = BKW && wave == 0;
+    const bool is_om = BKW && wave == 2 + RW;
+    const int team = BKW ? 0 : (is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB);
+    const int wr = BKW ? (wave >= 2 && wave < 2 + RW ? wave - 2 : 0) : (is_state ? 0 : (wave - CPB) % RW);
     const int bps = (a.chains + CPB - 1) / CPB;
     const bool segmented = queued;
     const int sb = queued ? q_site : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps));
@@ -156,10 +172,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     double *slot = reinterpret_cast<double *>(smem + a.off_slot) + (size_t)team * a.slot_doubles;
     volatile int *flags = reinterpret_cast<volatile int *>(smem + a.off_flag) + team * NFLAG;
     volatile int *f_job = flags, *f_res = flags + 1;
-    volatile int *f_mail = flags + 1 + RW, *f_ack = f_mail + 1, *f_ctl = f_mail + 2;
+    volatile int *f_mail = flags + 1 + RW, *f_ack = f_mail + 1, *f_ctl = f_mail + 2, *f_ov = f_mail + 3;
     double *mbox = reinterpret_cast<double *>(smem + a.off_spec);     // BKW: 2 x MREC, then 2 x CREC
     double *ctrl = mbox + 2 * MREC;
-    (void)f_mail; (void)f_ack; (void)f_ctl; (void)mbox; (void)ctrl;
+    (void)f_mail; (void)f_ack; (void)f_ctl; (void)f_ov; (void)mbox; (void)ctrl;
 
     // ---- stage the site: rows HBM -> LDS once per site update (as k_nuts), cavity precision re-laid
     {
@@ -191,11 +207,12 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             }
         }
         if (tid < CPB * NFLAG) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
+        if constexpr (BKW) { for (int idx = tid; idx < 2 * MREC; idx += blockDim.x) mbox[idx] = 0.0; }     // (entries beyond P stay 0)
     }
     __syncthreads();                                   // the only workgroup barrier of a piece
     if (chain >= a.chains) return;
 
-    if (!is_state && !is_bk) {
+    if (!is_state && !is_bk && !is_om) {
         // ================================================================= row wave
         // responses of this lane's rows as a bit mask (row of iteration `it`: wr*64 + lane + it*64*RW)
         unsigned long long ybits = 0;
@@ -309,11 +326,60 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
             wave_sum2(da, ll);
-            double *res = slot + (RW == 1 ? 0 : JOB + wr * RES);
+            double *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
             if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
             if (lane == 0) { res[DP] = da; res[DP + 1] = ll; }
             duo_publish(f_res + wr, seq);
             STAMP(6);
+        }
+    }
+
+    if constexpr (BKW) {
+        if (is_om) {
+            // ============================================================= cavity-term wave (one chain per workgroup)
+            // Omega v for the position of every job, v = phi - mu published with the job: lane e holds row e (the rows
+            // beyond 64 on lanes 0, 1 of a second register); OUP column pairs per round, loads first
+            const double *vj = slot + VOFF;
+            const int e0 = lane < dm ? lane : dm - 1;
+            const double2 *Op = reinterpret_cast<const double2 *>(Oms) + e0;
+            const int rcw = lane < 2 ? lane : 1;
+            const double2 *Tp = reinterpret_cast<const double2 *>(Ots + (size_t)rcw * tstride);
+            for (int seq = 1;; ++seq) {
+                const int got = duo_wait(f_job, seq);
+                if (got != seq) {
+                    if (got == DUO_TIMEOUT && lane == 0) atomicOr(a.err, 1);
+                    return;
+                }
+                double ov0 = 0.0, ov1 = 0.0;
+                for (int p0 = 0; p0 < npad; p0 += OUP) {
+                    double2 o[OUP], vp[OUP], tt[OUP];
+#pragma unroll
+                    for (int u = 0; u < OUP; ++u) {
+                        o[u] = Op[(size_t)(p0 + u) * dm];
+                        vp[u] = *reinterpret_cast<const double2 *>(vj + 2 * ((p0 + u) & 31));      // uniform address: a broadcast
+                        if constexpr (NV > 1) tt[u] = Tp[p0 + u]; else tt[u] = o[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < OUP; ++u) {
+                        ov0 = fma(o[u].x, vp[u].x, ov0);
+                        ov0 = fma(o[u].y, vp[u].y, ov0);
+                        if constexpr (NV > 1) {
+                            ov1 = fma(tt[u].x, vp[u].x, ov1);
+                            ov1 = fma(tt[u].y, vp[u].y, ov1);
+                        }
+                    }
+                }
+                if constexpr (NV > 1) {                                      // columns 64.. : the tail rows by symmetry
+                    const double a0 = Ots[e0], a1 = Ots[tstride + e0];
+                    const double b0 = Ots[(size_t)rcw * tstride + dm], b1 = Ots[(size_t)rcw * tstride + dm + 1];
+                    const double w0 = vj[64], w1 = vj[65];
+                    ov0 = fma(a0, w0, ov0); ov1 = fma(b0, w0, ov1);
+                    ov0 = fma(a1, w1, ov0); ov1 = fma(b1, w1, ov1);
+                }
+                slot[OVOFF + lane] = lane < d ? ov0 : 0.0;
+                if constexpr (NV > 1) slot[OVOFF + 64 + lane] = 64 + lane < d ? ov1 : 0.0;
+                duo_publish(f_ov, seq);
+            }
         }
     }
 
@@ -493,13 +559,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 const int got = duo_wait_ge(f_mail, mexp);
                 if (got < 0) { bail = 1; post(DUO_LEAVE); break; }       // the state wave gave up, or the wait timed out
                 const double *m = mbox + (mexp & 1) * MREC;
-                const int gen_m = (int)m[3 * NV * 64 + 2];
+                const int gen_m = (int)m[4 * NV * 64 + 2];
                 FORV {
                     in_q.v[i] = m[(0 * NV + i) * 64 + lane]; in_p.v[i] = m[(1 * NV + i) * 64 + lane];
                     in_g.v[i] = m[(2 * NV + i) * 64 + lane];
                 }
-                double lpt = m[3 * NV * 64 + 4 + lane];
-                const double ll_m = m[3 * NV * 64];
+                double lpt = 0.0;
+                FORV lpt += m[(3 * NV + i) * 64 + lane];
+                const double ll_m = m[4 * NV * 64];
                 duo_publish(f_ack, mexp);           // the entry is in registers: the state wave may reuse it
                 if (gen_m != gen) continue;         // integrated past a change of state: dropped
                 FORV { zq.v[i] = in_q.v[i]; zp.v[i] = in_p.v[i]; zg.v[i] = in_g.v[i]; }
@@ -546,7 +613,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         else {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < RW; ++w) s += slot[JOB + w * RES + j];
+            for (int w = 0; w < RW; ++w) s += slot[RESO + w * RREC + j];
             return s;
         }
     };
@@ -554,8 +621,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // (zq, zp, zg) holds the last finished leapfrog state; `pending`: its bookkeeping is still to run
     double f_lpt = 0.0, f_ks = 0.0, f_ll = 0.0;     // its log density / kinetic energy, not yet summed over the lanes
     bool pending = false;
-    int seq = 0, gen = 0, mseq = 0;
-    (void)gen; (void)mseq;
+    int seq = 0, gen = 0, mseq = 0, ctl_pre = -1, ack_pre = 0;
+    (void)gen; (void)mseq; (void)ctl_pre; (void)ack_pre;
     const int lane0 = lane;
     // ---- the critical-path shortcut (m4b / m5b, one row wave).  (alpha, beta) of the NEXT position depend on
     // 3 (D + 1) of the P coordinates only, and the hierarchical structure is the same for every one of them:
@@ -574,6 +641,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     const int ve2 = !v_lane ? 0 : (lane0 == LA ? d : d + 1 + lane0);        // raw:       eta  | etb[j]
     const int ve3 = !v_lane ? 0 : (lane0 == LA ? 1 : 2 + D + lane0);        // log scale: lsig_a | lsig_b[j]
     double vq1 = 0, vq2 = 0, vq3 = 0, vp1 = 0, vp2 = 0, vp3 = 0, vm1 = 1, vm2 = 1, vm3 = 1, vex3 = 1, vo1 = 0, vo3 = 0;
+    const double vmu1 = gatherV(mu, ve1), vmu3 = gatherV(mu, ve3);          // (cavity mean at the view's coordinates)
+    (void)vmu1; (void)vmu3;
     bool fast_pub = false;                              // the job of the position in flight went out by the shortcut
     double job_eps = 0.0;
     STAMP_INIT;
@@ -587,7 +656,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         EPX_BIND_COLD(lane);
         if constexpr (BKW) {
             // ---- the bookkeeping wave's word: a record of a new generation means "continue from here instead"
-            const int ctl = gen == 0 ? duo_wait_ge(f_ctl, 1) : __builtin_amdgcn_readfirstlane(*f_ctl);
+            // (read right after the last job went out, see below: a record that arrives in between is seen one leapfrog
+            // later, which the generation numbers allow)
+            const int ctl = gen == 0 ? duo_wait_ge(f_ctl, 1) : __builtin_amdgcn_readfirstlane(ctl_pre >= 0 ? ctl_pre : *f_ctl);
+            ctl_pre = -1;
             if (ctl < 0) { bail = 1; break; }
             if (ctl != gen) {
                 if (fast_pub) {                    // the job in flight continues a trajectory nobody wants: let it land
@@ -595,6 +667,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                         const int got = duo_wait(f_res + w, seq);
                         if (got != seq) bail = 1;
                     }
+                    if (duo_wait(f_ov, seq) != seq) bail = 1;       // (the cavity-term wave reads v: it must be done, too)
                     if (bail) break;
                 }
                 const double *cr = ctrl + (ctl & 1) * CREC;
@@ -639,6 +712,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             double *job = slot + JOB;
             if (lane < DP) job[1 + lane] = beta_l;
             if (lane == 0) job[0] = alpha;
+            if constexpr (RW > 1) {
+                FORV { const int e = lane + 64 * i; slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
+            }
             ++seq;
             duo_publish(f_job, seq);
             job_eps = eps_l;
@@ -696,7 +772,12 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 continue;
             }
         }
-        if (sent) first_half();
+        // One chain per workgroup, models with per-coefficient scales: the view holds EVERY coordinate (d = 2 D + 2,
+        // P = 3 D + 3), so while the shortcut keeps sending the jobs the state wave needs no vector at all -- the finished
+        // state goes to the bookkeeping wave straight from the view's lanes (same values: the vectors' formulas, element
+        // by element), and the vectors are only rebuilt from a control record when the trajectory restarts
+        const bool lean = BKW && fast_ok && sent;
+        if (sent && !lean) first_half();
         STAMP(1);
 
         // ---- cavity term Ov = Omega (phi - mu) of the position in flight ...
@@ -704,7 +785,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         FORV { const int e = lane + 64 * i; vv.v[i] = e < d ? sq.v[i] - mu.v[i] : 0.0; Ov.v[i] = 0.0; }
         int bzero = 0;
         asm volatile("" : "+v"(bzero));               // a register holding 0 the compiler cannot fold: address base
-        {
+        if constexpr (RW == 1) {
             // OU column pairs per round, loads first: the LDS latency is paid once per round.  The padding
             // pairs (and absent tail rows) hold zeros, so they add nothing and the sums keep order and value
             const int e0 = lane < dm ? lane : dm - 1;
@@ -741,8 +822,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 Ov.v[0] = fma(a1, w1, Ov.v[0]); Ov.v[1] = fma(b1, w1, Ov.v[1]);
             }
         }
-        FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
-        if (fast_ok) { vo1 = gatherV(Ov, ve1); vo3 = gatherV(Ov, ve3); }
+        if constexpr (RW == 1) {
+            FORV { const int e = lane + 64 * i; Ov.v[i] = e < d ? Ov.v[i] : 0.0; }
+            if (fast_ok) { vo1 = gatherV(Ov, ve1); vo3 = gatherV(Ov, ve3); }
+        }
 
         STAMP(2);
         // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
@@ -750,6 +833,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             const int got = duo_wait(f_res + w, seq);
             if (got != seq) bail = 1;
         }
+        if constexpr (BKW) { if (duo_wait(f_ov, seq) != seq) bail = 1; }
         STAMP(3);
         __builtin_amdgcn_s_setprio(EPX_PRIO_S_CRIT);    // chain rule, half kick, drift, publish: the row waves wait for it
         if (bail) break;
@@ -758,14 +842,22 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         else {
             da = 0.0; ll = 0.0;
 #pragma unroll
-            for (int w = 0; w < RW; ++w) { da += slot[JOB + w * RES + DP]; ll += slot[JOB + w * RES + DP + 1]; }
+            for (int w = 0; w < RW; ++w) { da += slot[RESO + w * RREC + DP]; ll += slot[RESO + w * RREC + DP + 1]; }
         }
-        FORV dbf[i] = xtg(jdx[i]);                  // (the shortcut reuses the slot for the next job: fetch first)
+        if (!lean) { FORV dbf[i] = xtg(jdx[i]); }   // (the shortcut reuses the slot for the next job: fetch first)
+        else { FORV dbf[i] = 0.0; }
+        if constexpr (RW > 1) {
+            // the cavity term of this position, from its own wave (lean: only the view's coordinates of it)
+            if (!lean) { FORV Ov.v[i] = slot[OVOFF + lane + 64 * i]; }
+            if (fast_ok) { vo1 = slot[OVOFF + ve1]; vo3 = slot[OVOFF + ve3]; }
+        }
         if (fast_ok) {
             const double t = xtg(lane == LA ? DP : (lane < DP ? lane : 0));     // lane LA: sum g (as `da` above)
             const double pr2 = laplace ? (double)((vq2 > 0) - (vq2 < 0)) : vq2;
             const double g1 = -vo1 + t, g2 = t * vex3 - pr2, g3 = -vo3 + t * vq2 * vex3;
             // second half of this leapfrog, first half of the next one (the loop top's formulas, element by element)
+            if (lean) STAMP(1);          // (diagnostic build, lean iterations: slot 1 = fetching the results)
+            const double q1o = vq1, q2o = vq2, q3o = vq3;                     // the position of this leapfrog
             const double fp1 = vp1 + 0.5 * eps_l * g1, fp2 = vp2 + 0.5 * eps_l * g2, fp3 = vp3 + 0.5 * eps_l * g3;
             vp1 = fp1 + 0.5 * eps_l * g1; vp2 = fp2 + 0.5 * eps_l * g2; vp3 = fp3 + 0.5 * eps_l * g3;
             vq1 = vq1 + eps_l * vm1 * vp1; vq2 = vq2 + eps_l * vm2 * vp2; vq3 = vq3 + eps_l * vm3 * vp3;
@@ -774,11 +866,41 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             double *job = slot + JOB;
             if (lane < DP) job[1 + lane] = ba;
             if (lane == LA) job[0] = ba;
+            if constexpr (RW > 1) {
+                // v = phi - mu of the next position for the row waves' cavity term: the view holds ALL of phi
+                // (locations and log scales; models with per-coefficient scales: d = 2 D + 2)
+                if (v_lane) { slot[VOFF + ve1] = vq1 - vmu1; slot[VOFF + ve3] = vq3 - vmu3; }
+            }
             ++seq;
             duo_publish(f_job, seq);
             job_eps = eps_l;
             fast_pub = true;
+            if (lean) STAMP(2);          // (... slot 2 = the view's update and the job's publication)
+            if constexpr (BKW) { ctl_pre = *f_ctl; ack_pre = *f_ack; }     // requested now, used after the chain rule: no round trip then
             __builtin_amdgcn_s_setprio(EPX_PRIO_S_BG);  // the row waves are off again: what follows has their whole pass
+            if constexpr (BKW) {
+                if (lean) {
+                    // ---- the finished state to the bookkeeping wave, from the view (entries of the mailbox in vector order)
+                    const double lp1 = -0.5 * (q1o - vmu1) * vo1, lp3 = -0.5 * (q3o - vmu3) * vo3;
+                    const double lp2 = laplace ? -fabs(q2o) : -0.5 * q2o * q2o;
+                    ++mseq;
+                    if (mseq > 2 && __builtin_amdgcn_readfirstlane(ack_pre) < mseq - 2) {
+                        const int got = duo_wait_ge(f_ack, mseq - 2);
+                        if (got < 0) { bail = 1; break; }
+                    }
+                    double *m = mbox + (mseq & 1) * MREC;
+                    if (v_lane) {
+                        m[ve1] = q1o; m[ve2] = q2o; m[ve3] = q3o;
+                        m[NV * 64 + ve1] = fp1; m[NV * 64 + ve2] = fp2; m[NV * 64 + ve3] = fp3;
+                        m[2 * NV * 64 + ve1] = g1; m[2 * NV * 64 + ve2] = g2; m[2 * NV * 64 + ve3] = g3;
+                        m[3 * NV * 64 + ve1] = lp1; m[3 * NV * 64 + ve2] = lp2; m[3 * NV * 64 + ve3] = lp3;
+                    }
+                    if (lane == 0) { m[4 * NV * 64] = uniform_d(ll); m[4 * NV * 64 + 2] = (double)gen; }
+                    duo_publish(f_mail, mseq);
+                    STAMP(4);
+                    continue;
+                }
+            }
         }
         da = uniform_d(da); ll = uniform_d(ll);
         // the parts of the chain rule that only need the position (cross-lane gathers)
@@ -792,6 +914,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                    g_etbq.v[i] = gatherV(sq, d + 1 + j); g_sbj.v[i] = gatherV(eq, 2 + D + j); }
         }
         double lpt = 0.0;
+        V lpv;
         {
             double dot = 0.0;
             if (model == 1) {
@@ -808,7 +931,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 double g = in_phi ? -ov : 0.0;
                 const double lp_phi = -0.5 * vv.v[i] * ov;
                 const double lp_pri = laplace ? -fabs(q) : -0.5 * q * q;
-                lpt += in_phi ? lp_phi : (in_par ? lp_pri : 0.0);
+                const double lterm = in_phi ? lp_phi : (in_par ? lp_pri : 0.0);
+                lpt += lterm;
+                lpv.v[i] = lterm;
                 const double pr = laplace ? (double)((q > 0) - (q < 0)) : q;    // d/dq of the N(0,1)/Laplace term
                 const double g_eta = c_eta - pr;
                 double add = 0.0, g_etb = 0.0;
@@ -848,7 +973,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             // ---- hand the finished state to the bookkeeping wave (it is at most two states behind)
             STAMP(4);
             ++mseq;
-            if (mseq > 2) {
+            if (mseq > 2 && __builtin_amdgcn_readfirstlane(ack_pre) < mseq - 2) {
                 const int got = duo_wait_ge(f_ack, mseq - 2);
                 if (got < 0) { bail = 1; break; }
             }
@@ -857,8 +982,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 m[(0 * NV + i) * 64 + lane] = sq.v[i]; m[(1 * NV + i) * 64 + lane] = sp.v[i];
                 m[(2 * NV + i) * 64 + lane] = sg.v[i];
             }
-            m[3 * NV * 64 + 4 + lane] = lpt;
-            if (lane == 0) { m[3 * NV * 64] = ll; m[3 * NV * 64 + 2] = (double)gen; }
+            FORV m[(3 * NV + i) * 64 + lane] = lpv.v[i];
+            if (lane == 0) { m[4 * NV * 64] = ll; m[4 * NV * 64 + 2] = (double)gen; }
             duo_publish(f_mail, mseq);
             STAMP(1);                               // (diagnostic build: the hand-over is booked on the bookkeeping slot)
         }
@@ -905,7 +1030,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             EPX_CK_LIST(EPX_CK_PUT)
 #undef EPX_CK_PUT
             ck_store(ckp + 4 * NV * 64 + lane, ckv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record is out before the site is put back
+            piece_checkpoint_out();                                 // the record is out before the site is put back
         }
     }
     if (!failed && t < a.iter) return;          // suspended at the end of a piece: no final record yet
@@ -934,7 +1059,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #undef a
 
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
-__global__ void __launch_bounds__(64 * (CPB * (1 + RW) + (CPB == 1 ? 1 : 0)))
+__global__ void __launch_bounds__(64 * (CPB * (1 + RW) + (CPB == 1 ? 2 : 0)))
 k_nuts_duo(NutsArgs a_by_value) {
     extern __shared__ __align__(16) unsigned char smem[];
     (void)a_by_value;
@@ -979,13 +1104,13 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     a.off_Om = (int)off; off += (size_t)npad * dm * 16;
     a.off_tail = (int)off; off += nv > 1 ? (size_t)2 * (2 * npad + 2) * 8 : 0;
     off = (off + 15) & ~(size_t)15;
-    a.slot_doubles = rw == 1 ? dp + 2 : (1 + rw) * (dp + 2);
+    a.slot_doubles = rw == 1 ? dp + 2 : (dp + 2) + nv * 64 + rw * (dp + 2) + nv * 64;            // as the kernel (VOFF, RESO, OVOFF)
     a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
     const bool bkw = cpb == 1;                                                        // as the kernel (BKW)
-    a.off_flag = (int)off; off += (size_t)cpb * (1 + rw + (bkw ? 3 : 0)) * 4;
+    a.off_flag = (int)off; off += (size_t)cpb * (1 + rw + (bkw ? 4 : 0)) * 4;
     off = (off + 15) & ~(size_t)15;
     a.off_spec = 0;
-    if (bkw) { a.off_spec = (int)off; off += (size_t)2 * ((3 * nv * 64 + 4 + 64) + (4 * nv * 64 + 4)) * 8; }
+    if (bkw) { a.off_spec = (int)off; off += (size_t)2 * ((4 * nv * 64 + 4) + (4 * nv * 64 + 4)) * 8; }
     a.om_in_lds = 1;
     const size_t cap = 160 * 1024;
     const size_t stack = (size_t)cpb * a.max_depth * nuts_stack_record(nv) * 8;
@@ -1007,7 +1132,7 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (CPB * (1 + RW) + (CPB == 1 ? 1 : 0))), a.lds_bytes, stream, a);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (CPB * (1 + RW) + (CPB == 1 ? 2 : 0))), a.lds_bytes, stream, a);
         return (int)hipGetLastError();
     };
     constexpr bool COLD = NV >= 2 || CPB > 1;

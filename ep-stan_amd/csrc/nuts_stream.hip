@@ -558,7 +558,7 @@ k_nuts_stream(NutsArgs a) {
             EPX_CK_LIST(EPX_CK_PUT)
 #undef EPX_CK_PUT
             ck_store(ckp + 4 * NV * 64 + lane0, ckv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the record is out before the site is put back
+            piece_checkpoint_out();                                 // the record is out before the site is put back
         }
         __syncthreads();
         if (threadIdx.x == 0) piece_release(a, smem);

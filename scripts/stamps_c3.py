@@ -38,6 +38,9 @@ def main():
     print('cycles per leapfrog (median over %d blocks), total %.0f' % (nb, med.sum()))
     for nm, v in zip(NAMES_DUO if eng.last_layout() >= 5 else NAMES, med):
         print('    %-36s %8.0f  %5.1f%%' % (nm, v, 100 * v / med.sum()))
+    big = int(np.argmax(st[:, 7]))
+    print('the workgroup with the most leapfrogs (%d): cycles per leapfrog %s, total S %.0f, total R %.0f'
+          % (st[big, 7], np.round(per[big]).astype(int), per[big, :5].sum(), per[big, 5:7].sum()))
     wg = lf.max(axis=1)
     print('us per leapfrog of the slowest chain of a workgroup ~ %.2f' % (M.sampling_ms[-1] * 1e3 / wg.max()))
 

@@ -1072,7 +1072,8 @@ def test_layout_policy_for_the_baseline_shapes():
         eng.close()
         return lay
 
-    assert picked('m4b_sg', 64, 16, 200) == 2          # C2: fewer sites than CUs -> one workgroup per chain
+    assert picked('m4b_sg', 64, 16, 200) == 6          # C2: every chain gets a CU -> one workgroup per chain, roles on waves
+    assert picked('m3b_sg', 64, 16, 200) == 2          # ... models without per-coefficient scales: gradient waves + bookkeeping wave
     assert picked('m4b_sg', 256, 16, 200) == 2         # two such workgroups share a CU: still ahead (measured)
     assert picked('m4b_sg', 400, 16, 200) == 5         # many small sites -> one workgroup per site (row + state waves)
     assert picked('m4b_sg', 512, 32, 500) == 5         # C3 / C4 per GPU

@@ -554,6 +554,7 @@ def test_ep_with_the_piece_queue_equals_ep_without(monkeypatch):
             M.engine.set_piece_queue = lambda *a, **k: None
         info = M.run(3, verbose=False, calc_moments=False, seed=5)
         out.append((M.Q.copy(), M.r.copy(), M.engine.last_segments(), M.engine.last_layout(), info))
+    print('EP with / without the piece queue: sum|Q| = %.6f / %.6f' % (np.abs(out[0][0]).sum(), np.abs(out[1][0]).sum()))
     assert out[0][3] == out[1][3] == 5 and out[0][4] == out[1][4] == 0
     assert out[0][2] == -16 and out[1][2] == 0          # iter = 64: 16 pieces of 4 transitions
     np.testing.assert_array_equal(out[0][0], out[1][0])
