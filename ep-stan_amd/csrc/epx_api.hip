@@ -534,9 +534,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     if (!lock && !c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
         (layout == 5 || layout == 6 || (layout == 0 && many) || auto6)) {
         const bool six = layout == 6 || auto6;
-        int rw = six ? 2 : 1;
-        if (six && getenv("EPX_L6_RW")) rw = atoi(getenv("EPX_L6_RW"));        // experiment: row waves of layout 6
-        const int cpb = six ? 1 : 4;
+        const int cpb = six ? 1 : 4, rw = six ? 2 : 1;
         NutsArgs t = a;
         const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
         // (layout 6: one chain per workgroup, the bookkeeping wave's stack lives in LDS or the layout is not used)

@@ -1147,12 +1147,11 @@ template <int NV, int DP>
 static int launch_duo_shape(const NutsArgs &a, int nblocks, int cpb, int rw, hipStream_t stream) {
     if (cpb == 4 && rw == 1) return launch_duo_one<NV, DP, 4, 1>(a, nblocks, stream);
     if (cpb == 1 && rw == 2) return launch_duo_one<NV, DP, 1, 2>(a, nblocks, stream);
-    if (cpb == 1 && rw == 4) return launch_duo_one<NV, DP, 1, 4>(a, nblocks, stream);
     return -1;
 }
 
 bool nuts_duo_has(int cpb, int rw, int dp, int nv) {
-    return ((cpb == 4 && rw == 1) || (cpb == 1 && (rw == 2 || rw == 4))) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
+    return ((cpb == 4 && rw == 1) || (cpb == 1 && rw == 2)) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
 }
 
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream) {
