@@ -650,7 +650,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         c->last_segments = -npieces;                 // (negative: pieces per site of a queued launch)
     }
     if (use_queue) {
-        const size_t need = (size_t)count * o.chains * (size_t)(4 * nv + 1) * 64;
+        const size_t need = (size_t)count * ((o.iter + c->dyn_len - 1) / c->dyn_len + 1) * o.chains * (size_t)(4 * nv + 1) * 64;    // a record per piece boundary
         if (c->ckpt_n < need) {
             if (c->ckpt) (void)hipFree(c->ckpt);
             c->ckpt = nullptr; c->ckpt_n = 0;

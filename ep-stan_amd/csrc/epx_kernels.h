@@ -164,7 +164,7 @@ struct NutsArgs {
     int seg_nwg;
     double *ckpt;                 // pieced launches: per (site, chain) a record of (4 NV + 1) x 64 doubles (sample, Welford sums, metric, scalars)
     // piece queue (epx_set_piece_queue): every workgroup claims a site by largest remaining predicted work and runs
-    // dyn_len transitions of it; dyn_prog[site] = transitions done, dyn_busy[site] = claimed
+    // dyn_len transitions of it; dyn_prog[site] = 2 x transitions done + (claimed): one word, changed atomically
     int *dyn_prog, *dyn_busy;
     const double *dyn_rate;       // predicted work per transition of every site of the batch, or NULL (all equal)
     int dyn_len, dyn_count;

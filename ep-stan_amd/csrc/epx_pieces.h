@@ -25,16 +25,25 @@ namespace epx {
 // been on earlier in the launch can hit that XCD's L2 copy of its OLDER record (seen as a rare wrong trajectory)
 __device__ inline void ck_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ inline double ck_load(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
+                                                             __HIP_MEMORY_SCOPE_SYSTEM));
 }
 template <typename T> __device__ inline void ck_assign(T &x, double v) { x = (T)v; }
 
 // doubles of one chain's checkpoint record: sample, Welford mean and sum of squares, metric (nv x 64 each), scalars (64)
 __host__ __device__ constexpr size_t piece_record_doubles(int nv) { return (size_t)(4 * nv + 1) * 64; }
+// Every piece BOUNDARY of a site has its own record (boundary b = transitions done / piece length): an address is
+// written once per launch, by one workgroup, and read once, by another -- no XCD can hold an older version of it
+// (the first form had one record per site, and a site that came back to an XCD it had been on could read a mix of
+// that L2's older lines and fresh ones: a rare wrong trajectory, found by the EP parity test)
+template <class Args>
+__device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundary, int chain, int nv) {
+    const int b = t_boundary / a.dyn_len, nb = (a.iter + a.dyn_len - 1) / a.dyn_len + 1;
+    return a.ckpt + (((size_t)site * nb + b) * a.chains + chain) * piece_record_doubles(nv);
+}
 
 // Claim a site (all threads of the workgroup; the LDS must not hold anything yet: smem[0..1100) is scratch, and
 // (site, first transition) stay at smem + off_piece for piece_release).  Returns false after 2^24 looks without one
@@ -48,8 +57,9 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
     for (int attempt = 0; attempt < (1 << 24) && q_site < 0; ++attempt) {
         double best = -1.0; int arg = -1;
         for (int s = tid; s < a.dyn_count; s += blockDim.x) {
-            const int pr = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int bz = __hip_atomic_load(a.dyn_busy + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ONE word per site: 2 x (transitions done) + (held): progress and claim change together, atomically
+            const int wd = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int pr = wd >> 1, bz = wd & 1;
             if (bz == 0 && pr < a.iter) {
                 // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
                 // remaining site would get it one at a time)
@@ -70,15 +80,18 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
             double b = -1.0; int g = -1;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
             int got = -2;                                  // -2: every unfinished site is held right now
+            int t0_got = 0;
             if (g >= 0) {
-                int expect = 0;
-                const bool ok = __hip_atomic_compare_exchange_strong(a.dyn_busy + g, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_AGENT);
+                int expect = __hip_atomic_load(a.dyn_prog + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = (expect & 1) == 0 && (expect >> 1) < a.iter;
+                if (ok) ok = __hip_atomic_compare_exchange_strong(a.dyn_prog + g, &expect, expect + 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
                 got = ok ? g : -1;                         // -1: somebody was faster, look again
+                t0_got = expect >> 1;                      // (the progress that was claimed: same word, same instant)
             }
             si[32] = got;
             if (got >= 0) {
-                si[33] = __hip_atomic_load(a.dyn_prog + got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                si[33] = t0_got;
                 volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);      // (kept for the release)
                 pz[0] = got; pz[1] = si[33];
             }
@@ -109,9 +122,8 @@ template <class Args>
 __device__ __forceinline__ void piece_release(Args &a, unsigned char *smem) {
     volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
     const int r_site = pz[0], r_t0 = pz[1];
-    __hip_atomic_store(a.dyn_prog + r_site, r_t0 + a.dyn_len < a.iter ? r_t0 + a.dyn_len : a.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(a.dyn_busy + r_site, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t1 = r_t0 + a.dyn_len < a.iter ? r_t0 + a.dyn_len : a.iter;
+    __hip_atomic_store(a.dyn_prog + r_site, 2 * t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // progress up, claim off: one store
 }
 
 }  // namespace epx

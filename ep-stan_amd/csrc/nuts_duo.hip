@@ -392,7 +392,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // cached by two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
     double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
     // (the checkpoint record's address is formed where it is used: nothing of a pieced launch stays live through the loops)
-    auto ck_rec = [&]() -> double * { return a.ckpt + ((size_t)sb * a.chains + chain) * piece_record_doubles(NV); };
+    auto ck_rec = [&](int t_boundary) -> double * { return piece_record(a, sb, t_boundary, chain, NV); };
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
     auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
@@ -438,7 +438,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     }
     if (resume) {
         // the sample and the Welford sums of the piece before this one (checkpoint record: qs, wmean, wm2, metric, scalars)
-        double *ckp = ck_rec();
+        double *ckp = ck_rec(t_begin);
         FORV {
             qs.v[i] = ck_load(ckp + (0 * NV + i) * 64 + lane);
             wmean.v[i] = ck_load(ckp + (1 * NV + i) * 64 + lane);
@@ -504,14 +504,17 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     }
     if constexpr (COLD) {
         if (resume) {
-            double *ckp = ck_rec();
+            double *ckp = ck_rec(t_begin);
             FORV inv_e.v[i] = ck_load(ckp + (3 * NV + i) * 64 + lane);
             const double ckv = ck_load(ckp + 4 * NV * 64 + lane);
 #define EPX_CK_GET(idx, x) ck_assign(x, readlane_d(ckv, idx));
             EPX_CK_LIST(EPX_CK_GET)
 #undef EPX_CK_GET
             ngrad -= 1.0;                             // the gradient at the restored sample is evaluated once more
-            if (failed) {                             // it failed in its first piece, where everything was written
+            if (failed) {                             // it failed in its first piece, where everything was written:
+                // hand the mark on to the piece after this one (every boundary has its own record), and leave
+                ck_store(ck_rec(t_end) + 4 * NV * 64 + lane, ckv);
+                piece_checkpoint_out();
                 *f_job = DUO_EXIT;
                 return;
             }
@@ -1018,7 +1021,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         if (segmented) {
             // ---- checkpoint at the transition boundary: the sample, the Welford sums, the metric and the scalars of
             // EPX_CK_LIST (the gradient at the sample is re-evaluated by the piece that continues)
-            double *ckp = ck_rec();
+            double *ckp = ck_rec(t_end);
             FORV {
                 ck_store(ckp + (0 * NV + i) * 64 + lane, qs.v[i]);
                 ck_store(ckp + (1 * NV + i) * 64 + lane, wmean.v[i]);

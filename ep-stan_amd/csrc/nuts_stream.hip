@@ -175,7 +175,8 @@ k_nuts_stream(NutsArgs a) {
     // (pieced launches: tree stack and cold store belong to the WORKGROUP, so that no line of them is ever cached by the
     // L2s of two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
     const size_t chain_slot = (size_t)(queued ? (int)blockIdx.x : sb) * a.chains + (active ? chain : 0);
-    double *ckp = queued ? a.ckpt + ((size_t)sb * a.chains + (active ? chain : 0)) * piece_record_doubles(NV) : nullptr;
+    double *ckp = queued ? piece_record(a, sb, t_begin, active ? chain : 0, NV) : nullptr;            // the record this piece starts from
+    double *ckp_out = queued ? piece_record(a, sb, t_end, active ? chain : 0, NV) : nullptr;        // ... and the one it leaves
     // wave-uniform base pointers (held in scalar registers; lanes add lane*8)
     auto uniform_ptr = [](double *p) -> double * {
         const unsigned long long u = (unsigned long long)p;
@@ -269,9 +270,11 @@ k_nuts_stream(NutsArgs a) {
         FORV { const int e = lane0 + 64 * i; if (e < P) inv_e.v[i] = cm[e]; }
     }
     int finished = active ? 0 : 1;
+    double ck_mark = 0.0;                              // (a failed chain's scalars, handed on from boundary to boundary)
     if (resume && active) {
         FORV inv_e.v[i] = ck_load(ckp + (3 * NV + i) * 64 + lane0);
         const double ckv = ck_load(ckp + 4 * NV * 64 + lane0);
+        ck_mark = ckv;
 #define EPX_CK_GET(idx, x) ck_assign(x, readlane_d(ckv, idx));
         EPX_CK_LIST(EPX_CK_GET)
 #undef EPX_CK_GET
@@ -548,18 +551,19 @@ k_nuts_stream(NutsArgs a) {
             // checkpoint at the transition boundary: the sample, the Welford sums, the metric and the scalars of
             // EPX_CK_LIST (the gradient at the sample is re-evaluated by the piece that continues)
             FORV {
-                ck_store(ckp + (0 * NV + i) * 64 + lane0, qs.v[i]);
-                ck_store(ckp + (1 * NV + i) * 64 + lane0, wmean.v[i]);
-                ck_store(ckp + (2 * NV + i) * 64 + lane0, wm2.v[i]);
-                ck_store(ckp + (3 * NV + i) * 64 + lane0, inv_e.v[i]);
+                ck_store(ckp_out + (0 * NV + i) * 64 + lane0, qs.v[i]);
+                ck_store(ckp_out + (1 * NV + i) * 64 + lane0, wmean.v[i]);
+                ck_store(ckp_out + (2 * NV + i) * 64 + lane0, wm2.v[i]);
+                ck_store(ckp_out + (3 * NV + i) * 64 + lane0, inv_e.v[i]);
             }
             double ckv = 0.0;
 #define EPX_CK_PUT(idx, x) ckv = lane0 == (idx) ? (double)(x) : ckv;
             EPX_CK_LIST(EPX_CK_PUT)
 #undef EPX_CK_PUT
-            ck_store(ckp + 4 * NV * 64 + lane0, ckv);
+            ck_store(ckp_out + 4 * NV * 64 + lane0, ckv);
             piece_checkpoint_out();                                 // the record is out before the site is put back
         }
+        if (active && !a.dbg && was_failed) { ck_store(ckp_out + 4 * NV * 64 + lane0, ck_mark); piece_checkpoint_out(); }
         __syncthreads();
         if (threadIdx.x == 0) piece_release(a, smem);
     }
