@@ -583,3 +583,25 @@ def test_piece_queue_with_a_chain_that_fails_at_its_start(D, n, layout):
     assert eng.last_segments() == -5
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a, b)
+
+
+def test_piece_queue_runs_repeat_bit_for_bit(monkeypatch):
+    """The claims of a pieced launch depend on timing; its draws must not.  Eight EP runs from the queue in one
+    process (device memory full of the earlier runs' data) give the same global parameters bit for bit -- the check
+    that found the two-word site state of the first form (scripts/leak_check.py is the long version)."""
+    J = 300
+    monkeypatch.setattr(Master, 'LEAD_FRACTION', 2.0)
+    mod = models.m4b(J, 20, 340)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    ref = None
+    for rep in range(8):
+        M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=64,
+                   df0=models.default_df0(J), sync_sites=False)
+        assert M.run(2, verbose=False, calc_moments=False, seed=5) == 0 and M.engine.last_segments() == -16
+        cur = (M.Q.copy(), M.r.copy(), M.engine.get_chain_stats(4).copy())
+        if ref is None:
+            ref = cur
+        for a, b in zip(ref, cur):
+            np.testing.assert_array_equal(a, b)
+        del M
