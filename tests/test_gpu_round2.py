@@ -605,3 +605,29 @@ def test_piece_queue_runs_repeat_bit_for_bit(monkeypatch):
         for a, b in zip(ref, cur):
             np.testing.assert_array_equal(a, b)
         del M
+
+
+def test_piece_queue_on_streamed_sites_with_several_groups():
+    """K < J on the streaming layout (the sites sample different numbers of coordinates): pieces of 4 and of 7
+    transitions give the draws and chain statistics of the uncut launch."""
+    from epstan_amd.util import distribute_groups
+    J, K, D, n, it = 24, 8, 40, 90, 30
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    Nk, Nj_k, j_ind_k = distribute_groups(J, K, data.Nj)
+    M = Master('m4b', data.X, data.y, site_sizes=Nk, A_k={'J': Nj_k}, A_n={'j_ind': j_ind_k + 1},
+               prior={'Q': Q0, 'r': r0}, chains=4, iter=it)
+    eng, seeds = M.engine, np.arange(K) + 5
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random')
+    out = []
+    for q in (0, 4, 7):
+        eng.set_piece_queue(q, None)
+        eng.sample_batch(seeds, opts)
+        out.append(([eng.get_draws(k, all_params=True).copy() for k in range(K)], eng.get_chain_stats(4).copy(),
+                    eng.last_layout(), eng.last_segments()))
+    assert [o[2] for o in out] == [3, 3, 3] and [o[3] for o in out] == [0, -8, -5]
+    for o in out[1:]:
+        for a, b in zip(o[0], out[0][0]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(o[1], out[0][1])
