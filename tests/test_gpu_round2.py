@@ -511,7 +511,8 @@ def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate, D, n):
         eng.set_piece_queue(5, np.zeros(9))
 
 
-@pytest.mark.parametrize('model,D,n,piece_len', [('m4b', 40, 260, 9), ('m4b', 70, 150, 50), ('m1b', 40, 300, 1)])
+@pytest.mark.parametrize('model,D,n,piece_len', [('m4b', 40, 260, 9), ('m4b', 70, 150, 50), ('m1b', 40, 300, 1),
+                                                  ('m4a', 40, 150, 4), ('m1a', 40, 150, 5)])        # (the last two: Gaussian family)
 def test_piece_queue_on_the_streaming_layout(model, D, n, piece_len):
     """The same mechanism in k_nuts_stream (rows streamed from HBM, the four chains of a site in lock step): a piece
     ends when every chain of the site has reached the boundary; draws and statistics equal the uncut launch's."""
