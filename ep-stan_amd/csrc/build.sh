@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 mkdir -p build
 pids=()
 for f in dense nuts nuts_duo nuts_stream epx_api epx_comm; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ epx_kernels.h -nt build/$f.o ] || [ epx_device.h -nt build/$f.o ] || [ epx_ctx.h -nt build/$f.o ] || [ nuts_common.h -nt build/$f.o ] || [ nuts_state_machine.inc -nt build/$f.o ] || [ nuts_gradient.inc -nt build/$f.o ] || [ nuts_gradient_groups.inc -nt build/$f.o ] || [ epx_stream_tile.h -nt build/$f.o ] || [ ../../include/epx.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ epx_kernels.h -nt build/$f.o ] || [ epx_device.h -nt build/$f.o ] || [ epx_ctx.h -nt build/$f.o ] || [ nuts_common.h -nt build/$f.o ] || [ nuts_state_machine.inc -nt build/$f.o ] || [ nuts_gradient.inc -nt build/$f.o ] || [ nuts_gradient_groups.inc -nt build/$f.o ] || [ epx_stream_tile.h -nt build/$f.o ] || [ epx_pieces.h -nt build/$f.o ] || [ ../../include/epx.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
@@ -19,6 +19,6 @@ if [ "$EPX_STAMPS" = "1" ]; then
   # diagnostic variant with in-kernel cycle stamps (scripts/stamps.py); never benchmarked
   mkdir -p build_stamps
   for f in dense nuts nuts_duo nuts_stream epx_api epx_comm; do $HIPCC $FLAGS -DEPX_STAMPS -c $f.hip -o build_stamps/$f.o & done; wait
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_out/libepx_stamps.so build_stamps/dense.o build_stamps/nuts.o build_stamps/nuts_duo.o build_stamps/nuts_stream.o build_stamps/epx_api.o build_stamps/epx_comm.o -ldl
-  echo "built diagnostic gpurun_out/libepx_stamps.so"
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../../variants/libepx_stamps.so build_stamps/dense.o build_stamps/nuts.o build_stamps/nuts_duo.o build_stamps/nuts_stream.o build_stamps/epx_api.o build_stamps/epx_comm.o -ldl
+  echo "built diagnostic variants/libepx_stamps.so"
 fi

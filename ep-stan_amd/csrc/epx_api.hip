@@ -532,18 +532,22 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     // (only when every chain has a CU of its own: the regime where a launch is as long as its slowest chain)
     const bool auto6 = layout == 0 && !many && c->model >= EPX_M4B_SG && count * o.chains <= c->n_cu;
     if (!lock && !c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
-        (layout == 5 || layout == 6 || (layout == 0 && many) || auto6)) {
+        (layout == 5 || layout == 6 || layout == 7 || (layout == 0 && many) || auto6)) {
         const bool six = layout == 6 || auto6;
-        const int cpb = six ? 1 : 4, rw = six ? 2 : 1;
+        // layout 7: the row TEAM of nuts_duo.hip -- four row waves serve the four chains of a site in lock step on the
+        // matrix pipe; the state waves are layout 5's
+        const bool seven = layout == 7;
+        const int cpb = six ? 1 : 4, rw = six ? 2 : (seven ? 4 : 1);
         NutsArgs t = a;
         const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
         // (layout 6: one chain per workgroup, the bookkeeping wave's stack lives in LDS or the layout is not used)
-        const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP && (c->n_max + 64 * rw - 1) / (64 * rw) <= 64 &&
+        const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP &&
+                          (seven ? (c->n_max + 63) / 64 <= 32 : (c->n_max + 64 * rw - 1) / (64 * rw) <= 64) &&
                           (!six || t.stack_in_lds);
         if (fits) {
             a = t;
             a.err = c->err_flag;
-            layout = six ? 6 : 5;
+            layout = six ? 6 : (seven ? 7 : 5);
             {
                 a.stack_stride = nuts_resident_chain_doubles(nv, o.max_depth);
                 const size_t need = (size_t)stack_sites * o.chains * a.stack_stride;
@@ -558,7 +562,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
             *wpc_out = rw; *dp_out = dp; *nv_out = nv; *layout_out = layout;
             return 0;
         }
-        if (layout == 5 || layout == 6) layout = 0;
+        if (layout == 5 || layout == 6 || layout == 7) layout = 0;
     }
     if (layout == 0) layout = many ? 1 : 2;
     int wpc = 1;
@@ -604,7 +608,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
 }
 
 static int launch_sampler(const NutsArgs &a, int count, int wpc, int dp, int nv, int layout, hipStream_t stream) {
-    if (layout == 5 || layout == 6) return launch_nuts_duo(a, count, a.cpb, a.duo_rw, dp, nv, stream);
+    if (layout == 5 || layout == 6 || layout == 7) return launch_nuts_duo(a, count, a.cpb, a.duo_rw, dp, nv, stream);
     if (layout >= 3) return launch_nuts_stream(a, count, dp, nv, stream);
     return launch_nuts(a, count, wpc, dp, nv, stream);
 }
@@ -625,7 +629,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
     c->last_segments = 0;
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
-    const bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 3) && k0 == 0 && count == c->K &&
+    const bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
                            o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
     if (use_queue) {
         HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));
@@ -688,15 +692,16 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
 #ifdef EPX_STAMPS
     n_lead = 0; a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr; c->last_split = 0;
     {
-        const int nblk = count * ((o.chains + a.cpb - 1) / a.cpb);
-        if (c->stamps_n < (size_t)nblk) {
+        const int nblk = use_queue ? a.seg_nwg : count * ((o.chains + a.cpb - 1) / a.cpb);      // (a pieced launch: one workgroup per piece)
+        // (two records of 8 sums per workgroup: the roles' shares, then the phases of the row team's pass)
+        if (c->stamps_n < (size_t)2 * nblk) {
             if (c->stamps) (void)hipFree(c->stamps);
-            HIPCHK(dalloc(&c->stamps, (size_t)nblk * 8));
-            c->stamps_n = nblk;
+            HIPCHK(dalloc(&c->stamps, (size_t)2 * nblk * 8));
+            c->stamps_n = 2 * nblk;
         }
-        HIPCHK(hipMemset(c->stamps, 0, (size_t)nblk * 64));
+        HIPCHK(hipMemset(c->stamps, 0, (size_t)2 * nblk * 64));
         a.stamps = c->stamps;
-        c->stamps_last = nblk;
+        c->stamps_last = 2 * nblk;
     }
 #endif
     HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
@@ -731,7 +736,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     c->last_layout = layout;
     c->nsamp = o.chains * nkeep;
     int herr = 0;
-    if (layout == 5 || layout == 6 || use_queue) HIPCHK(hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (layout == 5 || layout == 6 || layout == 7 || use_queue) HIPCHK(hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (herr) {
         HIPCHK(hipMemset(c->err_flag, 0, sizeof(int)));

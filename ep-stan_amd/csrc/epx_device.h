@@ -5,6 +5,13 @@
 
 #define EPX_WAVE 64
 
+// A pointer the compiler KNOWS to be global memory: through a generic pointer whose origin it cannot see (a base
+// rebuilt from scalar registers, a member of a struct) it emits flat_load / flat_store, which are counted in vmcnt AND
+// lgkmcnt and complete out of order -- every wait for an LDS read then also waits for the global stores in flight, and
+// a wait for a flat load is a vmcnt(0) that drains an LDS-DMA ring.
+typedef __attribute__((address_space(1))) double gdouble;
+__device__ inline gdouble *as_global(const double *p) { return reinterpret_cast<gdouble *>((uintptr_t)p); }
+
 namespace epx {
 
 // ----------------------------------------------------------------------------

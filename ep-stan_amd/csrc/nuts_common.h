@@ -31,21 +31,21 @@ __device__ inline double elemU(const Vec<NV> &x, int e) {
 // b[e]): for the vectors of the tree bookkeeping that change once per subtree or per transition.  `b`
 // is wave-uniform, so every access is `saddr + lane * 8 + immediate`.
 struct GRef {
-    double *p; bool ok;       // elements beyond the vector's length are 0 and not stored (fewer cache lines per vector)
+    gdouble *p; bool ok;       // elements beyond the vector's length are 0 and not stored (fewer cache lines per vector)
     __device__ operator double() const { return ok ? *p : 0.0; }
     __device__ const GRef &operator=(double x) const { if (ok) *p = x; return *this; }
     __device__ const GRef &operator=(const GRef &o) const { const double x = o; if (ok) *p = x; return *this; }
     __device__ const GRef &operator+=(double x) const { if (ok) *p = *p + x; return *this; }
 };
 struct GIdx {
-    double *b; int lane, len;
+    gdouble *b; int lane, len;
     __device__ GRef operator[](int i) const { return GRef{b + (lane + 64 * i), lane + 64 * i < len}; }
 };
 struct GVec { GIdx v; };
 // A wave-uniform scalar of the bookkeeping kept in the chain's global store: the adaptation state and the run's
 // statistics are touched once per transition -- as registers they would be live through every leapfrog
 struct GScal {
-    double *p;
+    gdouble *p;
     __device__ operator double() const { return *p; }
     __device__ const GScal &operator=(double x) const { *p = x; return *this; }
     __device__ const GScal &operator=(const GScal &o) const { const double x = *o.p; *p = x; return *this; }
@@ -61,11 +61,11 @@ enum { GV_QS, GV_GS, GV_PQ, GV_PP, GV_PG, GV_MQ, GV_MP, GV_MG, GV_RHO, GV_PSP, G
        GV_SCAL,                 // one vector's worth of scalars (GScal)
        GV_COUNT };
 
-__device__ inline double *uniform_ptr(double *p) {
+__device__ inline gdouble *uniform_ptr(double *p) {
     const unsigned long long u = (unsigned long long)p;
     const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
     const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return (double *)(((unsigned long long)hi32 << 32) | lo32);
+    return reinterpret_cast<gdouble *>((uintptr_t)(((unsigned long long)hi32 << 32) | lo32));
 }
 
 template <int DP> struct Log2 { static constexpr int v = 1 + Log2<DP / 2>::v; };

@@ -47,10 +47,19 @@ namespace epx {
 #define EPX_PRIO_S_BG 0
 #define EPX_PRIO_S_CRIT 2
 #endif
+// Hand-off words and slots live in LDS and are reached through address_space(3) pointers: through a generic pointer
+// the compiler emits flat_load / flat_store, which are counted in vmcnt AND lgkmcnt -- a wait for a polled flag or for
+// a result then also waits for every global store in flight (the tree stack's, ~1-2 us each)
+typedef double lds_v2f64 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_v2f64 *lds_v2f64_p;
+typedef volatile __attribute__((address_space(3))) int duo_flag_t;
+typedef __attribute__((address_space(3))) double duo_lds_f64;
+__device__ inline duo_flag_t *duo_flags_at(const void *generic) { return reinterpret_cast<duo_flag_t *>((uintptr_t)(unsigned)(size_t)generic); }
+__device__ inline duo_lds_f64 *duo_lds_at(const void *generic) { return reinterpret_cast<duo_lds_f64 *>((uintptr_t)(unsigned)(size_t)generic); }
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23, DUO_NO_MORE = 1 << 30 };
 enum { DUO_RESTART = 1, DUO_LEAVE = 2 };
 
-__device__ inline int duo_wait(const volatile int *flag, int want) {
+__device__ inline int duo_wait(duo_flag_t *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
         const int v = __builtin_amdgcn_readfirstlane(*flag);
         if (v == want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
@@ -59,7 +68,7 @@ __device__ inline int duo_wait(const volatile int *flag, int want) {
     return DUO_TIMEOUT;
 }
 // for counters that only grow (acknowledgements, generations)
-__device__ inline int duo_wait_ge(const volatile int *flag, int want) {
+__device__ inline int duo_wait_ge(duo_flag_t *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
         const int v = __builtin_amdgcn_readfirstlane(*flag);
         if (v >= want || v == DUO_EXIT) { asm volatile("" ::: "memory"); return v; }
@@ -67,10 +76,44 @@ __device__ inline int duo_wait_ge(const volatile int *flag, int want) {
     }
     return DUO_TIMEOUT;
 }
+// Row team (TEAM form): every chain of the workgroup has posted job `pass` or has left; returns the number of chains
+// still running, -1 when the wait gives up
+__device__ inline int team_wait_jobs(duo_flag_t *f_job4, int pass, int nch) {
+    for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+        int ready = 1, live = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int v = __builtin_amdgcn_readfirstlane(f_job4[c]);
+            const bool gone = v == DUO_EXIT || c >= nch;
+            ready &= (gone || v == pass) ? 1 : 0;
+            live += gone ? 0 : 1;
+        }
+        if (ready) { asm volatile("" ::: "memory"); return live; }
+        __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
+    }
+    return -1;
+}
+// State wave (TEAM form): all four row waves have published pass `seq`
+__device__ inline int team_wait_rows(duo_flag_t *f_team4, int seq) {
+    for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+        int ok = 1, quit = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int v = __builtin_amdgcn_readfirstlane(f_team4[w]);
+            ok &= v == seq ? 1 : 0;
+            quit |= v == DUO_EXIT ? 1 : 0;
+        }
+        if (quit) return DUO_EXIT;
+        if (ok) { asm volatile("" ::: "memory"); return seq; }
+        __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
+    }
+    return DUO_TIMEOUT;
+}
+__device__ inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 __device__ inline void ck_assign(GScal &x, double v) { x = v; }
 __device__ inline void ck_assign(RScal &x, double v) { x = v; }
 // everything this wave wrote to LDS is visible before the flag that follows
-__device__ inline void duo_publish(volatile int *flag, int v) {
+__device__ inline void duo_publish(duo_flag_t *flag, int v) {
 #if EPX_PUBLISH_NOWAIT
     // the LDS serves the instructions of one wave in order: the flag's store is performed behind the data's
     asm volatile("" ::: "memory");
@@ -94,9 +137,20 @@ __device__ inline void duo_publish(volatile int *flag, int v) {
         __builtin_amdgcn_sched_barrier(0);                                         \
     } while (0)
 #define STAMP_INIT unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#define TSTAMP(i)                                                                  \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+        tdet[i] += t_ - tprev2; tprev2 = t_;                                       \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+#define TSTAMP_INIT unsigned long long tdet[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tprev2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMP_INIT do { } while (0)
+#define TSTAMP(i) do { } while (0)
+#define TSTAMP_INIT do { } while (0)
 #endif
 
 typedef const __attribute__((address_space(4))) NutsArgs DuoArgsK;       // the kernel arguments where they are: kernarg segment
@@ -104,8 +158,6 @@ typedef const __attribute__((address_space(4))) NutsArgs DuoArgsK;       // the 
 // One piece of a chain's run: transitions [t_begin, t_end) of one site by the waves of one workgroup (the whole run
 // in a plain launch).  PIECED is a template parameter because the piece loop around this body costs it its register
 // allocation (76 -> 500 B of scratch per lane, 15 % of the time): the plain launch keeps the kernel without the loop.
-typedef double lds_v2f64 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) lds_v2f64 *lds_v2f64_p;
 
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
 __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queued, int q_site, int q_t0) {
@@ -128,9 +180,21 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // BK answers with a control record only when the trajectory continues elsewhere (other tree end, new
     // transition, step-size trial): generation-numbered, states of an old generation are dropped.
     constexpr bool BKW = CPB == 1;
+    // Row TEAM (CPB == 4, RW == 4; layout 7): the four row waves are not a chain's own -- they serve the four chains of
+    // the site together, in lock step, on the matrix pipe.  Pass p: every chain has posted job p; wave w takes a quarter
+    // of the site's 16-row tiles through  F = alpha + X B  (v_mfma_f64_4x4x4: 16 rows x 4 chains per instruction), the
+    // logistic terms on the product's own lanes (one (row, chain) per lane), and  G += X' g  with g as it stands in
+    // those lanes (the product's D layout IS the B layout of the transposed product); it also takes a 16-row group of
+    // the cavity term  Omega V  (Omega in registers as A operands, V = phi - mu of the four chains published with the
+    // jobs).  The rows are read from LDS twice per pass for FOUR gradients (eight times in the one-wave-per-chain form),
+    // by instructions that cost one issue slot per 16 x 4 x 4 multiply-adds.  The state waves are the ones of the
+    // RW > 1 form: they sum the four waves' partial results in wave order.
+    constexpr bool TEAM = CPB == 4 && RW == 4;
+    constexpr int BOFF = TEAM ? 2 : 1;                // beta behind alpha in the job (TEAM: 16-byte aligned pairs)
     constexpr int MREC = 4 * NV * 64 + 4;             // mailbox entry: q, p, grad, per-element log-density terms; ll, -, generation, -
     constexpr int CREC = 4 * NV * 64 + 4;             // control record: q, p, grad, metric, eps_l, command
-    constexpr int NFLAG = 1 + RW + (BKW ? 4 : 0);     // per chain: job, results, (mail, acknowledged, control generation, cavity term)
+    constexpr int NFLAG = TEAM ? 1 : 1 + RW + (BKW ? 4 : 0);     // per chain: job, results, (mail, acknowledged, control generation, cavity term); TEAM: the job word, the team's four words behind the chains'
+
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // waves 0..CPB-1: state wave of chain c; then the row waves.  A workgroup's waves go to the SIMDs
@@ -145,8 +209,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     const bool is_state = BKW ? wave == 1 : wave < CPB;
     const bool is_bk = BKW && wave == 0;
     const bool is_om = BKW && wave == 2 + RW;
-    const int team = BKW ? 0 : (is_state ? wave : ((wave - CPB) / RW + CPB - 1) % CPB);
-    const int wr = BKW ? (wave >= 2 && wave < 2 + RW ? wave - 2 : 0) : (is_state ? 0 : (wave - CPB) % RW);
+    const int team = BKW ? 0 : (is_state ? wave : (TEAM ? 0 : ((wave - CPB) / RW + CPB - 1) % CPB));
+    const int wr = BKW ? (wave >= 2 && wave < 2 + RW ? wave - 2 : 0) : (is_state ? 0 : (TEAM ? wave - CPB : (wave - CPB) % RW));
     const int bps = (a.chains + CPB - 1) / CPB;
     const bool segmented = queued;
     const int sb = queued ? q_site : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps));
@@ -169,10 +233,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     double *Xs = reinterpret_cast<double *>(smem);
     double *Oms = reinterpret_cast<double *>(smem + a.off_Om);        // [(pair p, row e)] -> (Om[e][2p], Om[e][2p+1])
     double *Ots = reinterpret_cast<double *>(smem + a.off_tail);      // [row r - 64][column], stride tstride
-    double *slot = reinterpret_cast<double *>(smem + a.off_slot) + (size_t)team * a.slot_doubles;
-    volatile int *flags = reinterpret_cast<volatile int *>(smem + a.off_flag) + team * NFLAG;
-    volatile int *f_job = flags, *f_res = flags + 1;
-    volatile int *f_mail = flags + 1 + RW, *f_ack = f_mail + 1, *f_ctl = f_mail + 2, *f_ov = f_mail + 3;
+    duo_lds_f64 *slot = duo_lds_at(smem + a.off_slot) + team * a.slot_doubles;
+    duo_flag_t *flags = duo_flags_at(smem + a.off_flag) + team * NFLAG;
+    duo_flag_t *f_job = flags, *f_res = TEAM ? duo_flags_at(smem + a.off_flag) + CPB : flags + 1;
+    duo_flag_t *f_mail = flags + 1 + RW, *f_ack = f_mail + 1, *f_ctl = f_mail + 2, *f_ov = f_mail + 3;
     double *mbox = reinterpret_cast<double *>(smem + a.off_spec);     // BKW: 2 x MREC, then 2 x CREC
     double *ctrl = mbox + 2 * MREC;
     (void)f_mail; (void)f_ack; (void)f_ctl; (void)f_ov; (void)mbox; (void)ctrl;
@@ -180,11 +244,12 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // ---- stage the site: rows HBM -> LDS once per site update (as k_nuts), cavity precision re-laid
     {
         const double *Xg = a.X + (size_t)row0 * D;
-        const int nslot = n * SPR;
+        const int nslot = (TEAM ? (n + 15) / 16 * 16 : n) * SPR;       // (TEAM: whole 16-row tiles, zero rows behind the site's)
         for (int s = tid; s < nslot; s += blockDim.x) {
             const int r = s / SPR, jp = s % SPR, c0 = 2 * jp;
             double2 v;
-            if ((D & 1) == 0 && c0 + 1 < D) v = *reinterpret_cast<const double2 *>(Xg + (size_t)r * D + c0);
+            if (r >= n) { v.x = 0.0; v.y = 0.0; }
+            else if ((D & 1) == 0 && c0 + 1 < D) v = *reinterpret_cast<const double2 *>(Xg + (size_t)r * D + c0);
             else {
                 v.x = c0 < D ? Xg[(size_t)r * D + c0] : 0.0;
                 v.y = c0 + 1 < D ? Xg[(size_t)r * D + c0 + 1] : 0.0;
@@ -193,26 +258,221 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             *reinterpret_cast<double2 *>(Xs + (size_t)r * DP + 2 * (jp ^ sw)) = v;
         }
         const double *Om_g = a.cav_Om + (size_t)k * d * d;                // column-major, symmetric
-        for (int idx = tid; idx < npad * dm; idx += blockDim.x) {
-            const int p = idx / dm, e = idx % dm;
-            double2 v;
-            v.x = 2 * p < dm ? Om_g[(size_t)(2 * p) * d + e] : 0.0;
-            v.y = 2 * p + 1 < dm ? Om_g[(size_t)(2 * p + 1) * d + e] : 0.0;
-            *reinterpret_cast<double2 *>(Oms + 2 * (size_t)idx) = v;
-        }
-        if constexpr (NV > 1) {
-            for (int idx = tid; idx < 2 * tstride; idx += blockDim.x) {
-                const int r = idx / tstride, j = idx % tstride;
-                Ots[idx] = (r < tr && j < d) ? Om_g[(size_t)j * d + dm + r] : 0.0;
+        if constexpr (!TEAM) {
+            for (int idx = tid; idx < npad * dm; idx += blockDim.x) {
+                const int p = idx / dm, e = idx % dm;
+                double2 v;
+                v.x = 2 * p < dm ? Om_g[(size_t)(2 * p) * d + e] : 0.0;
+                v.y = 2 * p + 1 < dm ? Om_g[(size_t)(2 * p + 1) * d + e] : 0.0;
+                *reinterpret_cast<double2 *>(Oms + 2 * (size_t)idx) = v;
             }
+            if constexpr (NV > 1) {
+                for (int idx = tid; idx < 2 * tstride; idx += blockDim.x) {
+                    const int r = idx / tstride, j = idx % tstride;
+                    Ots[idx] = (r < tr && j < d) ? Om_g[(size_t)j * d + dm + r] : 0.0;
+                }
+            }
+        } else {
+            // (the cavity precision lives in the row waves' registers; jobs and results start as zeros: the column of a
+            // chain that does not exist stays finite)
+            double *s0 = reinterpret_cast<double *>(smem + a.off_slot);
+            for (int idx = tid; idx < CPB * a.slot_doubles; idx += blockDim.x) s0[idx] = 0.0;
         }
-        if (tid < CPB * NFLAG) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
+        if (tid < (TEAM ? 2 * CPB : CPB * NFLAG)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
         if constexpr (BKW) { for (int idx = tid; idx < 2 * MREC; idx += blockDim.x) mbox[idx] = 0.0; }     // (entries beyond P stay 0)
     }
     __syncthreads();                                   // the only workgroup barrier of a piece
     if (chain >= a.chains) return;
 
-    if (!is_state && !is_bk && !is_om) {
+    if constexpr (TEAM) {
+        if (!is_state) {
+            // ================================================================= row team (see TEAM above)
+            // v_mfma_f64_4x4x4f64 operand layout (measured, scripts/probe/mfma_layout.hip): A[b][i][k] in lane 16 k + 4 b + i,
+            // B[b][k][j] in lane 16 k + 4 b + j, D[b][i][j] in lane 16 i + 4 b + j.  With lane = (hi, bb, lo):
+            //   forward   A = X[row 4 bb + lo of the tile][column 8 r + 2 hi (+1)],   B = beta of chain lo at those columns,
+            //             D = f[row 4 bb + hi][chain lo]  -- and g = y - sigmoid(f) in the same lanes is the
+            //   backward  B = g[row 4 bb + hi][chain lo],   A = X[row 4 bb + hi][column 8 r + 2 lo (+1)],
+            //             D = (X' g)[column 8 r + 2 hi (+1)][chain lo], one partial sum per row block bb.
+            // One ds_read_b128 feeds two MFMAs (the two columns of a 16-byte slot are two k-steps / two column groups);
+            // the row images' XOR swizzle (slot ^ row) keeps both read patterns free of bank conflicts.
+            constexpr int KS = DP / 4, NRD = DP / 8, ROWB = DP * 8, TILEB = 16 * ROWB;
+            constexpr int DMAX = 2 * DP + 2;               // cavity term: d <= 2 D + 2 rows
+            constexpr int NJ = (DMAX + 3) / 4;             // its k-steps
+            constexpr int NGF = DMAX / 16;                 // 16-row groups, one per row wave; rows 16 NGF .. + 3 (wave 3) by a k-split
+            constexpr int NJT = (NJ + 3) / 4;
+            static_assert(NGF <= 4, "one 16-row group of the cavity term per row wave");
+            const int lo = lane & 3, bb = (lane >> 2) & 3, hi = lane >> 4;
+            const int nch = a.chains - cb * CPB < CPB ? a.chains - cb * CPB : CPB;
+            const int ntile = (n + 15) >> 4, tpw = (ntile + 3) >> 2;
+            const int t0 = wr * tpw, t1 = ntile < t0 + tpw ? ntile : t0 + tpw;
+            const int sdb = a.slot_doubles;
+            // cavity precision as A operands: group wr (rows 16 wr + 4 bb + lo, columns 4 J + hi); wave 3 also the rows
+            // beyond the groups, block bb taking the k-steps J = bb, bb + 4, ...
+            double om[NJ], omt[NJT];
+            {
+                const double *Om_g = a.cav_Om + (size_t)k * d * d;
+                const int e = 16 * wr + 4 * bb + lo;
+#pragma unroll
+                for (int J = 0; J < NJ; ++J) {
+                    const int c = 4 * J + hi;
+                    om[J] = (wr < NGF && e < d && c < d) ? Om_g[(size_t)c * d + e] : 0.0;
+                }
+                const int et = 16 * NGF + lo;
+#pragma unroll
+                for (int tt = 0; tt < NJT; ++tt) {
+                    const int c = 4 * (4 * tt + bb) + hi;
+                    omt[tt] = (wr == 3 && et < d && c < d) ? Om_g[(size_t)c * d + et] : 0.0;
+                }
+            }
+            const bool g_on = wr < NGF && 16 * wr < d, t_on = wr == 3 && d > 16 * NGF;
+            const int rf = lane & 15, rb = 4 * bb + hi;    // row within a tile: forward operand; backward operand and products
+            unsigned ybits = 0;                            // responses of this lane's product rows, one bit per tile
+            for (int t = t0; t < t1; ++t) {
+                const int r = 16 * t + rb;
+                if (r < n && a.y[row0 + r]) ybits |= 1u << (t - t0);
+            }
+            const unsigned xbase = (unsigned)(size_t)Xs;
+            const unsigned swf = (unsigned)((rf / RPL) & (SPR - 1)), swb = (unsigned)((rb / RPL) & (SPR - 1));
+            unsigned af[NRD], ab[NRD];
+#pragma unroll
+            for (int r = 0; r < NRD; ++r) {
+                af[r] = xbase + (unsigned)rf * ROWB + ((((unsigned)(4 * r + hi)) ^ swf) << 4);
+                ab[r] = xbase + (unsigned)rb * ROWB + ((((unsigned)(4 * r + lo)) ^ swb) << 4);
+            }
+            duo_lds_f64 *const sl = slot + lo * sdb;   // the slot of chain lo (team == 0 here: `slot` is chain 0's)
+            STAMP_INIT;
+            TSTAMP_INIT;
+            __builtin_amdgcn_s_setprio(EPX_PRIO_R);
+            for (int pass = 1;; ++pass) {
+                const int live = team_wait_jobs(f_job, pass, nch);
+                STAMP(5);
+                TSTAMP(0);
+                if (live <= 0) {
+                    if (live < 0) { if (lane == 0) atomicOr(a.err, 1); f_res[wr] = DUO_EXIT; }
+#ifdef EPX_STAMPS
+                    if (a.stamps && wr == 0 && lane == 0) {
+                        a.stamps[(size_t)blockIdx.x * 8 + 5] = tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] = tacc[6];
+                        for (int i = 0; i < 7; ++i) a.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + i] = tdet[i];
+                        a.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)(pass - 1);
+                    }
+#endif
+                    return;
+                }
+                // ---- operands of this pass
+                double bop[KS];
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) {
+                    const lds_v2f64 v = *(lds_v2f64_p)(sl + JOB + BOFF + 8 * r + 2 * hi);
+                    bop[2 * r] = v.x; bop[2 * r + 1] = v.y;
+                }
+                const double alpha_c = sl[JOB];
+                // ---- cavity term Omega V of the four chains
+                if (g_on) {
+                    double acc = 0.0, acc1 = 0.0;             // (two chains: a dependent product issues 4 cycles later than a free one)
+#pragma unroll
+                    for (int J = 0; J < NJ; J += 2) {
+                        if (4 * J < d) acc = mfma4(om[J], sl[VOFF + 4 * J + hi], acc);
+                        if (J + 1 < NJ && 4 * (J + 1) < d) acc1 = mfma4(om[J + 1 < NJ ? J + 1 : J], sl[VOFF + 4 * (J + 1) + hi], acc1);
+                    }
+                    sl[OVOFF + 16 * wr + rb] = acc + acc1;
+                }
+                if (t_on) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int tt = 0; tt < NJT; ++tt) acc = mfma4(omt[tt], sl[VOFF + 4 * (4 * tt + bb) + hi], acc);
+                    acc += dpp_d<0x124>(acc); acc += dpp_d<0x128>(acc);          // the four blocks' k-shares (row_ror 4, 8)
+                    if (bb == 0) sl[OVOFF + 16 * NGF + hi] = acc;
+                }
+                TSTAMP(1);
+                // ---- the rows: two tiles per round (their logistic terms overlap).  The LDS reads run ahead of their
+                // use: the backward operands of a round and the forward operands of the NEXT round are requested
+                // before the round's logistic terms, so no product waits for an LDS round trip
+                double gacc[KS];
+#pragma unroll
+                for (int c = 0; c < KS; ++c) gacc[c] = 0.0;
+                double dsum = 0.0, lsum = 0.0, wprod = 1.0;
+                unsigned yb = ybits;
+                lds_v2f64 xf0[NRD], xf1[NRD];
+                {
+                    const unsigned o0 = (unsigned)t0 * TILEB, o1 = t0 + 1 < t1 ? o0 + TILEB : o0;
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) {
+                        xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + o0));
+                        xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + o1));
+                    }
+                }
+                for (int t = t0; t < t1; t += 2) {
+                    const bool two = t + 1 < t1;
+                    const unsigned o0 = (unsigned)t * TILEB, o1 = two ? o0 + TILEB : o0;
+                    double f0 = alpha_c, f1 = alpha_c;
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) {
+                        // (the two tiles' chains alternate: a product that waits for its own accumulator issues 4 cycles late)
+                        f0 = mfma4(xf0[r].x, bop[2 * r], f0); f1 = mfma4(xf1[r].x, bop[2 * r], f1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f0 = mfma4(xf0[r].y, bop[2 * r + 1], f0); f1 = mfma4(xf1[r].y, bop[2 * r + 1], f1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    TSTAMP(2);
+                    lds_v2f64 xb0[NRD], xb1[NRD];
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) {
+                        xb0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(ab[r] + o0));
+                        xb1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(ab[r] + o1));
+                    }
+                    {
+                        // (the round after the last one re-reads this round's tiles: a valid address, values unused)
+                        const int tn = t + 2 < t1 ? t + 2 : t;
+                        const unsigned n0 = (unsigned)tn * TILEB, n1 = tn + 1 < t1 ? n0 + TILEB : n0;
+#pragma unroll
+                        for (int r = 0; r < NRD; ++r) {
+                            xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + n0));
+                            xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + n1));
+                        }
+                    }
+                    TSTAMP(3);
+                    double l0, l1, w0, w1, g0, g1;
+                    logistic_split2(f0, f1, (double)(yb & 1u), (double)((yb >> 1) & 1u), l0, l1, w0, w1, g0, g1);
+                    yb >>= 2;
+                    if (!two || 16 * (t + 2) > n) {        // the site's last tile: rows beyond n add nothing
+                        const bool v0 = 16 * t + rb < n, v1 = two && 16 * (t + 1) + rb < n;
+                        l0 = v0 ? l0 : 0.0; w0 = v0 ? w0 : 1.0; g0 = v0 ? g0 : 0.0;
+                        l1 = v1 ? l1 : 0.0; w1 = v1 ? w1 : 1.0; g1 = v1 ? g1 : 0.0;
+                    }
+                    lsum += l0; wprod *= w0; dsum += g0;
+                    lsum += l1; wprod *= w1; dsum += g1;
+                    TSTAMP(4);
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) {
+                        gacc[2 * r] = mfma4(xb0[r].x, g0, gacc[2 * r]); gacc[2 * r + 1] = mfma4(xb0[r].y, g0, gacc[2 * r + 1]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) {
+                        gacc[2 * r] = mfma4(xb1[r].x, g1, gacc[2 * r]); gacc[2 * r + 1] = mfma4(xb1[r].y, g1, gacc[2 * r + 1]);
+                    }
+                    TSTAMP(5);
+                }
+                // ---- sums over the row blocks (lanes ^ 4, ^ 8), then over the rows hi of a block for the two scalars
+                // (a product with ones: D[.][j] = sum over k of B[k][j])
+#pragma unroll
+                for (int c = 0; c < KS; ++c) { gacc[c] += dpp_d<0x124>(gacc[c]); gacc[c] += dpp_d<0x128>(gacc[c]); }
+                double dz = mfma4(1.0, dsum, 0.0), lz = mfma4(1.0, lsum - log_ge1_d(wprod), 0.0);
+                dz += dpp_d<0x124>(dz); lz += dpp_d<0x124>(lz);
+                dz += dpp_d<0x128>(dz); lz += dpp_d<0x128>(lz);
+                duo_lds_f64 *res = sl + RESO + wr * RREC;
+                if (bb == 0) {
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) res[8 * (c >> 1) + 2 * hi + (c & 1)] = gacc[c];
+                    if (hi == 0) { res[DP] = dz; res[DP + 1] = lz; }
+                }
+                duo_publish(f_res + wr, pass);
+                STAMP(6);
+                TSTAMP(6);
+            }
+        }
+    }
+
+    if (!TEAM && !is_state && !is_bk && !is_om) {
         // ================================================================= row wave
         // responses of this lane's rows as a bit mask (row of iteration `it`: wr*64 + lane + it*64*RW)
         unsigned long long ybits = 0;
@@ -240,7 +500,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #endif
                 return;
             }
-            const double *job = slot + JOB;
+            const duo_lds_f64 *job = slot + JOB;
             const double alpha = job[0];
             double beta_l = job[1 + (lane < DP ? lane : 0)];
             if (lane >= D) beta_l = 0.0;
@@ -326,7 +586,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
             wave_sum2(da, ll);
-            double *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
+            duo_lds_f64 *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
             if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
             if (lane == 0) { res[DP] = da; res[DP + 1] = ll; }
             duo_publish(f_res + wr, seq);
@@ -339,7 +599,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             // ============================================================= cavity-term wave (one chain per workgroup)
             // Omega v for the position of every job, v = phi - mu published with the job: lane e holds row e (the rows
             // beyond 64 on lanes 0, 1 of a second register); OUP column pairs per round, loads first
-            const double *vj = slot + VOFF;
+            const duo_lds_f64 *vj = slot + VOFF;
             const int e0 = lane < dm ? lane : dm - 1;
             const double2 *Op = reinterpret_cast<const double2 *>(Oms) + e0;
             const int rcw = lane < 2 ? lane : 1;
@@ -356,7 +616,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #pragma unroll
                     for (int u = 0; u < OUP; ++u) {
                         o[u] = Op[(size_t)(p0 + u) * dm];
-                        vp[u] = *reinterpret_cast<const double2 *>(vj + 2 * ((p0 + u) & 31));      // uniform address: a broadcast
+                        { const lds_v2f64 t2 = *(lds_v2f64_p)(vj + 2 * ((p0 + u) & 31)); vp[u].x = t2.x; vp[u].y = t2.y; }      // uniform address: a broadcast
                         if constexpr (NV > 1) tt[u] = Tp[p0 + u]; else tt[u] = o[u];
                     }
 #pragma unroll
@@ -390,7 +650,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     const size_t g_stack = (size_t)a.max_depth * SREC;                 // the cold store sits behind the stack's place
     // (pieced launches: the tree stack and the cold store belong to the persistent WORKGROUP, so no line of them is ever
     // cached by two XCDs; what a chain carries from piece to piece goes through the checkpoint record)
-    double *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
+    gdouble *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
     // (the checkpoint record's address is formed where it is used: nothing of a pieced launch stays live through the loops)
     auto ck_rec = [&](int t_boundary) -> double * { return piece_record(a, sb, t_boundary, chain, NV); };
     auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
@@ -404,7 +664,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     using CV = typename std::conditional<COLD, GVec, V>::type;
     V mu, inv_e, zq, zp, zg;
     CV qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, bq, bg;
-    double *cold = COLD ? stk_g + g_stack : nullptr;
+    gdouble *cold = COLD ? stk_g + g_stack : nullptr;
     auto bind = [&](CV &x, int which, int ln) {
         if constexpr (COLD) { x.v.b = cold + (size_t)which * NV * 64; x.v.lane = ln; x.v.len = P; }
     };
@@ -418,7 +678,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     using CS = typename std::conditional<COLD, GScal, RScal>::type;
     CS lps, da_mu, s_bar, x_bar, da_count, va_n, eps_sum, acc_sum, depth_sum, nleap_tot, plp, mlp, b_plp, lsw, t_end_c;
     if constexpr (COLD) {
-        double *sc0 = cold + (size_t)GV_SCAL * NV * 64;
+        gdouble *sc0 = cold + (size_t)GV_SCAL * NV * 64;
         lps.p = sc0; da_mu.p = sc0 + 1; s_bar.p = sc0 + 2; x_bar.p = sc0 + 3; da_count.p = sc0 + 4; va_n.p = sc0 + 5;
         eps_sum.p = sc0 + 6; acc_sum.p = sc0 + 7; depth_sum.p = sc0 + 8; nleap_tot.p = sc0 + 9;
         plp.p = sc0 + 10; mlp.p = sc0 + 11; b_plp.p = sc0 + 12; lsw.p = sc0 + 13; t_end_c.p = sc0 + 14;
@@ -621,6 +881,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         }
     };
 
+    auto rows_in = [&](int sq_) -> bool {               // the row waves' results of job sq_ are in
+        if constexpr (TEAM) return team_wait_rows(f_res, sq_) == sq_;
+        else {
+            bool ok = true;
+            for (int w = 0; w < RW; ++w) ok &= duo_wait(f_res + w, sq_) == sq_;
+            return ok;
+        }
+    };
     // (zq, zp, zg) holds the last finished leapfrog state; `pending`: its bookkeeping is still to run
     double f_lpt = 0.0, f_ks = 0.0, f_ll = 0.0;     // its log density / kinetic energy, not yet summed over the lanes
     bool pending = false;
@@ -666,10 +934,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             if (ctl < 0) { bail = 1; break; }
             if (ctl != gen) {
                 if (fast_pub) {                    // the job in flight continues a trajectory nobody wants: let it land
-                    for (int w = 0; w < RW; ++w) {
-                        const int got = duo_wait(f_res + w, seq);
-                        if (got != seq) bail = 1;
-                    }
+                    if (!rows_in(seq)) bail = 1;
                     if (duo_wait(f_ov, seq) != seq) bail = 1;       // (the cavity-term wave reads v: it must be done, too)
                     if (bail) break;
                 }
@@ -712,8 +977,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 beta_l = gatherV(sq, 2 + lane) + gatherV(sq, d + 1 + lane) * gatherV(eq, 2 + D + lane);
             }
             // ---- hand (alpha, beta) to the row waves
-            double *job = slot + JOB;
-            if (lane < DP) job[1 + lane] = beta_l;
+            duo_lds_f64 *job = slot + JOB;
+            if constexpr (TEAM) beta_l = lane < D ? beta_l : 0.0;         // (the padding columns of the B operand stay finite)
+            if (lane < DP) job[BOFF + lane] = beta_l;
             if (lane == 0) job[0] = alpha;
             if constexpr (RW > 1) {
                 FORV { const int e = lane + 64 * i; slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
@@ -765,10 +1031,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             const bool same_end = mode == MODE_TREE && depth > 0 && fwd == fwd_was && eps_l == job_eps;
             if (leave || !(parked || same_end)) {
                 // the job in flight continues a trajectory that is no longer wanted: let it land, drop it
-                for (int w = 0; w < RW; ++w) {
-                    const int got = duo_wait(f_res + w, seq);
-                    if (got != seq) bail = 1;
-                }
+                if (!rows_in(seq)) bail = 1;
                 STAMP(3);
                 if (bail || leave) { bail |= leave << 1; break; }
                 fast_pub = false;               // the new start goes out by the full transforms at the loop top
@@ -832,10 +1095,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 
         STAMP(2);
         // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
-        for (int w = 0; w < RW; ++w) {
-            const int got = duo_wait(f_res + w, seq);
-            if (got != seq) bail = 1;
-        }
+        if (!rows_in(seq)) bail = 1;
         if constexpr (BKW) { if (duo_wait(f_ov, seq) != seq) bail = 1; }
         STAMP(3);
         __builtin_amdgcn_s_setprio(EPX_PRIO_S_CRIT);    // chain rule, half kick, drift, publish: the row waves wait for it
@@ -866,8 +1126,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             vq1 = vq1 + eps_l * vm1 * vp1; vq2 = vq2 + eps_l * vm2 * vp2; vq3 = vq3 + eps_l * vm3 * vp3;
             vex3 = exp_d(vq3);
             const double ba = vq1 + vq2 * vex3;
-            double *job = slot + JOB;
-            if (lane < DP) job[1 + lane] = ba;
+            duo_lds_f64 *job = slot + JOB;
+            if (lane < DP) job[BOFF + lane] = (!TEAM || lane < D) ? ba : 0.0;
             if (lane == LA) job[0] = ba;
             if constexpr (RW > 1) {
                 // v = phi - mu of the next position for the row waves' cavity term: the view holds ALL of phi
@@ -1062,7 +1322,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #undef a
 
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
-__global__ void __launch_bounds__(64 * (CPB * (1 + RW) + (CPB == 1 ? 2 : 0)))
+__global__ void __launch_bounds__(64 * (CPB == 4 && RW == 4 ? 8 : CPB * (1 + RW) + (CPB == 1 ? 2 : 0)))
 k_nuts_duo(NutsArgs a_by_value) {
     extern __shared__ __align__(16) unsigned char smem[];
     (void)a_by_value;
@@ -1102,15 +1362,16 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     const int nv = (a.P + 63) / 64;
     const int ou = nv > 1 ? 4 : 8;                                                     // as the kernel (OU)
     const int d = a.d, dm = d < 64 ? d : 64, npad = ((dm + 1) / 2 + ou - 1) / ou * ou;
-    size_t off = (size_t)n_max * dp * 8;
+    const bool teamm = cpb == 4 && rw == 4;                                            // as the kernel (TEAM): whole 16-row tiles, no cavity precision in LDS
+    size_t off = (size_t)(teamm ? (n_max + 15) / 16 * 16 : n_max) * dp * 8;
     a.n_max = n_max; a.duo_rw = rw; a.cpb = cpb;
-    a.off_Om = (int)off; off += (size_t)npad * dm * 16;
-    a.off_tail = (int)off; off += nv > 1 ? (size_t)2 * (2 * npad + 2) * 8 : 0;
+    a.off_Om = (int)off; off += teamm ? 0 : (size_t)npad * dm * 16;
+    a.off_tail = (int)off; off += nv > 1 && !teamm ? (size_t)2 * (2 * npad + 2) * 8 : 0;
     off = (off + 15) & ~(size_t)15;
     a.slot_doubles = rw == 1 ? dp + 2 : (dp + 2) + nv * 64 + rw * (dp + 2) + nv * 64;            // as the kernel (VOFF, RESO, OVOFF)
     a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
     const bool bkw = cpb == 1;                                                        // as the kernel (BKW)
-    a.off_flag = (int)off; off += (size_t)cpb * (1 + rw + (bkw ? 4 : 0)) * 4;
+    a.off_flag = (int)off; off += teamm ? 32 : (size_t)cpb * (1 + rw + (bkw ? 4 : 0)) * 4;
     off = (off + 15) & ~(size_t)15;
     a.off_spec = 0;
     if (bkw) { a.off_spec = (int)off; off += (size_t)2 * ((4 * nv * 64 + 4) + (4 * nv * 64 + 4)) * 8; }
@@ -1135,7 +1396,7 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (CPB * (1 + RW) + (CPB == 1 ? 2 : 0))), a.lds_bytes, stream, a);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (CPB == 4 && RW == 4 ? 8 : CPB * (1 + RW) + (CPB == 1 ? 2 : 0))), a.lds_bytes, stream, a);
         return (int)hipGetLastError();
     };
     constexpr bool COLD = NV >= 2 || CPB > 1;
@@ -1149,12 +1410,13 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 template <int NV, int DP>
 static int launch_duo_shape(const NutsArgs &a, int nblocks, int cpb, int rw, hipStream_t stream) {
     if (cpb == 4 && rw == 1) return launch_duo_one<NV, DP, 4, 1>(a, nblocks, stream);
+    if (cpb == 4 && rw == 4) return launch_duo_one<NV, DP, 4, 4>(a, nblocks, stream);
     if (cpb == 1 && rw == 2) return launch_duo_one<NV, DP, 1, 2>(a, nblocks, stream);
     return -1;
 }
 
 bool nuts_duo_has(int cpb, int rw, int dp, int nv) {
-    return ((cpb == 4 && rw == 1) || (cpb == 1 && rw == 2)) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
+    return ((cpb == 4 && (rw == 1 || rw == 4)) || (cpb == 1 && rw == 2)) && (dp == 16 || dp == 32) && (nv == 1 || nv == 2);
 }
 
 int launch_nuts_duo(const NutsArgs &a, int count, int cpb, int rw, int dp, int nv, hipStream_t stream) {

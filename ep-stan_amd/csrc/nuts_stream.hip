@@ -47,14 +47,14 @@ template <int NV> struct VecS { double v[NV]; };
 
 // cold-store vector: same `.v[i]` syntax as VecS, backed by global memory
 struct ColdRef {
-    double *p;
+    gdouble *p;
     __device__ operator double() const { return *p; }
     __device__ const ColdRef &operator=(double x) const { *p = x; return *this; }
     __device__ const ColdRef &operator=(const ColdRef &o) const { const double x = *o.p; *p = x; return *this; }
     __device__ const ColdRef &operator+=(double x) const { *p = *p + x; return *this; }
 };
 // b is wave-uniform (scalar registers), so every access is `saddr + lane*8 + immediate`
-struct ColdIdx { double *b; int lane; __device__ ColdRef operator[](int i) const { return ColdRef{b + (lane + 64 * i)}; } };
+struct ColdIdx { gdouble *b; int lane; __device__ ColdRef operator[](int i) const { return ColdRef{b + (lane + 64 * i)}; } };
 struct ColdV { ColdIdx v; };
 enum { CV_QS, CV_GS, CV_PQ, CV_PP, CV_PG, CV_MQ, CV_MP, CV_MG, CV_RHO, CV_PSP, CV_PSM, CV_WMEAN, CV_WM2, CV_BQ, CV_BG, CV_COUNT };
 
@@ -178,14 +178,14 @@ k_nuts_stream(NutsArgs a) {
     double *ckp = queued ? piece_record(a, sb, t_begin, active ? chain : 0, NV) : nullptr;            // the record this piece starts from
     double *ckp_out = queued ? piece_record(a, sb, t_end, active ? chain : 0, NV) : nullptr;        // ... and the one it leaves
     // wave-uniform base pointers (held in scalar registers; lanes add lane*8)
-    auto uniform_ptr = [](double *p) -> double * {
+    auto uniform_ptr = [](double *p) -> gdouble * {
         const unsigned long long u = (unsigned long long)p;
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        return (double *)(((unsigned long long)hi32 << 32) | lo32);
+        return reinterpret_cast<gdouble *>((uintptr_t)(((unsigned long long)hi32 << 32) | lo32));
     };
-    double *stk_g = uniform_ptr(a.stack + chain_slot * ((size_t)a.max_depth * SREC + (size_t)CV_COUNT * PMAX));
-    double *cold = stk_g + (size_t)a.max_depth * SREC;
+    gdouble *stk_g = uniform_ptr(a.stack + chain_slot * ((size_t)a.max_depth * SREC + (size_t)CV_COUNT * PMAX));
+    gdouble *cold = stk_g + (size_t)a.max_depth * SREC;
     auto ld_stk = [&](int off) -> double { return stk_g[off]; };
     auto st_stk = [&](int off, double v) { stk_g[off] = v; };
 

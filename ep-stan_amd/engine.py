@@ -306,7 +306,7 @@ class HipEngine(object):
         (up to 4) chains of a workgroup advance in lock step and share one pass per leapfrog;
         otherwise every gradient is its own pass (over LDS-resident rows)."""
         cs = self.get_chain_stats(chains, k0, count)[:, :, 3]
-        if self.last_layout() in (1, 2, 5, 6):
+        if self.last_layout() in (1, 2, 5, 6, 7):
             return cs.sum(axis=1)
         nb = (chains + 3) // 4
         pad = np.zeros((cs.shape[0], nb * 4)); pad[:, :chains] = cs

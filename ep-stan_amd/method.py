@@ -816,7 +816,8 @@ class Master(object):
                         # when a site fills the LDS (one workgroup per CU) and there are more sites than CUs: run the
                         # sampler from a piece queue -- one workgroup per piece of a site's transitions, the site with
                         # the largest predicted remaining work first (same draws; only the dispatch changes)
-                        if eng.last_layout() in (5, 3) and n_lead == 0 and self._one_workgroup_per_cu():
+                        if (eng.last_layout() in (5, 7, 3) and n_lead == 0 and self.K_local > eng.cu_count()
+                                and self._one_workgroup_per_cu()):
                             it_s = w0.stan_params['iter']
                             lf = eng.get_chain_stats(w0.stan_params['chains'])[:, :, 3]
                             eng.set_piece_queue(max(1, it_s // self.PIECES_PER_SITE), np.maximum(lf.max(axis=1), 1.0) / it_s)

@@ -8,3 +8,4 @@ hipcc --offload-arch=gfx950 -O2 scripts/probe/mfma_layout.hip -o variants/mfma_l
 hipcc --offload-arch=gfx950 -O2 scripts/probe/concurrent.hip -o variants/concurrent
 hipcc --offload-arch=gfx950 -O2 scripts/probe/xcu_latency.hip -o variants/xcu_latency
 echo "built variants/stream_probe variants/mfma_layout variants/concurrent variants/xcu_latency"
+hipcc --offload-arch=gfx950 -O2 scripts/probe/mfma_rate.hip -o variants/mfma_rate

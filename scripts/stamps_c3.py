@@ -29,6 +29,9 @@ def main():
     lib.epx_dbg_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     nb = lib.epx_dbg_get_stamps(eng.ctx, buf.ctypes.data, 8192)
     st = buf[:nb].astype(np.float64)
+    det = None
+    if nb % 2 == 0 and eng.last_layout() == 7:          # second half: the phases of the row team's pass
+        det = st[nb // 2:]; st = st[:nb // 2]; nb //= 2
     per = st[:, :7] / st[:, 7:8]
     med = np.median(per, axis=0)
     lf = eng.get_chain_stats(4)[:, :, 3]
@@ -38,6 +41,13 @@ def main():
     print('cycles per leapfrog (median over %d blocks), total %.0f' % (nb, med.sum()))
     for nm, v in zip(NAMES_DUO if eng.last_layout() >= 5 else NAMES, med):
         print('    %-36s %8.0f  %5.1f%%' % (nm, v, 100 * v / med.sum()))
+    if det is not None:
+        ok = det[:, 7] > 0
+        pd = np.median(det[ok, :7] / det[ok, 7:8], axis=0)
+        print('row team, cycles per pass (median over %d blocks), total %.0f' % (ok.sum(), pd.sum()))
+        for nm, v in zip(['waiting for the jobs', 'operands + cavity term', 'forward products', 'LDS requests', 'logistic terms',
+                          'backward products', 'sums + publication'], pd):
+            print('    %-36s %8.0f  %5.1f%%' % (nm, v, 100 * v / pd.sum()))
     big = int(np.argmax(st[:, 7]))
     print('the workgroup with the most leapfrogs (%d): cycles per leapfrog %s, total S %.0f, total R %.0f'
           % (st[big, 7], np.round(per[big]).astype(int), per[big, :5].sum(), per[big, 5:7].sum()))
