@@ -558,7 +558,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
                 }
                 a.stack = c->stack;
             }
-            a.no_spec = 0;
+            a.no_spec = seven && getenv("EPX_NO_LEAN") ? 1 : 0;       // (diagnostic: layout 7 with the full chain rule in every round)
             *wpc_out = rw; *dp_out = dp; *nv_out = nv; *layout_out = layout;
             return 0;
         }

@@ -109,6 +109,14 @@ __device__ inline int team_wait_rows(duo_flag_t *f_team4, int seq) {
     }
     return DUO_TIMEOUT;
 }
+// Lanes of ONE wave exchange values through LDS: for the compiler that is a data race unless the stores are released
+// and the loads acquire (without it a load behind `if (lane writes) store` is taken to return what an earlier load of
+// the address returned in the lanes that did not store).  No instruction beyond the wait for the stores.
+__device__ inline void wave_lds_exchange() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 __device__ inline void ck_assign(GScal &x, double v) { x = v; }
 __device__ inline void ck_assign(RScal &x, double v) { x = v; }
@@ -277,6 +285,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             // chain that does not exist stays finite)
             double *s0 = reinterpret_cast<double *>(smem + a.off_slot);
             for (int idx = tid; idx < CPB * a.slot_doubles; idx += blockDim.x) s0[idx] = 0.0;
+            double *s1 = reinterpret_cast<double *>(smem + a.off_scr);
+            for (int idx = tid; idx < CPB * NV * 64; idx += blockDim.x) s1[idx] = 0.0;
         }
         if (tid < (TEAM ? 2 * CPB : CPB * NFLAG)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
         if constexpr (BKW) { for (int idx = tid; idx < 2 * MREC; idx += blockDim.x) mbox[idx] = 0.0; }     // (entries beyond P stay 0)
@@ -653,8 +663,18 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     gdouble *stk_g = (STL && !COLD) ? nullptr : uniform_ptr(a.stack + ((size_t)(segmented ? (int)blockIdx.x : sb) * a.chains + chain) * a.stack_stride);
     // (the checkpoint record's address is formed where it is used: nothing of a pieced launch stays live through the loops)
     auto ck_rec = [&](int t_boundary) -> double * { return piece_record(a, sb, t_boundary, chain, NV); };
-    auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
-    auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
+    // When the whole stack does not fit, its lowest levels still may (stack_lds_levels; level l is touched by every
+    // 2^(l+1)-th leaf: two levels take 3 of 4 records off the global store and its latency off the bookkeeping)
+    duo_lds_f64 *stk_h = duo_lds_at(smem + a.off_stack) + team * a.stack_lds_levels * SREC;
+    const int stk_lim = STL ? 0 : a.stack_lds_levels * SREC;
+    auto ld_stk = [&](int off) -> double {
+        if constexpr (STL) return stk_l[off];
+        else { if (__builtin_amdgcn_readfirstlane(off) < stk_lim) return stk_h[off]; return stk_g[off]; }
+    };
+    auto st_stk = [&](int off, double v) {
+        if constexpr (STL) stk_l[off] = v;
+        else { if (__builtin_amdgcn_readfirstlane(off) < stk_lim) stk_h[off] = v; else stk_g[off] = v; }
+    };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
 
@@ -1042,7 +1062,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         // P = 3 D + 3), so while the shortcut keeps sending the jobs the state wave needs no vector at all -- the finished
         // state goes to the bookkeeping wave straight from the view's lanes (same values: the vectors' formulas, element
         // by element), and the vectors are only rebuilt from a control record when the trajectory restarts
-        const bool lean = BKW && fast_ok && sent;
+        // (the row TEAM form does the same inside the one state wave: the finished state is re-laid from the view's lanes
+        // to vector order through an LDS scratch line -- no first half on the full vectors, no gathers, no chain rule)
+        const bool lean = (BKW || (TEAM && !a.no_spec)) && fast_ok && sent;
         if (sent && !lean) first_half();
         STAMP(1);
 
@@ -1138,7 +1160,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             duo_publish(f_job, seq);
             job_eps = eps_l;
             fast_pub = true;
-            if (lean) STAMP(2);          // (... slot 2 = the view's update and the job's publication)
+            if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
             if constexpr (BKW) { ctl_pre = *f_ctl; ack_pre = *f_ack; }     // requested now, used after the chain rule: no round trip then
             __builtin_amdgcn_s_setprio(EPX_PRIO_S_BG);  // the row waves are off again: what follows has their whole pass
             if constexpr (BKW) {
@@ -1160,6 +1182,38 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     }
                     if (lane == 0) { m[4 * NV * 64] = uniform_d(ll); m[4 * NV * 64 + 2] = (double)gen; }
                     duo_publish(f_mail, mseq);
+                    STAMP(4);
+                    continue;
+                }
+            }
+            if constexpr (TEAM) {
+                if (lean) {
+                    // ---- the finished state from the view, in vector order for the bookkeeping of the next round:
+                    // lane j wrote (location, raw, log scale) of coefficient j; element e of a vector is read back by lane
+                    // e % 64.  One scratch line serves the four vectors one after the other (the LDS executes a wave's
+                    // accesses in order).  Entries beyond P are never written and stay 0.
+                    const double lp1 = -0.5 * (q1o - vmu1) * vo1, lp3 = -0.5 * (q3o - vmu3) * vo3;
+                    const double lp2 = laplace ? -fabs(q2o) : -0.5 * q2o * q2o;
+                    duo_lds_f64 *scr = duo_lds_at(smem + a.off_scr) + team * (NV * 64);
+                    if (v_lane) { scr[ve1] = q1o; scr[ve2] = q2o; scr[ve3] = q3o; }
+                    wave_lds_exchange();
+                    FORV zq.v[i] = scr[lane + 64 * i];
+                    wave_lds_exchange();
+                    if (v_lane) { scr[ve1] = fp1; scr[ve2] = fp2; scr[ve3] = fp3; }
+                    wave_lds_exchange();
+                    FORV zp.v[i] = scr[lane + 64 * i];
+                    wave_lds_exchange();
+                    if (v_lane) { scr[ve1] = g1; scr[ve2] = g2; scr[ve3] = g3; }
+                    wave_lds_exchange();
+                    FORV zg.v[i] = scr[lane + 64 * i];
+                    wave_lds_exchange();
+                    if (v_lane) { scr[ve1] = lp1; scr[ve2] = lp2; scr[ve3] = lp3; }
+                    wave_lds_exchange();
+                    double lpt = 0.0, ks = 0.0;
+                    FORV { lpt += scr[lane + 64 * i]; ks += inv_e.v[i] * zp.v[i] * zp.v[i]; }
+                    wave_lds_exchange();
+                    f_lpt = lpt; f_ks = ks; f_ll = uniform_d(ll);
+                    pending = true;
                     STAMP(4);
                     continue;
                 }
@@ -1378,8 +1432,18 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     a.om_in_lds = 1;
     const size_t cap = 160 * 1024;
     const size_t stack = (size_t)cpb * a.max_depth * nuts_stack_record(nv) * 8;
-    a.stack_in_lds = 0; a.off_stack = (int)off;
+    a.off_scr = 0;
+    if (teamm) { a.off_scr = (int)off; off += (size_t)cpb * nv * 64 * 8; }
+    a.stack_in_lds = 0; a.off_stack = (int)off; a.stack_lds_levels = 0;
     if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
+    else if (teamm) {
+        // (TEAM: the cavity precision is in registers, so the LDS has room for the lowest stack levels)
+        const size_t per_level = (size_t)cpb * nuts_stack_record(nv) * 8;
+        int lv = (int)((cap - 16 - off) / per_level);
+        if (lv > 3) lv = 3;
+        if (lv > a.max_depth) lv = a.max_depth;
+        if (lv > 0) { a.stack_lds_levels = lv; off += (size_t)lv * per_level; }
+    }
     a.off_piece = (int)off; off += 16;
     a.lds_bytes = (int)off;
     return off;

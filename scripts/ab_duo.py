@@ -10,6 +10,6 @@ mod = models.m4b(J, 32, 500)
 data = mod.simulate_data(Sigma_x='rand', rng=100)
 _, _, Q0, r0 = mod.get_prior()
 M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
-           df0=models.default_df0(J), layout=5, sync_sites=False)
+           df0=models.default_df0(J), layout=int(os.environ.get('AB_LAYOUT', '5')), sync_sites=False)
 M.run(3, verbose=False, seed=1)
 print(os.environ.get('EPX_LIB', 'default'), 'launch ms', np.round(M.sampling_ms, 1), 'gradients', ['%.4g' % g for g in M.ngrad_log])
