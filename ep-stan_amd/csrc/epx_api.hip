@@ -533,21 +533,27 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     const bool auto6 = layout == 0 && !many && c->model >= EPX_M4B_SG && count * o.chains <= c->n_cu;
     if (!lock && !c->multi && !c->gauss && dp > 0 && nv <= 2 && !no_spec &&
         (layout == 5 || layout == 6 || layout == 7 || (layout == 0 && many) || auto6)) {
-        const bool six = layout == 6 || auto6;
         // layout 7: the row TEAM of nuts_duo.hip -- four row waves serve the four chains of a site in lock step on the
-        // matrix pipe; the state waves are layout 5's
-        const bool seven = layout == 7;
-        const int cpb = six ? 1 : 4, rw = six ? 2 : (seven ? 4 : 1);
-        NutsArgs t = a;
-        const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
-        // (layout 6: one chain per workgroup, the bookkeeping wave's stack lives in LDS or the layout is not used)
-        const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP &&
-                          (seven ? (c->n_max + 63) / 64 <= 32 : (c->n_max + 64 * rw - 1) / (64 * rw) <= 64) &&
-                          (!six || t.stack_in_lds);
-        if (fits) {
+        // matrix pipe, the state waves are layout 5's; the default for batches that fill the chip since round 3 (layout 5
+        // when the TEAM form does not fit the LDS: it pads the rows to whole 16-row tiles)
+        int cand[2], ncand = 0;
+        if (layout == 6 || auto6) cand[ncand++] = 6;
+        else if (layout == 5) cand[ncand++] = 5;
+        else if (layout == 7) cand[ncand++] = 7;
+        else { cand[ncand++] = 7; cand[ncand++] = 5; }
+        for (int ic = 0; ic < ncand; ++ic) {
+            const bool six = cand[ic] == 6, seven = cand[ic] == 7;
+            const int cpb = six ? 1 : 4, rw = six ? 2 : (seven ? 4 : 1);
+            NutsArgs t = a;
+            const size_t lds = nuts_duo_lds_layout(t, cpb, rw, dp, c->n_max);
+            // (layout 6: one chain per workgroup, the bookkeeping wave's stack lives in LDS or the layout is not used)
+            const bool fits = nuts_duo_has(cpb, rw, dp, nv) && lds <= LDS_CAP &&
+                              (seven ? (c->n_max + 63) / 64 <= 32 : (c->n_max + 64 * rw - 1) / (64 * rw) <= 64) &&
+                              (!six || t.stack_in_lds);
+            if (!fits) continue;
             a = t;
             a.err = c->err_flag;
-            layout = six ? 6 : (seven ? 7 : 5);
+            layout = cand[ic];
             {
                 a.stack_stride = nuts_resident_chain_doubles(nv, o.max_depth);
                 const size_t need = (size_t)stack_sites * o.chains * a.stack_stride;
@@ -669,7 +675,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // The launch ends with its slowest chain; this takes that chain at the faster tick.
     NutsArgs a2;
     int wpc2 = 0, dp2 = 0, nv2 = 0, n_lead = 0;
-    if (!use_queue && o.layout == 0 && (layout == 1 || layout == 5) && a.order && c->split_n > 0 && !eps_dev) {
+    if (!use_queue && o.layout == 0 && (layout == 1 || layout == 5 || layout == 7) && a.order && c->split_n > 0 && !eps_dev) {
         n_lead = c->split_n < count ? c->split_n : count - 1;
         const int cap = c->n_cu / (2 * o.chains);          // at most half of the CUs for the lead sites
         if (n_lead > cap) n_lead = cap;

@@ -42,6 +42,9 @@ namespace epx {
 #ifndef EPX_DUO_SLEEP
 #define EPX_DUO_SLEEP 1
 #endif
+#ifndef EPX_TEAM_SLEEP
+#define EPX_TEAM_SLEEP 2         // the state waves' looks at the row team's words (a pass takes thousands of cycles)
+#endif
 #ifndef EPX_PRIO_R
 #define EPX_PRIO_R 0
 #define EPX_PRIO_S_BG 0
@@ -78,34 +81,27 @@ __device__ inline int duo_wait_ge(duo_flag_t *flag, int want) {
 }
 // Row team (TEAM form): every chain of the workgroup has posted job `pass` or has left; returns the number of chains
 // still running, -1 when the wait gives up
-__device__ inline int team_wait_jobs(duo_flag_t *f_job4, int pass, int nch) {
+// (one LDS read and two vector compares per look: lane l reads word l & 3, the verdict is a ballot -- a polling wave
+// shares its SIMD's vector pipe with a wave that computes)
+__device__ inline int team_wait_jobs(duo_flag_t *f_job4, int pass, int nch, int lane) {
+    const int c = lane & 3;
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
-        int ready = 1, live = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int v = __builtin_amdgcn_readfirstlane(f_job4[c]);
-            const bool gone = v == DUO_EXIT || c >= nch;
-            ready &= (gone || v == pass) ? 1 : 0;
-            live += gone ? 0 : 1;
-        }
-        if (ready) { asm volatile("" ::: "memory"); return live; }
+        const int v = f_job4[c];
+        const bool gone = v == DUO_EXIT || c >= nch;
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(!gone) & 0xFull;
+        if (__builtin_amdgcn_ballot_w64(gone || v == pass) == ~0ull) { asm volatile("" ::: "memory"); return __builtin_popcountll(live); }
         __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
     }
     return -1;
 }
 // State wave (TEAM form): all four row waves have published pass `seq`
-__device__ inline int team_wait_rows(duo_flag_t *f_team4, int seq) {
+__device__ inline int team_wait_rows(duo_flag_t *f_team4, int seq, int lane) {
+    const int w = lane & 3;
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
-        int ok = 1, quit = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int v = __builtin_amdgcn_readfirstlane(f_team4[w]);
-            ok &= v == seq ? 1 : 0;
-            quit |= v == DUO_EXIT ? 1 : 0;
-        }
-        if (quit) return DUO_EXIT;
-        if (ok) { asm volatile("" ::: "memory"); return seq; }
-        __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
+        const int v = f_team4[w];
+        if (__builtin_amdgcn_ballot_w64(v == seq) == ~0ull) { asm volatile("" ::: "memory"); return seq; }
+        if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) return DUO_EXIT;
+        __builtin_amdgcn_s_sleep(EPX_TEAM_SLEEP);
     }
     return DUO_TIMEOUT;
 }
@@ -354,7 +350,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             TSTAMP_INIT;
             __builtin_amdgcn_s_setprio(EPX_PRIO_R);
             for (int pass = 1;; ++pass) {
-                const int live = team_wait_jobs(f_job, pass, nch);
+                const int live = team_wait_jobs(f_job, pass, nch, lane);
                 STAMP(5);
                 TSTAMP(0);
                 if (live <= 0) {
@@ -902,7 +898,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     };
 
     auto rows_in = [&](int sq_) -> bool {               // the row waves' results of job sq_ are in
-        if constexpr (TEAM) return team_wait_rows(f_res, sq_) == sq_;
+        if constexpr (TEAM) return team_wait_rows(f_res, sq_, lane) == sq_;
         else {
             bool ok = true;
             for (int w = 0; w < RW; ++w) ok &= duo_wait(f_res + w, sq_) == sq_;

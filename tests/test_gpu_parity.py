@@ -15,6 +15,7 @@ from epstan_amd.method import Master, Worker         # noqa: E402
 from oracle import ep_oracle as eo                   # noqa: E402
 from oracle import nuts_oracle as no                 # noqa: E402
 import injectors                                     # noqa: E402
+from conftest import record_slack                    # noqa: E402
 
 # deterministic stages: SURVEY.md §8c tolerance (QR vs Cholesky-of-scatter and
 # reduction order differ by cond * eps)
@@ -290,6 +291,10 @@ def test_logdensity_gradient_matches_oracle(model, D, n):
     ('m5b_sg', 4, 50, 1, 60, 100.), ('m2b_sg', 6, 80, 2, 60, 100.), ('m3b_sg', 6, 80, 1, 60, 100.),
     ('m4b_sg', 16, 200, 2, 44, 1000.), ('m4b_sg', 16, 200, 1, 44, 1000.), ('m4b_sg', 32, 120, 1, 44, 1000.),
     ('m1b_sg', 32, 300, 2, 60, 100.), ('m3b_sg', 11, 64, 2, 60, 100.), ('m2b_sg', 32, 100, 1, 44, 1000.),
+    # layouts 5 and 7: state wave + row wave per chain; state waves + a row team on the matrix pipe (the default at C3 / C4)
+    ('m4b_sg', 32, 120, 5, 44, 1000.), ('m4b_sg', 16, 200, 5, 44, 1000.),
+    ('m4b_sg', 32, 120, 7, 44, 1000.), ('m4b_sg', 16, 200, 7, 44, 1000.), ('m4b_sg', 32, 500, 7, 44, 1000.),
+    ('m1b_sg', 16, 120, 7, 60, 100.), ('m5b_sg', 21, 333, 7, 44, 1000.), ('m3b_sg', 32, 300, 7, 44, 1000.), ('m2b_sg', 9, 77, 7, 60, 100.),
     # layout 4: chains in lock step, rows resident, MFMA products
     ('m4b_sg', 4, 50, 4, 60, 100.), ('m1b_sg', 16, 200, 4, 60, 100.), ('m4b_sg', 32, 120, 4, 44, 1000.),
     ('m5b_sg', 9, 77, 4, 60, 100.), ('m3b_sg', 32, 300, 4, 44, 1000.), ('m2b_sg', 21, 333, 4, 44, 1000.),
@@ -332,6 +337,7 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
                 assert cs[k, c, 3] == st_o[k, c, 3]                              # same gradient count
                 np.testing.assert_allclose(cs[k, c, 0], st_o[k, c, 0], rtol=1e-5)    # step-size path
                 np.testing.assert_allclose(cs[k, c, 5], st_o[k, c, 5], rtol=1e-4)    # accept_stat
+    record_slack('full run vs oracle %s D=%d n=%d layout %d: chains equal to the end' % (model, D, n, layout), n_full, '>= 9', 12)
     assert n_full >= 9, n_full                                             # of 12 (site, chain) runs
     if n_full == 12:
         np.testing.assert_allclose(stats[:, 2], st_o[:, :, 2].sum(1))
@@ -347,6 +353,8 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
     ('m4b_sg', 4, 50, 1), ('m4b_sg', 4, 50, 2), ('m5b_sg', 8, 64, 2), ('m3b_sg', 16, 100, 1),
     ('m4b_sg', 16, 200, 2), ('m4b_sg', 16, 200, 1), ('m4b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 2),
     ('m1b_sg', 32, 500, 1), ('m4b_sg', 32, 500, 4), ('m4b_sg', 16, 200, 4), ('m1b_sg', 32, 500, 4), ('m3b_sg', 7, 45, 4),
+    ('m4b_sg', 32, 500, 5), ('m1b_sg', 32, 500, 5),           # the kernel round 2's bench timed, at its own site shape
+    ('m4b_sg', 32, 500, 7), ('m1b_sg', 32, 500, 7), ('m4b_sg', 16, 200, 7), ('m5b_sg', 32, 300, 7), ('m3b_sg', 21, 100, 7),   # ... and round 3's
     ('m4a_sg', 16, 200, 2), ('m4a_sg', 16, 200, 1), ('m1a_sg', 32, 300, 1), ('m3a_sg', 8, 64, 2),
 ])
 def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
@@ -378,6 +386,7 @@ def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
         nbad += int(np.sum(~same_tree | (err > 1e-6)))
         assert np.all(err[same_tree] < 1e-6), err
         assert st_o[:, :, 2].min() >= 1
+    record_slack('teacher-forced transitions %s D=%d n=%d layout %d: transitions that differ' % (model, D, n, layout), nbad, '<= 1', 24)
     assert nbad <= 1, nbad
 
 
@@ -446,14 +455,15 @@ def test_site_order_hint_does_not_change_results(model, D, n, layout):
 @pytest.mark.parametrize('model,D,n,K', [('m1b_sg', 4, 30, 330), ('m4b_sg', 32, 300, 200)])
 def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n, K):
     """epx_set_site_split: the leading sites of the order give exactly the draws of layout 2, the
-    others those of layout 1 (= layout 5's, bit for bit), whatever the split (the two launches share
+    others those of the layout the library picks for them (7, or 1 for D <= 8), whatever the split (the two launches share
     every buffer).  K: enough sites for the library to pick one workgroup per site by itself (320
     when two layout-2 workgroups fit a CU): layout 5 where the shape is instantiated, else layout 1."""
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 5, K=K, tight=30.0)
     eng, _, _ = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     seeds = np.arange(K, dtype=np.int64) + 11
     ref = {}
-    for layout in (1, 2):
+    auto = 7 if D >= 9 else 1            # what the library picks for the rest: the row-team kernel where it is instantiated
+    for layout in (1, 2, auto):
         eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', layout=layout, max_depth=6))
         assert eng.last_layout() == layout and eng.last_split() == 0
         ref[layout] = (np.stack([eng.get_draws(k, True) for k in range(K)]), eng.get_chain_stats(4))
@@ -464,19 +474,19 @@ def test_split_launch_runs_lead_sites_one_workgroup_per_chain(model, D, n, K):
         eng.set_site_split(n_lead)
         stats, ms = eng.sample_batch(seeds, opts)
         m = eng.last_split()
-        assert eng.last_layout() == (5 if D >= 9 else 1) and 1 <= m <= n_lead
+        assert eng.last_layout() == auto and 1 <= m <= n_lead
         assert m == n_lead or n_lead == 150          # clamped to half of the CUs
         dr = np.stack([eng.get_draws(k, True) for k in range(K)])
         cs = eng.get_chain_stats(4)
         lead, rest = order[:m], order[m:]
         np.testing.assert_array_equal(dr[lead], ref[2][0][lead])
         np.testing.assert_array_equal(cs[lead], ref[2][1][lead])
-        np.testing.assert_array_equal(dr[rest], ref[1][0][rest])
-        np.testing.assert_array_equal(cs[rest], ref[1][1][rest])
+        np.testing.assert_array_equal(dr[rest], ref[auto][0][rest])
+        np.testing.assert_array_equal(cs[rest], ref[auto][1][rest])
     eng.set_site_split(0)
     eng.sample_batch(seeds, opts)
     assert eng.last_split() == 0
-    np.testing.assert_array_equal(np.stack([eng.get_draws(k, True) for k in range(K)]), ref[1][0])
+    np.testing.assert_array_equal(np.stack([eng.get_draws(k, True) for k in range(K)]), ref[auto][0])
     # an explicit layout is never split
     eng.set_site_split(5)
     eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', layout=1, max_depth=6))
@@ -730,6 +740,7 @@ def test_streaming_sampler_equals_resident_and_oracle(model, D, n, chains):
             if np.all(err[c] < 1e-4):
                 n_full += 1
                 assert cs[k, c, 2] == st_o[k, c, 2] and cs[k, c, 3] == st_o[k, c, 3]
+    record_slack('streaming run vs oracle %s D=%d n=%d: chains equal to the end' % (model, D, n), n_full, '>= %d' % ((3 * 2 * chains) // 4), 2 * chains)
     assert n_full >= (3 * 2 * chains) // 4, n_full
 
 
@@ -926,6 +937,7 @@ def test_multigroup_site_updates_match_oracle(model, D, groups, chains, layout):
             if np.all(err[c] < 1e-4):
                 n_full += 1
                 assert cs[k, c, 2] == st_o[k, c, 2] and cs[k, c, 3] == st_o[k, c, 3]
+    record_slack('multi-group run vs oracle: chains equal to the end', n_full, '>= %d' % ((3 * K * chains) // 4), 3 * K * chains)
     assert n_full >= (3 * K * chains) // 4, n_full
     # one group per site through the groups entry point = the `_sg` model, bit for bit
     ones = np.ones(K, dtype=np.int32)
@@ -1075,8 +1087,8 @@ def test_layout_policy_for_the_baseline_shapes():
     assert picked('m4b_sg', 64, 16, 200) == 6          # C2: every chain gets a CU -> one workgroup per chain, roles on waves
     assert picked('m3b_sg', 64, 16, 200) == 2          # ... models without per-coefficient scales: gradient waves + bookkeeping wave
     assert picked('m4b_sg', 256, 16, 200) == 2         # two such workgroups share a CU: still ahead (measured)
-    assert picked('m4b_sg', 400, 16, 200) == 5         # many small sites -> one workgroup per site (row + state waves)
-    assert picked('m4b_sg', 512, 32, 500) == 5         # C3 / C4 per GPU
+    assert picked('m4b_sg', 400, 16, 200) == 7         # many small sites -> one workgroup per site (state waves + row team)
+    assert picked('m4b_sg', 512, 32, 500) == 7         # C3 / C4 per GPU
     assert picked('m1b_sg', 400, 4, 50) == 1           # D <= 8: the one-wave-per-chain kernel
     assert picked('m4b_sg', 100, 32, 500) == 2
     assert picked('m4b_sg', 4, 128, 2000) == 3         # C5 site size: rows beyond the LDS -> streaming

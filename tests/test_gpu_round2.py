@@ -16,6 +16,7 @@ from epstan_amd.method import Master, Worker
 from oracle import ep_oracle as eo
 from oracle import nuts_oracle as no
 from test_gpu_parity import _engine_with_cavity, _site_problem
+from conftest import record_slack
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -121,6 +122,7 @@ def test_layout_6_follows_the_oracle_run(model, D, n):
                 n_full += 1
                 assert cs[k, c, 3] == st_o[k, c, 3]
     print('layout 6: chains equal to the oracle to the end: %d of 12' % n_full)
+    record_slack('layout 6 run vs oracle %s D=%d n=%d: chains equal to the end' % (model, D, n), n_full, '>= 9', 12)
     assert n_full >= 9, n_full
 
 
@@ -135,24 +137,25 @@ def test_layout_policy_prefers_the_duo_kernel_for_large_batches():
     eng = M.engine
     seeds = np.arange(330) + 1
     ref = {}
-    for layout in (0, 1, 5, 2):
+    for layout in (0, 1, 5, 2, 7):
         eng.set_site_order(None)
         eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', layout=layout, max_depth=6))
         ref[layout] = (_all_draws(eng, 330), eng.last_layout())
-    assert [ref[l][1] for l in (0, 1, 5, 2)] == [5, 1, 5, 2]
-    np.testing.assert_array_equal(ref[0][0], ref[1][0])
+    assert [ref[l][1] for l in (0, 1, 5, 2, 7)] == [7, 1, 5, 2, 7]
+    np.testing.assert_array_equal(ref[5][0], ref[1][0])
+    np.testing.assert_array_equal(ref[0][0], ref[7][0])
     # split launch: the lead sites of the order run one workgroup per chain (layout 2's draws)
     order = np.arange(330, dtype=np.int32)[::-1].copy()
     eng.set_site_order(order)
     eng.set_site_split(9)
     eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=12, init='random', max_depth=6))
     m = eng.last_split()
-    assert eng.last_layout() == 5 and 1 <= m <= 9
+    assert eng.last_layout() == 7 and 1 <= m <= 9
     dr = _all_draws(eng, 330)
     lead = order[:m]
     rest = order[m:]
     np.testing.assert_array_equal(dr[lead], ref[2][0][lead])
-    np.testing.assert_array_equal(dr[rest], ref[1][0][rest])
+    np.testing.assert_array_equal(dr[rest], ref[7][0][rest])
     eng.set_site_order(None)
     eng.set_site_split(0)
 
@@ -200,6 +203,7 @@ def test_gaussian_family_streamed_run_follows_the_oracle(model, D, n, chains):
                 n_full += 1
                 assert cs[k, c, 3] == st_o[k, c, 3]
     print('Gaussian family, layout 3: chains equal to the oracle to the end: %d of %d' % (n_full, 3 * chains))
+    record_slack('Gaussian family streamed vs oracle: chains equal to the end', n_full, '>= %d' % ((3 * chains * 3) // 4), 3 * chains)
     assert n_full >= (3 * chains * 3) // 4, n_full
 
 
@@ -279,6 +283,7 @@ def test_carried_adaptation_history_and_second_call_follow_the_oracle():
                     n_full += 1
                     assert cs2[k, c, 3] == st_o[k, c, 3]
         print('carry, layout %d: chains equal to the oracle to the end: %d of 12' % (layout, n_full))
+        record_slack('carried adaptation vs oracle, layout %d: chains equal to the end' % layout, n_full, '>= 9', 12)
         assert n_full >= 9, (layout, n_full)
         assert np.all(np.isfinite(cs2[:, :, 1])) and np.all(cs2[:, :, 1] > 0)
 
@@ -312,7 +317,7 @@ def test_ep_with_carried_adaptation_agrees_with_the_fresh_path_and_needs_fewer_l
 # ------------------------------------------------------------------ BASELINE configs at their own size
 def test_one_ep_iteration_at_c3_size_with_invariants():
     """C3 = C4 per GPU: J = 512 sites, D = 32, n_j = 500, m4b, 4 x 200.  Two EP iterations through the
-    default path (layout 5, HBM tree stack + cold store, fused update): finite, positive definite,
+    default path (layout 7: row team on the matrix pipe, cold store in HBM, fused update): finite, positive definite,
     symmetric, site sums consistent with the global approximation, one site's moment stage against
     the oracle from the device's own draws, and the split launch reproduces the unsplit draws."""
     J, D, n = 512, 32, 500
@@ -323,7 +328,7 @@ def test_one_ep_iteration_at_c3_size_with_invariants():
                df0=models.default_df0(J))
     eng = M.engine
     info, (m_s, S_s), (st, ms, rh, ot) = M.run(2, verbose=False, return_analytics=True, seed=1)
-    assert info == 0 and eng.last_layout() == 5
+    assert info == 0 and eng.last_layout() == 7
     assert np.all(np.isfinite(m_s)) and np.all(np.isfinite(S_s))
     for S in S_s:
         np.testing.assert_allclose(S, S.T, rtol=1e-10, atol=1e-14)
@@ -346,7 +351,7 @@ def test_one_ep_iteration_at_c3_size_with_invariants():
     seeds = np.arange(J) + 77
     ref = {}
     eng.set_site_order(None)
-    for layout in (5, 2):
+    for layout in (7, 2):
         eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=16, init='random', layout=layout, max_depth=7))
         ref[layout] = _all_draws(eng, J)
     order = np.argsort(-stats[:, 2]).astype(np.int32)
@@ -357,7 +362,7 @@ def test_one_ep_iteration_at_c3_size_with_invariants():
     assert m >= 1
     dr = _all_draws(eng, J)
     np.testing.assert_array_equal(dr[order[:m]], ref[2][order[:m]])
-    np.testing.assert_array_equal(dr[order[m:]], ref[5][order[m:]])
+    np.testing.assert_array_equal(dr[order[m:]], ref[7][order[m:]])
 
 
 def test_one_damped_iteration_at_c5_site_size_through_the_sweep():
@@ -483,24 +488,26 @@ def _run(eng, seeds, opts, J):
     return _all_draws(eng, J), eng.get_chain_stats(4).copy(), stats.copy()
 
 
+@pytest.mark.parametrize('layout', [5, 7])
 @pytest.mark.parametrize('piece_len,rate,D,n', [(7, None, 16, 120), (1, 'skewed', 16, 120), (25, 'skewed', 12, 90),
                                                  (500, None, 16, 120), (13, 'skewed', 32, 500), (26, None, 32, 500)])
-def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate, D, n):
+def test_piece_queue_gives_the_draws_of_the_uncut_launch(piece_len, rate, D, n, layout):
     """epx_set_piece_queue: one workgroup per piece claims a site by largest remaining predicted work, runs piece_len
     transitions of it from the checkpoint the piece before left (warm-up windows and metric updates on either side of
     a cut: it = 50, windows end at transitions 11 and 22), and puts it back; whatever the claims, the draws, the
     chain and the site statistics are those of one workgroup per site -- also of a warm start from them."""
     it = 50
     M, eng, seeds = _pieced_problem(D, n, it, J=9)
-    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=5)
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=layout)
     ref = _run(eng, seeds, opts, 9)
+    assert eng.last_layout() == layout
     r = None if rate is None else np.array([9.0, 1.0, 1.0, 5.0, 1.0, 1.0, 2.0, 1.0, 30.0])
     eng.set_piece_queue(piece_len, r)
     got = _run(eng, seeds, opts, 9)
     assert eng.last_segments() == -((it + piece_len - 1) // piece_len)
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a, b)
-    warm = HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=5)
+    warm = HipEngine.sampler_opts(chains=4, iter=it, init='prev', layout=layout)
     w_got = _run(eng, seeds + 1, warm, 9)
     eng.set_piece_queue(0)
     _run(eng, seeds, opts, 9)
@@ -556,13 +563,13 @@ def test_ep_with_the_piece_queue_equals_ep_without(monkeypatch):
         info = M.run(3, verbose=False, calc_moments=False, seed=5)
         out.append((M.Q.copy(), M.r.copy(), M.engine.last_segments(), M.engine.last_layout(), info))
     print('EP with / without the piece queue: sum|Q| = %.6f / %.6f' % (np.abs(out[0][0]).sum(), np.abs(out[1][0]).sum()))
-    assert out[0][3] == out[1][3] == 5 and out[0][4] == out[1][4] == 0
+    assert out[0][3] == out[1][3] == 7 and out[0][4] == out[1][4] == 0
     assert out[0][2] == -16 and out[1][2] == 0          # iter = 64: 16 pieces of 4 transitions
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize('D,n,layout', [(16, 120, 5), (40, 150, 3)])
+@pytest.mark.parametrize('D,n,layout', [(16, 120, 5), (16, 120, 7), (40, 150, 3)])
 def test_piece_queue_with_a_chain_that_fails_at_its_start(D, n, layout):
     """A site whose density is not finite at the initial point fails in its FIRST piece, where its draws and its
     statistics are written; the later pieces of that site find the mark in the checkpoint record and end at once.
