@@ -36,7 +36,7 @@ LDS_PEAK_TBS = 150.0
 CONFIGS = {
     # name: (sites per GPU, D, n_j, correlated covariates, default steps, default warm-up)
     'c2': (64, 16, 200, 1, 20, 5),
-    'c3': (512, 32, 500, 1, 8, 5),
+    'c3': (512, 32, 500, 1, 20, 5),      # the driver's command: --steps 20 --warmup 5
     'c5shard': (512, 128, 2000, 0, 2, 2),
 }
 
@@ -273,15 +273,20 @@ def main():
                 'passes_max_over_mean_site': float(np.mean([p.max() / p.mean() for p in M.pass_log[n_launch0:]])),
                 'fp64_tflops': achieved_tf}
     else:
-        tr, src = measured_traffic(('r02_%s_pmc_hbm.json' % args.config, 'r01_%s_pmc_hbm.json' % args.config))
+        tr, src = measured_traffic(('r03_%s_pmc_hbm.json' % args.config, 'r02_%s_pmc_hbm.json' % args.config))
         lds_tbs = float(ngrad.mean()) * B_g / t_kernel / 1e12
-        roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'fp64-valu',
+        team = layout == 7
+        roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
                 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_source': src,
-                'note': 'FP64 vector flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
-                        'duration of the sampler launch.  The kernel issues no MFMA (a wave owns one chain: '
-                        'matrix-vector work) and X is LDS resident, so neither the matrix pipes nor HBM '
-                        'bound it: lds_frac / hbm_frac below',
+                'note': ('FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event duration of the '
+                         'sampler launch.  Layout 7: the two products of a gradient run on v_mfma_f64_4x4x4 for the four '
+                         'chains of a site in lock step (dense FP64 matrix peak = FP64 vector peak = 78.6 TFLOP/s); X is '
+                         'LDS resident, so HBM does not bound it: lds_frac / hbm_frac below') if team else
+                        ('FP64 vector flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
+                         'duration of the sampler launch.  The kernel issues no MFMA (a wave owns one chain: '
+                         'matrix-vector work) and X is LDS resident, so neither the matrix pipes nor HBM '
+                         'bound it: lds_frac / hbm_frac below'),
                 'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
                 'lds_swept_TBps': lds_tbs, 'lds_peak_TBps': LDS_PEAK_TBS, 'lds_frac': lds_tbs / LDS_PEAK_TBS,
                 'hbm_algorithmic_bytes': hbm_alg,

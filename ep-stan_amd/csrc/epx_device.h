@@ -363,4 +363,32 @@ __device__ inline void logistic_split2(double fa, double fb, double ya, double y
     ga = ya - sa; gb = yb - sb;
 }
 
+// The same two logistic terms without the not-a-number select behind the exponential: a non-finite argument still
+// shows in `lin` (y f - max(f, 0)), which is how the row team's caller learns of it -- through the log density.
+__device__ inline void logistic_pair_lean(double fa, double fb, double ya, double yb, double &lina, double &linb,
+                                          double &wa, double &wb, double &ga, double &gb) {
+    const double xa = -fabs(fa), xb = -fabs(fb);
+    const double ca = fmin(fmax(xa, -800.0), 800.0), cb = fmin(fmax(xb, -800.0), 800.0);
+    const double ka = __builtin_rint(ca * 1.4426950408889634074), kb = __builtin_rint(cb * 1.4426950408889634074);
+    double ra = fma(ka, -6.93147180369123816490e-01, ca), rb = fma(kb, -6.93147180369123816490e-01, cb);
+    ra = fma(ka, -1.90821492927058770002e-10, ra); rb = fma(kb, -1.90821492927058770002e-10, rb);
+    double pa = 1.6059043836821613e-10, pb = 1.6059043836821613e-10;
+#define EPX_STEP2(c) pa = fma(pa, ra, c); pb = fma(pb, rb, c); __builtin_amdgcn_sched_barrier(0)
+    EPX_STEP2(2.08767569878681e-09); EPX_STEP2(2.505210838544172e-08); EPX_STEP2(2.755731922398589e-07);
+    EPX_STEP2(2.7557319223985893e-06); EPX_STEP2(2.48015873015873e-05); EPX_STEP2(1.984126984126984e-04);
+    EPX_STEP2(1.388888888888889e-03); EPX_STEP2(8.333333333333333e-03); EPX_STEP2(4.1666666666666664e-02);
+    EPX_STEP2(1.6666666666666666e-01); EPX_STEP2(0.5); EPX_STEP2(1.0); EPX_STEP2(1.0);
+#undef EPX_STEP2
+    const double ea = ldexp(pa, (int)ka), eb = ldexp(pb, (int)kb);
+    wa = 1.0 + ea; wb = 1.0 + eb;
+    double qa = __builtin_amdgcn_rcp(wa), qb = __builtin_amdgcn_rcp(wb);
+    double ta = fma(-wa, qa, 1.0), tb = fma(-wb, qb, 1.0);
+    qa = fma(qa, ta, qa); qb = fma(qb, tb, qb);
+    ta = fma(-wa, qa, 1.0); tb = fma(-wb, qb, 1.0);
+    qa = fma(qa, ta, qa); qb = fma(qb, tb, qb);
+    const double sa = (fa >= 0) ? qa : ea * qa, sb = (fb >= 0) ? qb : eb * qb;
+    lina = ya * fa - fmax(fa, 0.0); linb = yb * fb - fmax(fb, 0.0);
+    ga = ya - sa; gb = yb - sb;
+}
+
 }  // namespace epx

@@ -79,6 +79,10 @@ __device__ inline int duo_wait_ge(duo_flag_t *flag, int want) {
     }
     return DUO_TIMEOUT;
 }
+// Rows the TEAM form keeps in LDS for a site of n rows: every row wave takes the same EVEN number of 16-row tiles (its
+// rounds are pairs of tiles at compile-time distances), the tiles behind the site's rows hold zeros
+__host__ __device__ inline int team_tiles_per_wave(int n) { const int t = ((n + 15) / 16 + 3) / 4; return (t + 1) & ~1; }
+__host__ __device__ inline int team_rows(int n) { return 4 * team_tiles_per_wave(n) * 16; }
 // Row team (TEAM form): every chain of the workgroup has posted job `pass` or has left; returns the number of chains
 // still running, -1 when the wait gives up
 // (one LDS read and two vector compares per look: lane l reads word l & 3, the verdict is a ballot -- a polling wave
@@ -248,7 +252,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // ---- stage the site: rows HBM -> LDS once per site update (as k_nuts), cavity precision re-laid
     {
         const double *Xg = a.X + (size_t)row0 * D;
-        const int nslot = (TEAM ? (n + 15) / 16 * 16 : n) * SPR;       // (TEAM: whole 16-row tiles, zero rows behind the site's)
+        const int nslot = (TEAM ? team_rows(n) : n) * SPR;       // (TEAM: an even number of whole 16-row tiles per row wave, zero rows behind the site's)
         for (int s = tid; s < nslot; s += blockDim.x) {
             const int r = s / SPR, jp = s % SPR, c0 = 2 * jp;
             double2 v;
@@ -309,8 +313,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             static_assert(NGF <= 4, "one 16-row group of the cavity term per row wave");
             const int lo = lane & 3, bb = (lane >> 2) & 3, hi = lane >> 4;
             const int nch = a.chains - cb * CPB < CPB ? a.chains - cb * CPB : CPB;
-            const int ntile = (n + 15) >> 4, tpw = (ntile + 3) >> 2;
-            const int t0 = wr * tpw, t1 = ntile < t0 + tpw ? ntile : t0 + tpw;
+            const int tpw = team_tiles_per_wave(n);       // (even; tiles beyond the site's rows are zeros and masked)
+            const int t0 = wr * tpw, t1 = t0 + tpw;
             const int sdb = a.slot_doubles;
             // cavity precision as A operands: group wr (rows 16 wr + 4 bb + lo, columns 4 J + hi); wave 3 also the rows
             // beyond the groups, block bb taking the k-steps J = bb, bb + 4, ...
@@ -342,8 +346,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             unsigned af[NRD], ab[NRD];
 #pragma unroll
             for (int r = 0; r < NRD; ++r) {
-                af[r] = xbase + (unsigned)rf * ROWB + ((((unsigned)(4 * r + hi)) ^ swf) << 4);
-                ab[r] = xbase + (unsigned)rb * ROWB + ((((unsigned)(4 * r + lo)) ^ swb) << 4);
+                // (of the wave's first tile pair; a round's other reads sit at compile-time distances)
+                af[r] = xbase + (unsigned)t0 * TILEB + (unsigned)rf * ROWB + ((((unsigned)(4 * r + hi)) ^ swf) << 4);
+                ab[r] = xbase + (unsigned)t0 * TILEB + (unsigned)rb * ROWB + ((((unsigned)(4 * r + lo)) ^ swb) << 4);
             }
             duo_lds_f64 *const sl = slot + lo * sdb;   // the slot of chain lo (team == 0 here: `slot` is chain 0's)
             STAMP_INIT;
@@ -399,17 +404,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 double dsum = 0.0, lsum = 0.0, wprod = 1.0;
                 unsigned yb = ybits;
                 lds_v2f64 xf0[NRD], xf1[NRD];
-                {
-                    const unsigned o0 = (unsigned)t0 * TILEB, o1 = t0 + 1 < t1 ? o0 + TILEB : o0;
+                unsigned pf[NRD], pb[NRD];
 #pragma unroll
-                    for (int r = 0; r < NRD; ++r) {
-                        xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + o0));
-                        xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + o1));
-                    }
+                for (int r = 0; r < NRD; ++r) {
+                    pf[r] = af[r]; pb[r] = ab[r];
+                    xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)pf[r]);
+                    xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pf[r] + TILEB));
                 }
                 for (int t = t0; t < t1; t += 2) {
-                    const bool two = t + 1 < t1;
-                    const unsigned o0 = (unsigned)t * TILEB, o1 = two ? o0 + TILEB : o0;
                     double f0 = alpha_c, f1 = alpha_c;
 #pragma unroll
                     for (int r = 0; r < NRD; ++r) {
@@ -423,25 +425,23 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     lds_v2f64 xb0[NRD], xb1[NRD];
 #pragma unroll
                     for (int r = 0; r < NRD; ++r) {
-                        xb0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(ab[r] + o0));
-                        xb1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(ab[r] + o1));
+                        xb0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)pb[r]);
+                        xb1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pb[r] + TILEB));
                     }
-                    {
-                        // (the round after the last one re-reads this round's tiles: a valid address, values unused)
-                        const int tn = t + 2 < t1 ? t + 2 : t;
-                        const unsigned n0 = (unsigned)tn * TILEB, n1 = tn + 1 < t1 ? n0 + TILEB : n0;
+                    // (the round after the last one reads what lies behind the wave's tiles: values unused)
 #pragma unroll
-                        for (int r = 0; r < NRD; ++r) {
-                            xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + n0));
-                            xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + n1));
-                        }
+                    for (int r = 0; r < NRD; ++r) {
+                        xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pf[r] + 2 * TILEB));
+                        xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pf[r] + 3 * TILEB));
                     }
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) { pf[r] += 2 * TILEB; pb[r] += 2 * TILEB; }
                     TSTAMP(3);
                     double l0, l1, w0, w1, g0, g1;
-                    logistic_split2(f0, f1, (double)(yb & 1u), (double)((yb >> 1) & 1u), l0, l1, w0, w1, g0, g1);
+                    logistic_pair_lean(f0, f1, (double)(yb & 1u), (double)((yb >> 1) & 1u), l0, l1, w0, w1, g0, g1);
                     yb >>= 2;
-                    if (!two || 16 * (t + 2) > n) {        // the site's last tile: rows beyond n add nothing
-                        const bool v0 = 16 * t + rb < n, v1 = two && 16 * (t + 1) + rb < n;
+                    if (16 * (t + 2) > n) {                // the site's last tile(s): rows beyond n add nothing
+                        const bool v0 = 16 * t + rb < n, v1 = 16 * (t + 1) + rb < n;
                         l0 = v0 ? l0 : 0.0; w0 = v0 ? w0 : 1.0; g0 = v0 ? g0 : 0.0;
                         l1 = v1 ? l1 : 0.0; w1 = v1 ? w1 : 1.0; g1 = v1 ? g1 : 0.0;
                     }
@@ -1413,7 +1413,7 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     const int ou = nv > 1 ? 4 : 8;                                                     // as the kernel (OU)
     const int d = a.d, dm = d < 64 ? d : 64, npad = ((dm + 1) / 2 + ou - 1) / ou * ou;
     const bool teamm = cpb == 4 && rw == 4;                                            // as the kernel (TEAM): whole 16-row tiles, no cavity precision in LDS
-    size_t off = (size_t)(teamm ? (n_max + 15) / 16 * 16 : n_max) * dp * 8;
+    size_t off = (size_t)(teamm ? team_rows(n_max) : n_max) * dp * 8;
     a.n_max = n_max; a.duo_rw = rw; a.cpb = cpb;
     a.off_Om = (int)off; off += teamm ? 0 : (size_t)npad * dm * 16;
     a.off_tail = (int)off; off += nv > 1 && !teamm ? (size_t)2 * (2 * npad + 2) * 8 : 0;
