@@ -379,18 +379,26 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 const double alpha_c = sl[JOB];
                 // ---- cavity term Omega V of the four chains
                 if (g_on) {
+                    // (all B operands requested first: a product behind its own LDS round trip would pay the latency 17 times;
+                    // k-steps beyond d meet zero A operands)
+                    double vb[NJ];
+#pragma unroll
+                    for (int J = 0; J < NJ; ++J) vb[J] = sl[VOFF + 4 * J + hi];
                     double acc = 0.0, acc1 = 0.0;             // (two chains: a dependent product issues 4 cycles later than a free one)
 #pragma unroll
                     for (int J = 0; J < NJ; J += 2) {
-                        if (4 * J < d) acc = mfma4(om[J], sl[VOFF + 4 * J + hi], acc);
-                        if (J + 1 < NJ && 4 * (J + 1) < d) acc1 = mfma4(om[J + 1 < NJ ? J + 1 : J], sl[VOFF + 4 * (J + 1) + hi], acc1);
+                        acc = mfma4(om[J], vb[J], acc);
+                        if (J + 1 < NJ) acc1 = mfma4(om[J + 1 < NJ ? J + 1 : J], vb[J + 1 < NJ ? J + 1 : J], acc1);
                     }
                     sl[OVOFF + 16 * wr + rb] = acc + acc1;
                 }
                 if (t_on) {
+                    double vt[NJT];
+#pragma unroll
+                    for (int tt = 0; tt < NJT; ++tt) vt[tt] = sl[VOFF + 4 * (4 * tt + bb) + hi];
                     double acc = 0.0;
 #pragma unroll
-                    for (int tt = 0; tt < NJT; ++tt) acc = mfma4(omt[tt], sl[VOFF + 4 * (4 * tt + bb) + hi], acc);
+                    for (int tt = 0; tt < NJT; ++tt) acc = mfma4(omt[tt], vt[tt], acc);
                     acc += dpp_d<0x124>(acc); acc += dpp_d<0x128>(acc);          // the four blocks' k-shares (row_ror 4, 8)
                     if (bb == 0) sl[OVOFF + 16 * NGF + hi] = acc;
                 }
