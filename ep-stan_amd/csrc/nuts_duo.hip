@@ -1026,7 +1026,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         // ---- while they sweep the rows: the bookkeeping of the leapfrog that finished before this one
         if (!BKW && pending) {
             pending = false;
-            wave_sum2(f_lpt, f_ks);                 // the two reductions only the bookkeeping needs: off the critical path
+            // the two reductions only the bookkeeping needs: off the critical path
+            if constexpr (TEAM) wave_sum2_packed(f_lpt, f_ks); else wave_sum2(f_lpt, f_ks);
             zlp = f_lpt + f_ll;
             const double kin = 0.5 * f_ks;
             const int fwd_was = fwd;
@@ -1039,7 +1040,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #define STAMP_LEAF do { } while (0)
 #define EPX_RESUME resume
 #define EPX_T_END (int)(double)t_end_c
+#define EPX_WAVE_SUM2(a_, b_) do { if constexpr (TEAM) wave_sum2_packed(a_, b_); else wave_sum2(a_, b_); } while (0)
 #include "nuts_state_machine.inc"
+#undef EPX_WAVE_SUM2
 #undef EPX_RESUME
 #undef EPX_T_END
 #undef STAMP_LEAF
