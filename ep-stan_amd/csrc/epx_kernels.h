@@ -148,6 +148,7 @@ struct NutsArgs {
     int off_y, off_Om, off_mu, off_xch, off_stack, lds_bytes;
     int stack_in_lds;
     int off_scr;                  // nuts_duo.hip TEAM form: per chain one vector of LDS scratch (view -> vector order)
+    int stack_ps;                 // ... and the doubles one vector of such a record takes (packed: >= P)
     int stack_lds_levels;         // nuts_duo.hip, stack not (all) in LDS: the lowest levels of every chain's tree stack that are (0: none)
     int om_in_lds;
     int off_spec;                 // > 0: LDS offset of the speculative kernel's mailbox / control records (layout 2)

@@ -103,8 +103,8 @@ k_nuts(NutsArgs a) {
 
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack) + (size_t)team * a.max_depth * SREC;
     double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.stack_stride;
-    auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
-    auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
+    auto ld_stk = [&](int l, int v, int i) -> double { const int off = l * SREC + (v * NV + i) * 64 + lane; if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
+    auto st_stk = [&](int l, int v, int i, double x) { const int off = l * SREC + (v * NV + i) * 64 + lane; if constexpr (STL) stk_l[off] = x; else stk_g[off] = x; };
 
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
@@ -439,8 +439,8 @@ k_nuts_spec(NutsArgs a) {
     // =============================================================== bookkeeping wave
     double *stk_l = reinterpret_cast<double *>(smem + a.off_stack);
     double *stk_g = STL ? nullptr : a.stack + ((size_t)sb * a.chains + chain) * a.stack_stride;
-    auto ld_stk = [&](int off) -> double { if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
-    auto st_stk = [&](int off, double v) { if constexpr (STL) stk_l[off] = v; else stk_g[off] = v; };
+    auto ld_stk = [&](int l, int v, int i) -> double { const int off = l * SREC + (v * NV + i) * 64 + lane; if constexpr (STL) return stk_l[off]; else return stk_g[off]; };
+    auto st_stk = [&](int l, int v, int i, double x) { const int off = l * SREC + (v * NV + i) * 64 + lane; if constexpr (STL) stk_l[off] = x; else stk_g[off] = x; };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     V qs, gs, pq, pp, pg, mq, mp, mg, rho, psp, psm, wmean, wm2, bq, bg, sent_e, in_q, in_p, in_g;
     double lps = 0, plp = 0, mlp = 0, b_key = 0, b_plp = 0;

@@ -366,6 +366,11 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                         for (int i = 0; i < 7; ++i) a.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + i] = tdet[i];
                         a.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)(pass - 1);
                     }
+                    // (third record: every row wave's waiting and working cycles -- who the team waits for)
+                    if (a.stamps && lane == 0) {
+                        a.stamps[((size_t)2 * gridDim.x + blockIdx.x) * 8 + wr] = tacc[5];
+                        a.stamps[((size_t)2 * gridDim.x + blockIdx.x) * 8 + 4 + wr] = tacc[6];
+                    }
 #endif
                     return;
                 }
@@ -669,15 +674,19 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     auto ck_rec = [&](int t_boundary) -> double * { return piece_record(a, sb, t_boundary, chain, NV); };
     // When the whole stack does not fit, its lowest levels still may (stack_lds_levels; level l is touched by every
     // 2^(l+1)-th leaf: two levels take 3 of 4 records off the global store and its latency off the bookkeeping)
-    duo_lds_f64 *stk_h = duo_lds_at(smem + a.off_stack) + team * a.stack_lds_levels * SREC;
-    const int stk_lim = STL ? 0 : a.stack_lds_levels * SREC;
-    auto ld_stk = [&](int off) -> double {
+    // (those records are packed: a vector takes stack_ps >= P doubles there, not NV x 64)
+    const int stk_nl = STL ? 0 : a.stack_lds_levels, stk_ps = a.stack_ps;
+    duo_lds_f64 *stk_h = duo_lds_at(smem + a.off_stack) + team * stk_nl * 2 * stk_ps;
+    int stk_lane = lane;                // (the loop's opaque copy of the lane index: set at the top of every iteration)
+    auto ld_stk = [&](int l, int v, int i) -> double {
+        const int off = l * SREC + (v * NV + i) * 64 + stk_lane;
         if constexpr (STL) return stk_l[off];
-        else { if (__builtin_amdgcn_readfirstlane(off) < stk_lim) return stk_h[off]; return stk_g[off]; }
+        else { if (l < stk_nl) return stk_h[(2 * l + v) * stk_ps + i * 64 + stk_lane]; return stk_g[off]; }
     };
-    auto st_stk = [&](int off, double v) {
-        if constexpr (STL) stk_l[off] = v;
-        else { if (__builtin_amdgcn_readfirstlane(off) < stk_lim) stk_h[off] = v; else stk_g[off] = v; }
+    auto st_stk = [&](int l, int v, int i, double x) {
+        const int off = l * SREC + (v * NV + i) * 64 + stk_lane;
+        if constexpr (STL) stk_l[off] = x;
+        else { if (l < stk_nl) stk_h[(2 * l + v) * stk_ps + i * 64 + stk_lane] = x; else stk_g[off] = x; }
     };
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
@@ -948,6 +957,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         int lane_v = lane0;
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
+        stk_lane = lane;
         EPX_BIND_COLD(lane);
         if constexpr (BKW) {
             // ---- the bookkeeping wave's word: a record of a new generation means "continue from here instead"
@@ -1445,9 +1455,10 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
     else if (teamm) {
         // (TEAM: the cavity precision is in registers, so the LDS has room for the lowest stack levels)
-        const size_t per_level = (size_t)cpb * nuts_stack_record(nv) * 8;
+        a.stack_ps = (a.P + 1) & ~1;                  // a packed vector: only the P live elements (the accesses beyond are masked)
+        const size_t per_level = (size_t)cpb * 2 * a.stack_ps * 8;
         int lv = (int)((cap - 16 - off) / per_level);
-        if (lv > 3) lv = 3;
+        if (lv > 4) lv = 4;
         if (lv > a.max_depth) lv = a.max_depth;
         if (lv > 0) { a.stack_lds_levels = lv; off += (size_t)lv * per_level; }
     }

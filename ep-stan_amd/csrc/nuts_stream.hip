@@ -186,8 +186,9 @@ k_nuts_stream(NutsArgs a) {
     };
     gdouble *stk_g = uniform_ptr(a.stack + chain_slot * ((size_t)a.max_depth * SREC + (size_t)CV_COUNT * PMAX));
     gdouble *cold = stk_g + (size_t)a.max_depth * SREC;
-    auto ld_stk = [&](int off) -> double { return stk_g[off]; };
-    auto st_stk = [&](int off, double v) { stk_g[off] = v; };
+    int stk_lane = lane0;               // (the loop's opaque copy of the lane index: set at the top of every iteration)
+    auto ld_stk = [&](int l, int v, int i) -> double { return stk_g[l * SREC + (v * NV + i) * 64 + stk_lane]; };
+    auto st_stk = [&](int l, int v, int i, double x) { stk_g[l * SREC + (v * NV + i) * 64 + stk_lane] = x; };
 
     const RngKey key = make_key((uint64_t)a.seeds[sb], chain);
     const bool laplace = (model == 4);
@@ -317,6 +318,7 @@ k_nuts_stream(NutsArgs a) {
         int lane_v = lane0;
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
+        stk_lane = lane;
         // ---- lock step: leave only when every chain of the workgroup is done
         if (finished && !counted) { if (lane == 0) atomicAdd(sh_done, 1); counted = 1; }
         lds_barrier();
@@ -456,6 +458,7 @@ k_nuts_stream(NutsArgs a) {
         int lane_w = lane0;
         asm volatile("" : "+v"(lane_w));
         const int lane = lane_w;
+        stk_lane = lane;
         EPX_BIND_COLD(lane);
         {
             // ---- step D (wave = chain): lp and the chain rule back to (phi, eta, etb)

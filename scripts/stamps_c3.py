@@ -30,8 +30,10 @@ def main():
     nb = lib.epx_dbg_get_stamps(eng.ctx, buf.ctypes.data, 8192)
     st = buf[:nb].astype(np.float64)
     det = None
-    if nb % 2 == 0 and eng.last_layout() == 7:          # second half: the phases of the row team's pass
-        det = st[nb // 2:]; st = st[:nb // 2]; nb //= 2
+    waves = None
+    if nb % 3 == 0 and eng.last_layout() == 7:          # second third: the phases of the row team's pass; third: per row wave
+        nb //= 3
+        det = st[nb:2 * nb]; waves = st[2 * nb:]; st = st[:nb]
     per = st[:, :7] / st[:, 7:8]
     med = np.median(per, axis=0)
     lf = eng.get_chain_stats(4)[:, :, 3]
@@ -48,6 +50,10 @@ def main():
         for nm, v in zip(['waiting for the jobs', 'operands + cavity term', 'forward products', 'LDS requests', 'logistic terms',
                           'backward products', 'sums + publication'], pd):
             print('    %-36s %8.0f  %5.1f%%' % (nm, v, 100 * v / pd.sum()))
+    if waves is not None:
+        ok = det[:, 7] > 0
+        w = waves[ok] / det[ok, 7:8]
+        print('row waves 0..3, cycles per pass (median): waiting %s, working %s' % (np.round(np.median(w[:, :4], axis=0)), np.round(np.median(w[:, 4:], axis=0))))
     big = int(np.argmax(st[:, 7]))
     print('the workgroup with the most leapfrogs (%d): cycles per leapfrog %s, total S %.0f, total R %.0f'
           % (st[big, 7], np.round(per[big]).astype(int), per[big, :5].sum(), per[big, 5:7].sum()))
