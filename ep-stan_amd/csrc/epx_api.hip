@@ -539,8 +539,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
         int cand[2], ncand = 0;
         if (layout == 6 || auto6) cand[ncand++] = 6;
         else if (layout == 5) cand[ncand++] = 5;
-        else if (layout == 7) cand[ncand++] = 7;
-        else { cand[ncand++] = 7; cand[ncand++] = 5; }
+        else { cand[ncand++] = 7; cand[ncand++] = 5; }         // (a request for 7 that does not fit is served by 5)
         for (int ic = 0; ic < ncand; ++ic) {
             const bool six = cand[ic] == 6, seven = cand[ic] == 7;
             const int cpb = six ? 1 : 4, rw = six ? 2 : (seven ? 4 : 1);

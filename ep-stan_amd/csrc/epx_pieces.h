@@ -11,6 +11,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef EPX_PIECE_WAIT_S
+#define EPX_PIECE_WAIT_S 60
+#endif
+
 namespace epx {
 
 // what a chain carries from one piece to the next besides the sample, the Welford sums and the metric (lane, variable)
@@ -46,15 +50,18 @@ __device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundar
 }
 
 // Claim a site (all threads of the workgroup; the LDS must not hold anything yet: smem[0..1100) is scratch, and
-// (site, first transition) stay at smem + off_piece for piece_release).  Returns false after 2^24 looks without one
-// (never seen; the caller reports it).
+// (site, first transition) stay at smem + off_piece for piece_release).  Returns false after EPX_PIECE_WAIT_S seconds without
+// one (never seen; the caller reports it and the host call fails with an error).
 template <class Args>
 __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int tid, int &q_site, int &q_t0) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     volatile double *sc = reinterpret_cast<volatile double *>(smem);
     volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
     q_site = -1; q_t0 = 0;
-    for (int attempt = 0; attempt < (1 << 24) && q_site < 0; ++attempt) {
+    // (bounded by wall time, not by a count of looks: s_memrealtime ticks at 100 MHz; a piece takes milliseconds to a few
+    // seconds, so a workgroup that has found nothing for EPX_PIECE_WAIT_S seconds reports a lost piece instead of spinning on)
+    const unsigned long long t_claim0 = __builtin_amdgcn_s_memrealtime();
+    for (int attempt = 0; q_site < 0; ++attempt) {
         double best = -1.0; int arg = -1;
         for (int s = tid; s < a.dyn_count; s += blockDim.x) {
             // ONE word per site: 2 x (transitions done) + (held): progress and claim change together, atomically
@@ -89,6 +96,8 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
                 got = ok ? g : -1;                         // -1: somebody was faster, look again
                 t0_got = expect >> 1;                      // (the progress that was claimed: same word, same instant)
             }
+            // (thread 0 decides for the workgroup when to give up: every thread must leave the loop in the same round)
+            if (got < 0 && __builtin_amdgcn_s_memrealtime() - t_claim0 > (unsigned long long)EPX_PIECE_WAIT_S * 100000000ull) got = -3;
             si[32] = got;
             if (got >= 0) {
                 si[33] = t0_got;
@@ -100,6 +109,7 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
         const int got = __builtin_amdgcn_readfirstlane(si[32]);         // (wave-uniform for the compiler, too)
         if (got >= 0) { q_site = got; q_t0 = __builtin_amdgcn_readfirstlane(si[33]); }
         __syncthreads();
+        if (got == -3) break;
         if (got == -2) {
             // every unfinished site is held: a piece takes tens of milliseconds, so look again in ~0.2 ms (hundreds of
             // waiting workgroups polling the site words at full speed would be felt by the pieces that still run)

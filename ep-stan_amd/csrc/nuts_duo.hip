@@ -1416,7 +1416,7 @@ k_nuts_duo(NutsArgs a_by_value) {
     // A claim is a compare-and-swap on the site's `busy` word.  There are exactly as many workgroups as pieces, so a
     // workgroup that finds every unfinished site held waits for one to come back; the holders never wait.
     int q_site, q_t0;
-    if (!piece_claim(a, smem, tid, q_site, q_t0)) {                // (2^24 looks without a site: reported, never seen)
+    if (!piece_claim(a, smem, tid, q_site, q_t0)) {                // (no site for EPX_PIECE_WAIT_S seconds: reported, never seen)
         if (tid == 0) atomicOr(a.err, 4);
         return;
     }

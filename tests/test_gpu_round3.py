@@ -1,0 +1,149 @@
+"""Round-3 device tests: the kernels the driver's bench times, pinned directly against the oracle at their own
+site shapes and launch forms (row team on the matrix pipe = layout 7, pieced launches, the C5 shard), and the
+moment stage at the BASELINE sizes from the device's own draws.
+
+Everything goes through the C ABI (ctypes)."""
+
+import numpy as np
+import pytest
+
+from epstan_amd import _lib, models
+from epstan_amd.engine import DQI, HipEngine
+from epstan_amd.method import Master
+from oracle import ep_oracle as eo
+from oracle import nuts_oracle as no
+from test_gpu_parity import _engine_with_cavity, _site_problem
+from conftest import record_slack
+
+pytestmark = pytest.mark.gpu
+
+
+def _chains_equal_to_the_end(eng, draws_o, st_o, K, chains, it, P):
+    cs = eng.get_chain_stats(chains)
+    n_full = 0
+    for k in range(K):
+        dev = eng.get_draws(k, all_params=True)
+        ref = draws_o[k].reshape(-1, P)
+        err = np.abs(dev - ref).reshape(chains, it // 2, P).max(axis=2) / max(1.0, np.abs(ref).max())
+        for c in range(chains):
+            assert np.all(err[c, :5] < 1e-3), (k, c, err[c, :5])       # a wrong decision gives O(0.1-1)
+            if np.all(err[c] < 1e-4):
+                n_full += 1
+                assert cs[k, c, 2] == st_o[k, c, 2] and cs[k, c, 3] == st_o[k, c, 3]
+    return n_full
+
+
+@pytest.mark.parametrize('model,D,n,layout,piece_len', [
+    ('m4b_sg', 32, 500, 7, 7), ('m4b_sg', 32, 500, 5, 7), ('m4b_sg', 16, 200, 7, 5), ('m1b_sg', 32, 300, 7, 9),
+    ('m5b_sg', 21, 333, 7, 3)])
+def test_pieced_resident_launch_follows_the_oracle_run(model, D, n, layout, piece_len):
+    """What the bench times at C3 / C4 is a PIECED launch of the resident sampler: every site's run is cut into pieces
+    of `piece_len` transitions that different workgroups take from a queue.  Whole site updates of such a launch
+    against the C restatement, draw by draw (the oracle knows nothing of pieces) -- at the C3 site shape too."""
+    K, it, chains = 3, 44, 4
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 7 + D, K=K, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.array([101, 202, 303], dtype=np.int64)
+    eng.set_piece_queue(piece_len, np.array([3.0, 1.0, 2.0]))
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=layout))
+    assert eng.last_layout() == layout and eng.last_segments() == -((it + piece_len - 1) // piece_len)
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it)
+    n_full = _chains_equal_to_the_end(eng, draws_o, st_o, K, chains, it, P)
+    record_slack('pieced launch vs oracle %s D=%d n=%d layout %d: chains equal to the end' % (model, D, n, layout), n_full, '>= 9', 12)
+    assert n_full >= 9, n_full
+    eng.set_piece_queue(0)
+
+
+def test_pieced_streaming_launch_follows_the_oracle_run_at_d128():
+    """The C5 shard runs pieced launches of the streaming sampler (rows through the LDS-DMA ring, chains in lock step):
+    one site with D = 128 (d = 258, P = 387, seven registers per vector), a short run cut into pieces of 3
+    transitions, against the oracle chain by chain."""
+    model, D, n, it, chains = 'm4b_sg', 128, 400, 24, 4
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 3, K=2, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    assert (d, P) == (258, 387)
+    seeds = np.array([7, 8], dtype=np.int64)
+    eng.set_piece_queue(3, None)
+    eng.sample_batch(seeds, HipEngine.sampler_opts(chains=chains, iter=it, init='random'))
+    assert eng.last_layout() == 3 and eng.last_segments() == -8
+    draws_o, _, st_o = no.nuts_sites(model, X, y, k_lim, mu_dev, Om_dev, seeds, chains=chains, iter=it)
+    n_full = _chains_equal_to_the_end(eng, draws_o, st_o, 2, chains, it, P)
+    record_slack('pieced streaming launch vs oracle D=128: chains equal to the end', n_full, '>= 6', 8)
+    assert n_full >= 6, n_full
+    eng.set_piece_queue(0)
+
+
+def test_site_deltas_at_c3_size_follow_the_oracle_moment_stage():
+    """C3 site shape on 300 sites (more sites than CUs: pieced launches of layout 7): the site deltas dQi, dri
+    (method.py:413-458) that the device computed from its own draws against the NumPy oracle's moment stage from the
+    same draws and the global approximation the iteration started from."""
+    J, D, n = 300, 32, 500
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
+               df0=models.default_df0(J))
+    assert M.run(1, verbose=False, calc_moments=False, seed=3) == 0
+    Q1, r1 = M.Q.copy(), M.r.copy()
+    assert M.run(1, verbose=False, calc_moments=False, seed=4) == 0
+    eng = M.engine
+    assert eng.last_layout() == 7 and eng.last_segments() < 0
+    for k in (0, 137, 299):
+        samp = eng.get_draws(k)
+        dQ_o, dr_o, mt, scatter, ok = eo.tilted_moments(samp, Q1, r1, 'sample')
+        assert ok and samp.shape == (400, 66)
+        np.testing.assert_allclose(M.dQi[:, :, k], dQ_o, rtol=1e-7, atol=1e-7 * np.abs(dQ_o).max())
+        np.testing.assert_allclose(M.dri[:, k], dr_o, rtol=1e-7, atol=1e-7 * np.abs(dr_o).max())
+
+
+def test_c5_shard_launch_with_invariants():
+    """BASELINE config C5's per-GPU shard at its own size: 512 sites, D = 128, n_j = 2000 (d = 258), 4 x 200 NUTS
+    iterations per site, pieced launch of the streaming sampler -- one EP iteration with prec_estim='olse':
+    finite, symmetric, positive definite, site sums consistent with the global approximation, every site sampled,
+    and one site's delta against the oracle's moment stage from the device's own draws."""
+    J, D, n = 512, 128, 2000
+    mod = models.m4b(J, D, n)
+    data = mod.simulate_data(rng=100)                     # uncorrelated covariates (footnote)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
+               prec_estim='olse', df0=models.default_df0(J))
+    Qs, rs = M.Q.copy(), M.r.copy()
+    info, (m_s, S_s) = M.run(1, verbose=False, seed=5)
+    eng = M.engine
+    assert info == 0 and eng.last_layout() == 3 and eng.last_segments() < 0
+    assert np.all(np.isfinite(m_s)) and np.all(np.isfinite(S_s))
+    np.testing.assert_allclose(S_s[0], S_s[0].T, rtol=1e-9, atol=1e-13)
+    assert np.linalg.eigvalsh(S_s[0])[0] > 0
+    np.testing.assert_allclose(M.Q, M.Q0 + M.Qi.sum(axis=2), rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(M.r, M.r0 + M.ri.sum(axis=1), rtol=1e-9, atol=1e-7)
+    stats = M.last_site_stats
+    assert stats[:, 7].sum() == 0 and np.all(stats[:, 2] > 0)
+    print('C5 shard: leapfrogs per transition %.0f, sampling launch %.1f s' % (stats[:, 2].sum() / (J * 4 * 200), M.sampling_ms[-1] * 1e-3))
+    k = 311
+    samp = eng.get_draws(k)
+    dQ_o, dr_o, mt, scatter, ok = eo.tilted_moments(samp, Qs, rs, 'olse')
+    assert ok and samp.shape == (400, 258)
+    np.testing.assert_allclose(M.dQi[:, :, k], dQ_o, rtol=1e-7, atol=1e-7 * np.abs(dQ_o).max())
+    np.testing.assert_allclose(M.dri[:, k], dr_o, rtol=1e-7, atol=1e-7 * np.abs(dr_o).max())
+
+
+def test_team_layout_falls_back_when_the_padded_rows_do_not_fit():
+    """Layout 7 keeps an even number of whole 16-row tiles per row wave in LDS; a site whose padded rows do not fit
+    is served by layout 5 (request and automatic choice alike), and small / ragged sites run on 7."""
+    def picked(D, n, K, layout=0):
+        rng = np.random.RandomState(1)
+        X = rng.randn(K * n, D)
+        y = (rng.rand(K * n) < 0.5).astype(int)
+        eng = HipEngine('m4b_sg', X, y, np.arange(K + 1) * n)
+        d = eng.d
+        eng.set_prior(np.eye(d), np.zeros(d))
+        eng.set_global(np.eye(d) * 2.0, np.zeros(d))
+        assert np.all(eng.cavity_batch(0))
+        eng.sample_batch(np.arange(K) + 1, HipEngine.sampler_opts(chains=4, iter=4, init='random', max_depth=3, layout=layout))
+        lay = eng.last_layout()
+        eng.close()
+        return lay
+    assert picked(32, 500, 400) == 7
+    assert picked(32, 17, 400) == 7
+    assert picked(16, 1160, 400) == 5         # 1160 rows pad to 1280: the TEAM form does not fit the LDS, layout 5 does
+    assert picked(16, 1160, 400, layout=7) == 5
