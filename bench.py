@@ -33,6 +33,12 @@ FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0
 LDS_PEAK_TBS = 150.0
 
+# Hooks for tests/test_multirank_gloo.py only (None = the product path: HipEngine behind Master, RCCL inside libepx.so):
+# a CPU run of THIS file at the driver's world size executes the rank-0 JSON assembly, the barriers and the reductions
+# around the timed region before the driver depends on them.  Nothing in this file sets them.
+_ENGINE_FACTORY = None
+_COMM_FACTORY = None
+
 CONFIGS = {
     # name: (sites per GPU, D, n_j, correlated covariates, default steps, default warm-up)
     'c2': (64, 16, 200, 1, 20, 5),
@@ -121,12 +127,17 @@ def cpu_baseline(M, mod, data, chains, siter, n_all, n_seq, threads):
 
 def spawn_ranks(n, argv):
     """Parent of a plain `bench.py --gpus N`: start N fresh ranks, relay their output."""
-    with socket.socket() as s:
+    # two verified free ports: torchrun's rendezvous, and the one the ranks fall back to for the RCCL id when
+    # torchrun's store is not usable (dist.EpxComm); both sockets stay open until both numbers are known
+    with socket.socket() as s, socket.socket() as s2:
         s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
+        s2.bind(('127.0.0.1', 0))
+        port, port2 = s.getsockname()[1], s2.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
-    return subprocess.call(cmd)
+    env = dict(os.environ)
+    env.setdefault('EPX_COMM_PORT', str(port2))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -137,7 +148,7 @@ def main():
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--sites', type=int, default=None, help='sites per GPU (J = sites * gpus)')
     ap.add_argument('--D', type=int, default=None)
-    ap.add_argument('--n', type=int, default=None)
+    ap.add_argument('--n', '--rows', dest='n', type=int, default=None, help='rows per site')
     ap.add_argument('--model', default='m4b')
     ap.add_argument('--chains', type=int, default=4)
     ap.add_argument('--siter', type=int, default=200)
@@ -193,22 +204,26 @@ def main():
     import torch
     from epstan_amd import dist as edist, models
     from epstan_amd.method import Master
-    torch.cuda.set_device(local_rank)
+    on_gpu = _ENGINE_FACTORY is None
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     # every rank, also a single one, goes through the in-library RCCL communicator
-    comm = edist.EpxComm(rank=rank, world=world)
+    comm = edist.EpxComm(rank=rank, world=world) if _COMM_FACTORY is None else _COMM_FACTORY(rank, world)
 
     J = sites * world
     mod, data, Q0, r0 = workload(J, D, n, args.model, bool(cor))
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
                chains=args.chains, iter=args.siter, prec_estim=args.prec_estim,
                df0=models.default_df0(J), comm=comm, device=local_rank, layout=args.layout,
-               adapt=args.adapt, sync_sites=False)
-    rccl_rank, rccl_world = comm.size()
+               adapt=args.adapt, sync_sites=False, **({} if on_gpu else {'_engine_factory': _ENGINE_FACTORY}))
+    rccl_rank, rccl_world = comm.size() if hasattr(comm, 'size') else (comm.rank, comm.world)
 
     def sync():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         comm.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     if warm > 0:
         info = M.run(warm, verbose=False, seed=1)[0]
@@ -222,8 +237,10 @@ def main():
     info = res[0]
     tmax = float(comm.allreduce_max(np.array([dt]))[0])
     if rank != 0:
-        comm.barrier()          # rank 0's cpu_baseline leg needs nothing from the others
-        comm.close()
+        # rank 0's cpu_baseline leg needs nothing from the others, and they must not spin in a collective beside it
+        # (an RCCL barrier busy-waits a host thread per rank): they are done -- ncclCommDestroy needs no peer
+        if hasattr(comm, 'close'):
+            comm.close()
         return
     assert info == 0, 'EP failed with info %d' % info
 
@@ -329,8 +346,8 @@ def main():
         except Exception as ex:                      # the baseline must not void the GPU measurement
             out['cpu_baseline'] = {'value': None, 'unit': 'site-updates/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %r' % (ex,)}
-    comm.barrier()
-    comm.close()
+    if hasattr(comm, 'close'):
+        comm.close()
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + '\n').encode())
 

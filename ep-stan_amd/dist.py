@@ -65,11 +65,14 @@ def _scatter_gathered(parts, lead, per, counts, K):
 class EpxComm(object):
     """RCCL communicator held by libepx.so: one process per GPU, sites sharded over the ranks.
 
-    Rank and world size default to torchrun's environment (RANK / WORLD_SIZE).  The 128-byte
-    RCCL id goes from rank 0 to the others over a plain TCP connection to
-    MASTER_ADDR:(EPX_COMM_PORT or MASTER_PORT + 23) -- no torch.distributed involved.
+    Rank and world size default to torchrun's environment (RANK / WORLD_SIZE).  The 128-byte RCCL id goes from rank 0
+    to the others through a channel that already exists when there is one -- the key-value store torchrun's agent
+    serves on MASTER_ADDR:MASTER_PORT (no second port, nothing to bind) -- and otherwise over a plain TCP connection to
+    MASTER_ADDR:EPX_COMM_PORT (default MASTER_PORT + 23; `bench.py` picks and verifies a free one), where rank 0
+    counts a peer only once it has acknowledged the id.
     `Master` binds the communicator to its engine (`bind`, collective over all ranks)."""
     native = True
+    _binds = 0                # binds so far in this process: every rank binds in the same order -> a common key
 
     def __init__(self, rank=None, world=None, addr=None, port=None):
         env = os.environ
@@ -84,12 +87,36 @@ class EpxComm(object):
             raise ValueError('rank {} outside 0..{}'.format(self.rank, self.world - 1))
 
     # ---- bootstrap
+    def _store_exchange(self, uid, seq):
+        """Through torchrun's store (TORCHELASTIC_USE_AGENT_STORE): returns the id, or None when there is no such store."""
+        env = os.environ
+        if env.get('TORCHELASTIC_USE_AGENT_STORE', '') != 'True' or 'MASTER_PORT' not in env:
+            return None
+        try:
+            from datetime import timedelta
+            from torch.distributed import TCPStore
+            store = TCPStore(self.addr, int(env['MASTER_PORT']), self.world, False, timedelta(seconds=300))
+            key = 'epx_comm_id/%s/%s/%d' % (env.get('TORCHELASTIC_RUN_ID', '-'), env.get('TORCHELASTIC_RESTART_COUNT', '0'), seq)
+            if self.rank == 0:
+                store.set(key, uid)
+                return uid
+            return bytes(store.get(key))          # blocks until rank 0 has set it
+        except Exception as ex:                   # no store after all: the socket exchange below
+            import sys
+            print('epx: torchrun store not usable for the RCCL id (%r), using the socket exchange' % (ex,), file=sys.stderr)
+            return None
+
     def _exchange_id(self, uid):
         """Rank 0 serves `uid` to every other rank; the others fetch it (retrying while rank 0
         is not listening yet)."""
         n = _lib.COMM_ID_BYTES
         if self.world == 1:
             return uid
+        seq = EpxComm._binds
+        EpxComm._binds += 1
+        got = self._store_exchange(uid, seq)
+        if got is not None:
+            return got
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -101,10 +128,14 @@ class EpxComm(object):
                 while len(seen) < self.world - 1:
                     conn, _ = srv.accept()
                     with conn:
-                        conn.settimeout(60.0)
-                        peer = struct.unpack('<i', _recv_exact(conn, 4))[0]
-                        conn.sendall(uid)
-                        seen.add(peer)
+                        try:
+                            conn.settimeout(60.0)
+                            peer = struct.unpack('<i', _recv_exact(conn, 4))[0]
+                            conn.sendall(uid)
+                            if _recv_exact(conn, 1) == b'k':      # counted only once the peer HAS the id (it reconnects otherwise)
+                                seen.add(peer)
+                        except (ConnectionResetError, socket.timeout, OSError):
+                            pass
             finally:
                 srv.close()
             return uid
@@ -113,7 +144,9 @@ class EpxComm(object):
             try:
                 with socket.create_connection((self.addr, self.port), timeout=10.0) as conn:
                     conn.sendall(struct.pack('<i', self.rank))
-                    return _recv_exact(conn, n)
+                    got = _recv_exact(conn, n)
+                    conn.sendall(b'k')
+                    return got
             except (ConnectionRefusedError, ConnectionResetError, socket.timeout, OSError):
                 if time.time() > deadline:
                     raise

@@ -47,6 +47,24 @@ def _g6_master(runs, scenario, df0, nsites, comm=None, **kw):
     return M
 
 
+def _wide_problem(nsites=16, n=40, D=4):
+    """A synthetic problem with enough sites for eight ranks (the goldens have four)."""
+    rng = np.random.RandomState(77)
+    X = rng.randn(nsites * n, D)
+    y = (rng.rand(nsites * n) < 0.55).astype(int)
+    return X, y, np.full(nsites, n)
+
+
+def _wide_master(scenario, df0, comm=None, **kw):
+    import injectors
+    from epstan_amd.method import Master
+    X, y, Nj = _wide_problem()
+    M = Master('m1b_sg', X, y, site_sizes=Nj, prior={'Q': np.eye(5) * 0.25, 'r': np.zeros(5)},
+               A_k={'site_id': np.arange(len(Nj))}, chains=4, iter=200, df0=df0, comm=comm, **kw)
+    M._sample_injector = injectors.GaussianTilted(scenario)
+    return M
+
+
 @pytest.mark.parametrize('tag,scenario,niter,df0,nsites', [('smooth', 'smooth', 12, 0.5, 4),
                                                            ('decay', 'wide_first', 4, 1.0, 3)])
 def test_rccl_world_of_one_equals_the_local_path_and_the_goldens(runs, tag, scenario, niter, df0, nsites):
@@ -126,8 +144,14 @@ def _worker(rank, world, port, mode, outdir, transport):
         info, (m_s, S_s) = M.run(4, verbose=False, seed=1)
         np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
                  klo=M.k_lo, khi=M.k_hi)
+    elif mode in ('wide', 'wide_decay'):
+        M = _wide_master('smooth' if mode == 'wide' else 'wide_first', 0.5 if mode == 'wide' else 1.0, comm=comm, device=device)
+        info, (m_s, S_s) = M.run(6, verbose=False, seed=1)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
+                 klo=M.k_lo, khi=M.k_hi, df=np.array(M.df_log))
     else:
-        mod = models.m4b(6, 3, 60)
+        nsite = 16 if mode == 'nuts16' else 6
+        mod = models.m4b(nsite, 3, 60)
         data = mod.simulate_data(Sigma_x='rand', rng=100)
         _, _, Q0, r0 = mod.get_prior()
         M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
@@ -185,6 +209,61 @@ def test_sharding_does_not_change_the_first_iteration_on_gpu(tmp_path, transport
     from epstan_amd.method import Master
     res = _spawn('nuts', tmp_path, transport)
     mod = models.m4b(6, 3, 60)
+    data = mod.simulate_data(Sigma_x='rand', rng=100)
+    _, _, Q0, r0 = mod.get_prior()
+    M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=120, df0=0.4)
+    info, (m_s, S_s), an = M.run(1, verbose=False, return_analytics=True, seed=3)
+    for r in res:
+        assert int(r['info']) == info == 0
+        np.testing.assert_allclose(r['m'], m_s, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['Qi'], M.Qi, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r['msteps'], an[1], rtol=1e-12)
+        np.testing.assert_allclose(r['mrhats'], an[2], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ the driver's world size on one device
+def test_four_ranks_one_site_each_reproduce_the_reference_trajectory(runs, tmp_path):
+    """The four-site golden trajectory with one site per rank: four processes share device 0 and run the library's own
+    multi-rank code (epx_update_trial with per-rank statistics slots, site offsets, flag reductions) over gloo."""
+    res = _spawn('injected', tmp_path, 'host', world=4)
+    assert [(int(r['klo']), int(r['khi'])) for r in res] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    for r in res:
+        assert int(r['info']) == int(runs['g6_smooth_info'])
+        np.testing.assert_allclose(r['m'], runs['g6_smooth_m'], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['S'], runs['g6_smooth_S'], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['Qi'], runs['g6_smooth_Qi'], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(r['Q'], runs['g6_smooth_Q'], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize('mode,scenario,df0', [('wide', 'smooth', 0.5), ('wide_decay', 'wide_first', 1.0)])
+def test_eight_ranks_equal_one_rank_with_the_injected_sampler(tmp_path, mode, scenario, df0):
+    """World size 8 (the driver's node) on one device: 16 sites, two per rank, the deterministic injected sampler --
+    a smooth run and one whose first site drives the damping decay (non-positive-definite cavities on some ranks only:
+    the flag reduction decides for all).  Trajectory, site parameters and damping factors equal the one-rank run's."""
+    res = _spawn(mode, tmp_path, 'host', world=8)
+    L = _wide_master(scenario, df0)
+    info, (m_s, S_s) = L.run(6, verbose=False, seed=1)
+    assert [(int(r['klo']), int(r['khi'])) for r in res] == [(2 * i, 2 * i + 2) for i in range(8)]
+    if mode == 'wide_decay':
+        assert min(L.df_log) < 1.0                      # the decay branch was taken
+    for r in res:
+        assert int(r['info']) == info
+        np.testing.assert_allclose(r['df'], L.df_log, rtol=0, atol=0)
+        np.testing.assert_allclose(r['m'], m_s, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['S'], S_s, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['Qi'], L.Qi, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r['Q'], L.Q, rtol=1e-9, atol=1e-10)
+    for r in res[1:]:
+        np.testing.assert_array_equal(r['Qi'], res[0]['Qi'])
+
+
+def test_eight_ranks_equal_one_rank_with_the_real_sampler(tmp_path):
+    """The same with the device sampler: seeds are indexed by global site id, so eight ranks sample the draws one
+    rank samples in the first iteration."""
+    from epstan_amd import models
+    from epstan_amd.method import Master
+    res = _spawn('nuts16', tmp_path, 'host', world=8)
+    mod = models.m4b(16, 3, 60)
     data = mod.simulate_data(Sigma_x='rand', rng=100)
     _, _, Q0, r0 = mod.get_prior()
     M = Master('m4b_sg', data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=120, df0=0.4)

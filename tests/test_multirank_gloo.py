@@ -161,3 +161,81 @@ def test_two_ranks_with_groups_sweep_and_mix(tmp_path):
         np.testing.assert_allclose(r['mm'], mm, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(r['Sm'], Sm, rtol=1e-9, atol=1e-12)
     assert M.sweep_log[0]['cav_pd'][0] and not M.sweep_log[0]['cav_pd'][-1]
+
+
+# ------------------------------------------------------------------ the driver's launch, on CPU
+def _run_torchrun(n, script, args, timeout=600):
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script] + args
+    env = dict(os.environ)
+    env['OMP_NUM_THREADS'] = '1'
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+
+
+def test_bench_runs_end_to_end_at_world_size_8_on_cpu():
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one process per rank), with the oracle
+    engine and a gloo transport in place of the device: rendezvous, warm-up, timed region between barriers, max over
+    ranks, ONE JSON line from rank 0 with the whole-job value, clean exit of every rank."""
+    import json
+    res = _run_torchrun(8, os.path.join(ROOT, 'tests', 'bench_cpu_smoke.py'),
+                        ['--gpus', '8', '--sites', '2', '--D', '3', '--rows', '30', '--siter', '20', '--steps', '2',
+                         '--warmup', '1', '--cpu-sites', '0'])
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['config']['rccl_world_size'] == 8
+    assert out['metric'] == 'site-updates/sec' and out['unit'] == 'site-updates/s'
+    np.testing.assert_allclose(out['value'], 16 * 2 / (out['ms_per_step'] * 1e-3 * 2), rtol=1e-9)     # 16 sites, whole job
+    assert 'roofline' in out and out['roofline']['frac'] > 0
+
+
+def test_rccl_id_travels_through_torchruns_store():
+    """dist.EpxComm hands the RCCL id from rank 0 to the others through the key-value store torchrun's agent serves on
+    MASTER_PORT (no second port): four ranks, two binds in a row, every rank ends up with rank 0's bytes."""
+    helper = os.path.join(ROOT, 'tests', 'uid_exchange_helper.py')
+    res = _run_torchrun(4, helper, [], timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = sorted(l for l in res.stdout.splitlines() if l.startswith('uid '))
+    assert len(got) == 4 and len(set(l.split(' ', 2)[2] for l in got)) == 1, res.stdout
+
+
+def test_rccl_id_socket_exchange_counts_a_peer_only_after_its_acknowledgement():
+    """Without torchrun's store the id goes over a TCP connection to EPX_COMM_PORT; rank 0 keeps serving until every
+    peer has acknowledged (a peer that drops the connection before that is served again)."""
+    import threading
+    from epstan_amd import dist
+    port = _free_port()
+    uid = bytes(range(128))
+    out = {}
+
+    def rank0():
+        out[0] = dist.EpxComm(rank=0, world=3, addr='127.0.0.1', port=port)._exchange_id(uid)
+
+    def peer(r, flaky):
+        import socket as sk, struct, time
+        if flaky:                           # first attempt: ask, then hang up before taking the id
+            for _ in range(200):
+                try:
+                    c = sk.create_connection(('127.0.0.1', port), timeout=5.0)
+                    c.sendall(struct.pack('<i', r))
+                    c.close()
+                    break
+                except OSError:
+                    time.sleep(0.02)
+        out[r] = dist.EpxComm(rank=r, world=3, addr='127.0.0.1', port=port)._exchange_id(b'')
+
+    env_keep = os.environ.pop('TORCHELASTIC_USE_AGENT_STORE', None)
+    try:
+        ts = [threading.Thread(target=rank0), threading.Thread(target=peer, args=(1, True)), threading.Thread(target=peer, args=(2, False))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+    finally:
+        if env_keep is not None:
+            os.environ['TORCHELASTIC_USE_AGENT_STORE'] = env_keep
+    assert out.get(0) == uid and out.get(1) == uid and out.get(2) == uid
