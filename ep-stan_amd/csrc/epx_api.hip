@@ -634,8 +634,31 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
     c->last_segments = 0;
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
-    const bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
-                           o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
+    bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
+                     o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
+    if (use_queue) {
+        // A pieced launch keeps tree stack + cold store per WORKGROUP (sites x pieces regions: 4 GB at the C5 shard) and a
+        // checkpoint record per piece boundary.  If the device cannot give that memory, the launch runs unpieced -- same
+        // draws, one workgroup per site -- instead of failing the sampling call.
+        const int npieces = (o.iter + c->dyn_len - 1) / c->dyn_len;
+        const size_t need_stack = (size_t)count * npieces * o.chains * a.stack_stride;
+        const size_t need_ckpt = (size_t)count * (npieces + 1) * o.chains * (size_t)(4 * nv + 1) * 64;
+        if (c->stack_elems < need_stack) {
+            double *p = nullptr;
+            if (dalloc(&p, need_stack) == hipSuccess) {
+                if (c->stack) (void)hipFree(c->stack);
+                c->stack = p; c->stack_elems = need_stack;
+            } else { (void)hipGetLastError(); use_queue = false; }
+        }
+        if (use_queue && c->ckpt_n < need_ckpt) {
+            double *p = nullptr;
+            if (dalloc(&p, need_ckpt) == hipSuccess) {
+                if (c->ckpt) (void)hipFree(c->ckpt);
+                c->ckpt = p; c->ckpt_n = need_ckpt;
+            } else { (void)hipGetLastError(); use_queue = false; }
+        }
+        if (use_queue) a.stack = c->stack;
+    }
     if (use_queue) {
         HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));
         a.dyn_prog = c->dyn_words; a.dyn_busy = c->dyn_words + count;
@@ -741,8 +764,14 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     c->last_layout = layout;
     c->nsamp = o.chains * nkeep;
     int herr = 0;
-    if (layout == 5 || layout == 6 || layout == 7 || use_queue) HIPCHK(hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        // (no return between a queued copy into this frame and the synchronisation)
+        hipError_t e = hipSuccess;
+        if (layout == 5 || layout == 6 || layout == 7 || use_queue) e = hipMemcpyAsync(&herr, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        const hipError_t es = hipStreamSynchronize(c->stream);
+        HIPCHK(e);
+        HIPCHK(es);
+    }
     if (herr) {
         HIPCHK(hipMemset(c->err_flag, 0, sizeof(int)));
         return fail("sampler: a hand-off between the waves of a chain timed out (code %d); the draws of this call are void", herr);
@@ -1111,11 +1140,17 @@ int epx_update_trial(epx_ctx *c, double df, int reduce_sums, int site_base, doub
     HIPCHK(hipGetLastError());
     if (epx_comm_allreduce_dev(c, trial_d, 3, EPX_OP_MIN)) return -1;
     double tf[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(tf, trial_d, sizeof tf, hipMemcpyDeviceToHost, c->stream));
-    if (reduce_sums && next) HIPCHK(hipMemcpyAsync(ext.data(), ext_d, (size_t)next * 8, hipMemcpyDeviceToHost, c->stream));
-    if (want_moments && S) HIPCHK(hipMemcpyAsync(S, c->S, (size_t)c->d * c->d * 8, hipMemcpyDeviceToHost, c->stream));
-    if (want_moments && m) HIPCHK(hipMemcpyAsync(m, c->m, (size_t)c->d * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));           // the one synchronisation of the trial
+    {
+        // Once a device-to-host copy into this frame's buffers is queued, nothing returns before the stream has been
+        // synchronised: a copy that lands after an early return would write into a dead stack frame
+        hipError_t e = hipMemcpyAsync(tf, trial_d, sizeof tf, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && reduce_sums && next) e = hipMemcpyAsync(ext.data(), ext_d, (size_t)next * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && want_moments && S) e = hipMemcpyAsync(S, c->S, (size_t)c->d * c->d * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && want_moments && m) e = hipMemcpyAsync(m, c->m, (size_t)c->d * 8, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t es = hipStreamSynchronize(c->stream);           // the one synchronisation of the trial
+        HIPCHK(e);
+        HIPCHK(es);
+    }
     *global_pd = tf[0] != 0.0;
     *cav_pd = tf[1] != 0.0;
     if (first_bad) *first_bad = tf[2] >= 1e17 ? -1 : (int64_t)tf[2];

@@ -81,7 +81,7 @@ int epx_comm_unique_id(void *id_out) {
 
 int epx_comm_init(epx_ctx *c, const void *id, int rank, int nranks) {
     CTX(c);
-    if (c->comm) return fail("the context already has a communicator");
+    if (c->comm || c->comm_ext) return fail("the context already has a communicator");
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail("bad communicator arguments (rank %d of %d)", rank, nranks);
     if (load_rccl()) return -1;
     ncclUniqueId uid;

@@ -84,8 +84,6 @@ def main(model_name, conf, ret_master=False, verbose=True, _engine_factory=None,
     if conf.run_full or conf.run_consensus or conf.run_target or conf.run_all:
         raise NotImplementedError("only the distributed EP method (`run_ep`) is built; the full, "
                                   "consensus and target runs need Stan itself")
-    if conf.mix:
-        raise NotImplementedError("`mix` (Master.mix_phi / mix_pred) is out of scope (SURVEY.md §2)")
     J, D, K = conf.J, conf.D, conf.K
     if model_name not in models.MODELS:
         raise ValueError("unknown model {!r}; available: {}".format(model_name, sorted(models.MODELS)))
@@ -129,6 +127,12 @@ def main(model_name, conf, ret_master=False, verbose=True, _engine_factory=None,
                mstepsize_s_ep=mstepsize_s_ep, mrhat_s_ep=mrhat_s_ep, othertimes=othertimes)
     if info:
         res['last_iter'] = epstan_master.iter                                            # fit.py:391-403
+    elif conf.mix:
+        # fit.py:408-411, 440-441: the final approximation from the last samples of all the sites.  `mix_pred`
+        # (fit.py:414-421) reads worker.fit, which the reference's own child-process sampler never keeps: out of scope
+        S_ep, m_ep = epstan_master.mix_phi()
+        res['m_phi_ep'] = m_ep
+        res['S_phi_ep'] = S_ep
     if conf.save_res:
         os.makedirs(RES_PATH, exist_ok=True)
         fname = 'res_d_{}_{}.npz'.format(model_name, conf.id) if conf.id else 'res_d_{}.npz'.format(model_name)

@@ -271,6 +271,14 @@ def test_fit_configurations_and_ep_branch_schema(tmp_path, monkeypatch):
     np.testing.assert_allclose(res['S_s_ep'][0], np.eye(d) * 1.5**2, rtol=1e-12)        # the prior (m1b.py:46-50)
     with pytest.raises(NotImplementedError):
         fit.main('m1b', fit.configurations(run_full=True), _engine_factory=factory)
+    # conf.mix (fit.py:408-411, 440-441): the final approximation mixed from the last samples of all the sites
+    conf = fit.configurations(J=4, D=3, K=4, npg=15, iter=2, siter=40, run_ep=True, id='mx', mix=True)
+    res = fit.main('m1b', conf, verbose=False, _engine_factory=factory)
+    saved = np.load(os.path.join(str(tmp_path), 'res_d_m1b_mx.npz'), allow_pickle=True)
+    assert {'m_phi_ep', 'S_phi_ep'} <= set(saved.files)
+    assert res['m_phi_ep'].shape == (d,) and res['S_phi_ep'].shape == (d, d)
+    assert np.linalg.eigvalsh(res['S_phi_ep'])[0] > 0
+    np.testing.assert_allclose(saved['S_phi_ep'], res['S_phi_ep'])
     M = fit.main('m4b', fit.configurations(J=4, D=2, K=4, npg=10), ret_master=True, _engine_factory=factory)
     assert isinstance(M, Master) and M.dphi == 6 and abs(M.df0(1) - 0.5) < 1e-15
 
