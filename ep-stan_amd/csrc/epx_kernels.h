@@ -147,6 +147,7 @@ struct NutsArgs {
     int n_max;                    // rows reserved for X in LDS
     int off_y, off_Om, off_mu, off_xch, off_stack, lds_bytes;
     int stack_in_lds;
+    int scr_doubles;              // ... its length (the P live elements, rounded up)
     int off_scr;                  // nuts_duo.hip TEAM form: per chain one vector of LDS scratch (view -> vector order)
     int stack_ps;                 // ... and the doubles one vector of such a record takes (packed: >= P)
     int stack_lds_levels;         // nuts_duo.hip, stack not (all) in LDS: the lowest levels of every chain's tree stack that are (0: none)

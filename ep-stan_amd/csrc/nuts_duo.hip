@@ -182,7 +182,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // One chain per workgroup (RW > 1): [job RES | v = phi - mu (NV x 64) | per row wave: X'g, sum g, log-lik (RES) |
     // Omega v (NV x 64)] -- the cavity term is taken off the state wave, the longest role of this form, by a wave of
     // its own (O) that works beside the row waves
-    constexpr int VOFF = RES, RREC = RES, RESO = RES + NV * 64, OVOFF = RESO + RW * RREC;
+    // (VN: doubles of the v and Omega v lines -- the TEAM form keeps only the d <= 2 DP + 2 live ones, in whole 16-byte
+    // pairs, and gives the LDS it saves to one more level of the tree stack)
+    constexpr int VN = (CPB == 4 && RW == 4 && 2 * DP + 8 < NV * 64) ? 2 * DP + 8 : NV * 64;
+    constexpr int VOFF = RES, RREC = RES, RESO = RES + VN, OVOFF = RESO + RW * RREC;
     // One chain per workgroup (CPB == 1): the tree bookkeeping gets a wave of its own (BK), as in k_nuts_spec --
     // the state wave integrates on speculatively and hands every finished state over through a two-entry mailbox;
     // BK answers with a control record only when the trajectory continues elsewhere (other tree end, new
@@ -286,7 +289,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             double *s0 = reinterpret_cast<double *>(smem + a.off_slot);
             for (int idx = tid; idx < CPB * a.slot_doubles; idx += blockDim.x) s0[idx] = 0.0;
             double *s1 = reinterpret_cast<double *>(smem + a.off_scr);
-            for (int idx = tid; idx < CPB * NV * 64; idx += blockDim.x) s1[idx] = 0.0;
+            for (int idx = tid; idx < CPB * a.scr_doubles; idx += blockDim.x) s1[idx] = 0.0;
         }
         if (tid < (TEAM ? 2 * CPB : CPB * NFLAG)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
         if constexpr (BKW) { for (int idx = tid; idx < 2 * MREC; idx += blockDim.x) mbox[idx] = 0.0; }     // (entries beyond P stay 0)
@@ -355,7 +358,17 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             TSTAMP_INIT;
             __builtin_amdgcn_s_setprio(EPX_PRIO_R);
             for (int pass = 1;; ++pass) {
+#ifdef EPX_STAMPS
+                const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
+#endif
                 const int live = team_wait_jobs(f_job, pass, nch, lane);
+#ifdef EPX_STAMPS
+                {   // histogram of this wait: bins of 512 cycles, the last one open (fourth record of the stamps)
+                    const unsigned long long dw_ = __builtin_amdgcn_s_memtime() - tw0_;
+                    int bin_ = (int)(dw_ >> 9); bin_ = bin_ > 15 ? 15 : bin_;
+                    if (a.stamps && wr == 0 && lane == 0 && pass > 1) atomicAdd(&a.stamps[((size_t)3 * gridDim.x) * 8 + bin_], 1ull);
+                }
+#endif
                 STAMP(5);
                 TSTAMP(0);
                 if (live <= 0) {
@@ -1016,7 +1029,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             if (lane < DP) job[BOFF + lane] = beta_l;
             if (lane == 0) job[0] = alpha;
             if constexpr (RW > 1) {
-                FORV { const int e = lane + 64 * i; slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
+                FORV { const int e = lane + 64 * i; if (e < VN) slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
             }
             ++seq;
             duo_publish(f_job, seq);
@@ -1150,7 +1163,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         else { FORV dbf[i] = 0.0; }
         if constexpr (RW > 1) {
             // the cavity term of this position, from its own wave (lean: only the view's coordinates of it)
-            if (!lean) { FORV Ov.v[i] = slot[OVOFF + lane + 64 * i]; }
+            if (!lean) { FORV { const int e = lane + 64 * i; Ov.v[i] = e < VN ? slot[OVOFF + (e < VN ? e : 0)] : 0.0; } }
             if (fast_ok) { vo1 = slot[OVOFF + ve1]; vo3 = slot[OVOFF + ve3]; }
         }
         if (fast_ok) {
@@ -1211,24 +1224,28 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     // accesses in order).  Entries beyond P are never written and stay 0.
                     const double lp1 = -0.5 * (q1o - vmu1) * vo1, lp3 = -0.5 * (q3o - vmu3) * vo3;
                     const double lp2 = laplace ? -fabs(q2o) : -0.5 * q2o * q2o;
-                    duo_lds_f64 *scr = duo_lds_at(smem + a.off_scr) + team * (NV * 64);
+                    duo_lds_f64 *scr = duo_lds_at(smem + a.off_scr) + team * a.scr_doubles;
                     if (v_lane) { scr[ve1] = q1o; scr[ve2] = q2o; scr[ve3] = q3o; }
                     wave_lds_exchange();
-                    FORV zq.v[i] = scr[lane + 64 * i];
+                    // (the line holds the P live elements; what lies beyond is 0 by definition)
+                    const int scr_n = a.scr_doubles;
+#define EPX_SCR(i_) (lane + 64 * (i_) < scr_n ? scr[lane + 64 * (i_) < scr_n ? lane + 64 * (i_) : 0] : 0.0)
+                    FORV zq.v[i] = EPX_SCR(i);
                     wave_lds_exchange();
                     if (v_lane) { scr[ve1] = fp1; scr[ve2] = fp2; scr[ve3] = fp3; }
                     wave_lds_exchange();
-                    FORV zp.v[i] = scr[lane + 64 * i];
+                    FORV zp.v[i] = EPX_SCR(i);
                     wave_lds_exchange();
                     if (v_lane) { scr[ve1] = g1; scr[ve2] = g2; scr[ve3] = g3; }
                     wave_lds_exchange();
-                    FORV zg.v[i] = scr[lane + 64 * i];
+                    FORV zg.v[i] = EPX_SCR(i);
                     wave_lds_exchange();
                     if (v_lane) { scr[ve1] = lp1; scr[ve2] = lp2; scr[ve3] = lp3; }
                     wave_lds_exchange();
                     double lpt = 0.0, ks = 0.0;
-                    FORV { lpt += scr[lane + 64 * i]; ks += inv_e.v[i] * zp.v[i] * zp.v[i]; }
+                    FORV { lpt += EPX_SCR(i); ks += inv_e.v[i] * zp.v[i] * zp.v[i]; }
                     wave_lds_exchange();
+#undef EPX_SCR
                     f_lpt = lpt; f_ks = ks; f_ll = uniform_d(ll);
                     pending = true;
                     STAMP(4);
@@ -1439,7 +1456,8 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     a.off_Om = (int)off; off += teamm ? 0 : (size_t)npad * dm * 16;
     a.off_tail = (int)off; off += nv > 1 && !teamm ? (size_t)2 * (2 * npad + 2) * 8 : 0;
     off = (off + 15) & ~(size_t)15;
-    a.slot_doubles = rw == 1 ? dp + 2 : (dp + 2) + nv * 64 + rw * (dp + 2) + nv * 64;            // as the kernel (VOFF, RESO, OVOFF)
+    const int vn = (teamm && 2 * dp + 8 < nv * 64) ? 2 * dp + 8 : nv * 64;                           // as the kernel (VN)
+    a.slot_doubles = rw == 1 ? dp + 2 : (dp + 2) + vn + rw * (dp + 2) + vn;                         // as the kernel (VOFF, RESO, OVOFF)
     a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
     const bool bkw = cpb == 1;                                                        // as the kernel (BKW)
     a.off_flag = (int)off; off += teamm ? 32 : (size_t)cpb * (1 + rw + (bkw ? 4 : 0)) * 4;
@@ -1450,7 +1468,8 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     const size_t cap = 160 * 1024;
     const size_t stack = (size_t)cpb * a.max_depth * nuts_stack_record(nv) * 8;
     a.off_scr = 0;
-    if (teamm) { a.off_scr = (int)off; off += (size_t)cpb * nv * 64 * 8; }
+    a.scr_doubles = (a.P + 7) & ~7;
+    if (teamm) { a.off_scr = (int)off; off += (size_t)cpb * a.scr_doubles * 8; }
     a.stack_in_lds = 0; a.off_stack = (int)off; a.stack_lds_levels = 0;
     if (off + stack <= cap) { a.stack_in_lds = 1; off += stack; }
     else if (teamm) {

@@ -31,9 +31,11 @@ def main():
     st = buf[:nb].astype(np.float64)
     det = None
     waves = None
-    if nb % 3 == 0 and eng.last_layout() == 7:          # second third: the phases of the row team's pass; third: per row wave
-        nb //= 3
-        det = st[nb:2 * nb]; waves = st[2 * nb:]; st = st[:nb]
+    hist = None
+    if (nb - 2) % 3 == 0 and eng.last_layout() == 7:    # second third: the phases of the row team's pass; third: per row wave; then a histogram
+        hist = st[nb - 2:].reshape(-1)
+        nb = (nb - 2) // 3
+        det = st[nb:2 * nb]; waves = st[2 * nb:3 * nb]; st = st[:nb]
     per = st[:, :7] / st[:, 7:8]
     med = np.median(per, axis=0)
     lf = eng.get_chain_stats(4)[:, :, 3]
@@ -54,6 +56,9 @@ def main():
         ok = det[:, 7] > 0
         w = waves[ok] / det[ok, 7:8]
         print('row waves 0..3, cycles per pass (median): waiting %s, working %s' % (np.round(np.median(w[:, :4], axis=0)), np.round(np.median(w[:, 4:], axis=0))))
+    if hist is not None:
+        print('row wave 0: waits for the jobs by length, bins of 512 cycles (last: >= 7680), share of the passes: %s' % np.round(hist / max(hist.sum(), 1), 3))
+        print('   ... share of the waiting TIME (bin centre x count): %s' % np.round((np.arange(16) + 0.5) * hist / max(((np.arange(16) + 0.5) * hist).sum(), 1), 3))
     big = int(np.argmax(st[:, 7]))
     print('the workgroup with the most leapfrogs (%d): cycles per leapfrog %s, total S %.0f, total R %.0f'
           % (st[big, 7], np.round(per[big]).astype(int), per[big, :5].sum(), per[big, 5:7].sum()))
