@@ -262,7 +262,8 @@ int epx_ctx_destroy(epx_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->comm || c->comm_ext) (void)epx_comm_destroy(c);
-    void *ptrs[] = {c->ckpt, c->dyn_rate, c->dyn_words, c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
+    delete c->dyn_rate_h; c->dyn_rate_h = nullptr;
+    void *ptrs[] = {c->dyn_lens_d, c->ckpt, c->dyn_rate, c->dyn_words, c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
                     c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
@@ -636,13 +637,39 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
     bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
                      o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
+    // Pieces of equal PREDICTED work: with a rate per site (leapfrogs per transition of the last call) a site gets pieces
+    // of  piece_len x (mean rate / its rate)  transitions, within [piece_len / 4, 4 piece_len] -- the workgroups of the
+    // launch then last about equally long.  (Workgroups go to the XCDs round-robin in launch order: while pieces differ
+    // 6 x in length, a CU that ends early waits until the dispatcher's turn comes back to its XCD -- 10 % of the CUs
+    // of a C5-shard launch were idle that way, profiles/r03_stream_piece_timeline.json.)
+    std::vector<int> lens_h;
+    size_t total_pieces = 0;
+    int nb_site = 0;
     if (use_queue) {
-        // A pieced launch keeps tree stack + cold store per WORKGROUP (sites x pieces regions: 4 GB at the C5 shard) and a
+        lens_h.assign((size_t)count, c->dyn_len);
+        if (c->dyn_has_rate && c->dyn_rate_h && (int)c->dyn_rate_h->size() >= count) {
+            double mean = 0.0;
+            for (int k = 0; k < count; ++k) mean += (*c->dyn_rate_h)[k];
+            mean /= count;
+            const int lo = c->dyn_len / 4 > 1 ? c->dyn_len / 4 : 1, hi = 4 * c->dyn_len;
+            for (int k = 0; k < count; ++k) {
+                int l = (int)std::lround(c->dyn_len * mean / (*c->dyn_rate_h)[k]);
+                l = l < lo ? lo : (l > hi ? hi : l);
+                lens_h[k] = l > o.iter ? o.iter : l;
+            }
+        }
+        for (int k = 0; k < count; ++k) {
+            const int np = (o.iter + lens_h[k] - 1) / lens_h[k];
+            total_pieces += np;
+            nb_site = np + 1 > nb_site ? np + 1 : nb_site;
+        }
+    }
+    if (use_queue) {
+        // A pieced launch keeps tree stack + cold store per WORKGROUP (one region per piece: 4 GB at the C5 shard) and a
         // checkpoint record per piece boundary.  If the device cannot give that memory, the launch runs unpieced -- same
         // draws, one workgroup per site -- instead of failing the sampling call.
-        const int npieces = (o.iter + c->dyn_len - 1) / c->dyn_len;
-        const size_t need_stack = (size_t)count * npieces * o.chains * a.stack_stride;
-        const size_t need_ckpt = (size_t)count * (npieces + 1) * o.chains * (size_t)(4 * nv + 1) * 64;
+        const size_t need_stack = total_pieces * o.chains * a.stack_stride;
+        const size_t need_ckpt = (size_t)count * nb_site * o.chains * (size_t)(4 * nv + 1) * 64;
         if (c->stack_elems < need_stack) {
             double *p = nullptr;
             if (dalloc(&p, need_stack) == hipSuccess) {
@@ -664,32 +691,15 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         a.dyn_prog = c->dyn_words; a.dyn_busy = c->dyn_words + count;
         a.dyn_rate = c->dyn_has_rate ? c->dyn_rate : nullptr;
         a.dyn_len = c->dyn_len; a.dyn_count = count;
-        const int npieces = (o.iter + c->dyn_len - 1) / c->dyn_len;
-        a.seg_nwg = count * npieces;
-        {
-            // tree stack + cold store are private to a WORKGROUP of a pieced launch (no line of them is ever shared by
-            // the L2s of two XCDs): one region per piece
-            const size_t need = (size_t)a.seg_nwg * o.chains * a.stack_stride;
-            if (c->stack_elems < need) {
-                if (c->stack) (void)hipFree(c->stack);
-                c->stack = nullptr; c->stack_elems = 0;
-                HIPCHK(dalloc(&c->stack, need));
-                c->stack_elems = need;
-            }
-            a.stack = c->stack;
-        }
+        if (!c->dyn_lens_d) HIPCHK(dalloc(&c->dyn_lens_d, (size_t)c->K));
+        HIPCHK(hipMemcpyAsync(c->dyn_lens_d, lens_h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));            // (lens_h is a local)
+        a.dyn_lens = c->dyn_lens_d; a.dyn_nb = nb_site;
+        a.seg_nwg = (int)total_pieces;                      // one workgroup per piece
+        a.stack = c->stack;                                  // (tree stack + cold store: one region per piece, sized above)
+        a.ckpt = c->ckpt;                                    // (one record per piece boundary of a site)
         a.order = nullptr;
-        c->last_segments = -npieces;                 // (negative: pieces per site of a queued launch)
-    }
-    if (use_queue) {
-        const size_t need = (size_t)count * ((o.iter + c->dyn_len - 1) / c->dyn_len + 1) * o.chains * (size_t)(4 * nv + 1) * 64;    // a record per piece boundary
-        if (c->ckpt_n < need) {
-            if (c->ckpt) (void)hipFree(c->ckpt);
-            c->ckpt = nullptr; c->ckpt_n = 0;
-            HIPCHK(dalloc(&c->ckpt, need));
-            c->ckpt_n = need;
-        }
-        a.ckpt = c->ckpt;
+        c->last_segments = -((o.iter + c->dyn_len - 1) / c->dyn_len);      // (negative: pieces per site of a queued launch, at the nominal length)
     }
     // Split launch (epx_set_site_split): the leading sites of the order -- the ones expected to
     // need the most leapfrogs -- run one workgroup per chain (layout 2, shorter leapfrog) on a
@@ -941,6 +951,8 @@ int epx_set_piece_queue(epx_ctx *c, int piece_len, const double *rate) {
             if (!(rate[k] > 0.0) || !std::isfinite(rate[k])) return fail("predicted work of site %d is not positive", k);
         if (!c->dyn_rate) HIPCHK(dalloc(&c->dyn_rate, (size_t)c->K));
         HIPCHK(hipMemcpy(c->dyn_rate, rate, (size_t)c->K * 8, hipMemcpyHostToDevice));
+        if (!c->dyn_rate_h) c->dyn_rate_h = new std::vector<double>();
+        c->dyn_rate_h->assign(rate, rate + c->K);
     }
     c->dyn_len = piece_len;
     return 0;

@@ -86,6 +86,8 @@ struct epx_ctx {
     size_t ckpt_n;
     // piece queue (epx_set_piece_queue): transitions per claim (0: off), predicted work per transition of the sites
     int dyn_len, dyn_has_rate;
+    int *dyn_lens_d;          // per-site piece lengths of the queue (device), their host copy below
+    std::vector<double> *dyn_rate_h;
     double *dyn_rate;
     int *dyn_words;           // [progress (K) | busy (K)]
     double *sweep_buf;        // damping sweep: target block + ndf x 5 criteria

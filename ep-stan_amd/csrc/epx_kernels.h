@@ -172,6 +172,8 @@ struct NutsArgs {
     int *dyn_prog, *dyn_busy;
     const double *dyn_rate;       // predicted work per transition of every site of the batch, or NULL (all equal)
     int dyn_len, dyn_count;
+    const int *dyn_lens;          // per site: transitions of one of ITS pieces (pieces of equal predicted work), or NULL: dyn_len for all
+    int dyn_nb;                   // checkpoint records (piece boundaries) reserved per site
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int

@@ -43,10 +43,14 @@ __host__ __device__ constexpr size_t piece_record_doubles(int nv) { return (size
 // written once per launch, by one workgroup, and read once, by another -- no XCD can hold an older version of it
 // (the first form had one record per site, and a site that came back to an XCD it had been on could read a mix of
 // that L2's older lines and fresh ones: a rare wrong trajectory, found by the EP parity test)
+// transitions of one piece of `site`: pieces hold equal PREDICTED work, so a site whose transitions are long has short ones
+template <class Args>
+__device__ __forceinline__ int piece_len_of(Args &a, int site) { return a.dyn_lens ? a.dyn_lens[site] : a.dyn_len; }
 template <class Args>
 __device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundary, int chain, int nv) {
-    const int b = t_boundary / a.dyn_len, nb = (a.iter + a.dyn_len - 1) / a.dyn_len + 1;
-    return a.ckpt + (((size_t)site * nb + b) * a.chains + chain) * piece_record_doubles(nv);
+    const int len = piece_len_of(a, site);
+    const int b = (t_boundary + len - 1) / len;          // (the last boundary is a.iter, whatever the length)
+    return a.ckpt + (((size_t)site * a.dyn_nb + b) * a.chains + chain) * piece_record_doubles(nv);
 }
 
 // Claim a site (all threads of the workgroup; the LDS must not hold anything yet: smem[0..1100) is scratch, and
@@ -132,7 +136,8 @@ template <class Args>
 __device__ __forceinline__ void piece_release(Args &a, unsigned char *smem) {
     volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
     const int r_site = pz[0], r_t0 = pz[1];
-    const int t1 = r_t0 + a.dyn_len < a.iter ? r_t0 + a.dyn_len : a.iter;
+    const int r_len = piece_len_of(a, r_site);
+    const int t1 = r_t0 + r_len < a.iter ? r_t0 + r_len : a.iter;
     __hip_atomic_store(a.dyn_prog + r_site, 2 * t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // progress up, claim off: one store
 }
 

@@ -227,7 +227,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     const int sb = queued ? q_site : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps));
     const int cb = queued ? 0 : blockIdx.x % bps;
     const int t_begin = queued ? q_t0 : 0;
-    const int t_end = queued ? (q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter) : a.iter;
+    const int q_len = queued ? piece_len_of(a, q_site) : 0;
+    const int t_end = queued ? (q_t0 + q_len < a.iter ? q_t0 + q_len : a.iter) : a.iter;
     const bool resume = t_begin > 0;
     const int k = a.k0 + sb;
     const int chain = cb * CPB + team;

@@ -73,15 +73,22 @@ __global__ void __launch_bounds__(RES ? 256 : STREAM_THREADS)
 k_nuts_stream(NutsArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     int q_site = -1, q_t0 = 0;
+#ifdef EPX_STAMPS
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();       // (100 MHz, the same clock on every CU)
+#endif
     if constexpr (PIECED) {
         if (!piece_claim(a, smem, (int)threadIdx.x, q_site, q_t0)) {
             if (threadIdx.x == 0) atomicOr(a.err, 4);
             return;
         }
     }
+#ifdef EPX_STAMPS
+    const unsigned long long tl_claim = __builtin_amdgcn_s_memrealtime();
+#endif
     const bool queued = PIECED;
     const int t_begin = queued ? q_t0 : 0;
-    const int t_end = queued ? (q_t0 + a.dyn_len < a.iter ? q_t0 + a.dyn_len : a.iter) : a.iter;
+    const int q_len = queued ? piece_len_of(a, q_site) : 0;
+    const int t_end = queued ? (q_t0 + q_len < a.iter ? q_t0 + q_len : a.iter) : a.iter;
     const bool resume = t_begin > 0;
     using V = VecS<NV>;
     constexpr int NT = RES ? 256 : STREAM_THREADS;
@@ -546,6 +553,10 @@ k_nuts_stream(NutsArgs a) {
     if (a.stamps && wave == 0 && lane0 == 0) {
         for (int i = 0; i < 7; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
         a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)ngrad;
+        // second record: the piece's timeline (entry, claim, end of sampling; site, first transition, leapfrogs)
+        unsigned long long *tl = a.stamps + ((size_t)gridDim.x + blockIdx.x) * 8;
+        tl[0] = tl_entry; tl[1] = tl_claim; tl[2] = __builtin_amdgcn_s_memrealtime();
+        tl[3] = (unsigned long long)sb; tl[4] = (unsigned long long)t_begin; tl[5] = (unsigned long long)ngrad;
     }
 #endif
     // ------------------------------------------------------------- epilogue
