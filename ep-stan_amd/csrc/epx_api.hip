@@ -637,17 +637,17 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
     bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
                      o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
-    // Pieces of equal PREDICTED work: with a rate per site (leapfrogs per transition of the last call) a site gets pieces
-    // of  piece_len x (mean rate / its rate)  transitions, within [piece_len / 4, 4 piece_len] -- the workgroups of the
-    // launch then last about equally long.  (Workgroups go to the XCDs round-robin in launch order: while pieces differ
-    // 6 x in length, a CU that ends early waits until the dispatcher's turn comes back to its XCD -- 10 % of the CUs
-    // of a C5-shard launch were idle that way, profiles/r03_stream_piece_timeline.json.)
+    // Piece lengths are per site.  Default: piece_len transitions for every site.  With EPX_EQUAL_WORK_PIECES set (A/B only)
+    // a site gets pieces of  piece_len x (mean rate / its rate)  transitions, within [piece_len / 4, 4 piece_len], so that
+    // the workgroups of the launch last about equally long -- tried against the 10 % of idle CUs that the piece timeline of
+    // a C5-shard launch shows (profiles/r03_stream_piece_timeline.json) and measured SLOWER (54.6 % against 58.1 % of the
+    // HBM peak: more pieces re-prime more often and the light sites' long pieces coarsen the end of the launch); kept off.
     std::vector<int> lens_h;
     size_t total_pieces = 0;
     int nb_site = 0;
     if (use_queue) {
         lens_h.assign((size_t)count, c->dyn_len);
-        if (c->dyn_has_rate && c->dyn_rate_h && (int)c->dyn_rate_h->size() >= count) {
+        if (getenv("EPX_EQUAL_WORK_PIECES") && c->dyn_has_rate && c->dyn_rate_h && (int)c->dyn_rate_h->size() >= count) {
             double mean = 0.0;
             for (int k = 0; k < count; ++k) mean += (*c->dyn_rate_h)[k];
             mean /= count;
