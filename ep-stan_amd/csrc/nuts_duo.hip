@@ -42,6 +42,9 @@ namespace epx {
 #ifndef EPX_DUO_SLEEP
 #define EPX_DUO_SLEEP 1
 #endif
+#ifndef EPX_TEAM_BARRIER
+#define EPX_TEAM_BARRIER 1       // 1: the TEAM form's hand-offs are workgroup barriers (two per pass); 0: polled LDS words (A/B)
+#endif
 #ifndef EPX_TEAM_SLEEP
 #define EPX_TEAM_SLEEP 2         // the state waves' looks at the row team's words (a pass takes thousands of cycles)
 #endif
@@ -117,6 +120,10 @@ __device__ inline void wave_lds_exchange() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The TEAM form's hand-off: every wave of the workgroup is in lock step with the passes anyway, so "the jobs are in"
+// and "the results are in" are the two s_barriers of a pass (LDS traffic drained first; vector-memory operations stay
+// in flight).  A waiting wave is parked by the hardware: no polls on the SIMD its partner computes on, no wake-up latency.
+__device__ inline void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 __device__ inline void ck_assign(GScal &x, double v) { x = v; }
 __device__ inline void ck_assign(RScal &x, double v) { x = v; }
@@ -202,6 +209,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // RW > 1 form: they sum the four waves' partial results in wave order.
     constexpr bool TEAM = CPB == 4 && RW == 4;
     constexpr int BOFF = TEAM ? 2 : 1;                // beta behind alpha in the job (TEAM: 16-byte aligned pairs)
+    constexpr bool TBAR = TEAM && EPX_TEAM_BARRIER;   // hand-offs by workgroup barriers (see team_barrier)
     constexpr int MREC = 4 * NV * 64 + 4;             // mailbox entry: q, p, grad, per-element log-density terms; ll, -, generation, -
     constexpr int CREC = 4 * NV * 64 + 4;             // control record: q, p, grad, metric, eps_l, command
     constexpr int NFLAG = TEAM ? 1 : 1 + RW + (BKW ? 4 : 0);     // per chain: job, results, (mail, acknowledged, control generation, cavity term); TEAM: the job word, the team's four words behind the chains'
@@ -249,6 +257,23 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     duo_flag_t *flags = duo_flags_at(smem + a.off_flag) + team * NFLAG;
     duo_flag_t *f_job = flags, *f_res = TEAM ? duo_flags_at(smem + a.off_flag) + CPB : flags + 1;
     duo_flag_t *f_mail = flags + 1 + RW, *f_ack = f_mail + 1, *f_ctl = f_mail + 2, *f_ov = f_mail + 3;
+    // TBAR: the chains of the workgroup that are still running.  A state wave whose chain is done (or does not exist)
+    // takes the word down and then keeps the others' barriers company until it reads 0 -- right behind "the jobs are
+    // in", where every wave looks at it (a wave that simply left, or waited at a later barrier, would be counted as
+    // arrived at the others' next one)
+    duo_flag_t *f_live = duo_flags_at(smem + a.off_flag) + 2 * CPB;
+    auto team_leave = [&](bool was_live) {
+        if constexpr (TBAR) {
+            if (was_live && lane == 0)
+                __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) int *>(const_cast<__attribute__((address_space(3))) int *>(f_live)), -1,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                team_barrier();
+                if (__builtin_amdgcn_readfirstlane(*f_live) == 0) break;
+                team_barrier();
+            }
+        }
+    };
     double *mbox = reinterpret_cast<double *>(smem + a.off_spec);     // BKW: 2 x MREC, then 2 x CREC
     double *ctrl = mbox + 2 * MREC;
     (void)f_mail; (void)f_ack; (void)f_ctl; (void)f_ov; (void)mbox; (void)ctrl;
@@ -292,11 +317,13 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             double *s1 = reinterpret_cast<double *>(smem + a.off_scr);
             for (int idx = tid; idx < CPB * a.scr_doubles; idx += blockDim.x) s1[idx] = 0.0;
         }
-        if (tid < (TEAM ? 2 * CPB : CPB * NFLAG)) reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] = 0;
+        if (tid < (TEAM ? 2 * CPB + 1 : CPB * NFLAG))
+            reinterpret_cast<volatile int *>(smem + a.off_flag)[tid] =
+                (TEAM && tid == 2 * CPB) ? (a.chains - cb * CPB < CPB ? a.chains - cb * CPB : CPB) : 0;
         if constexpr (BKW) { for (int idx = tid; idx < 2 * MREC; idx += blockDim.x) mbox[idx] = 0.0; }     // (entries beyond P stay 0)
     }
     __syncthreads();                                   // the only workgroup barrier of a piece
-    if (chain >= a.chains) return;
+    if (chain >= a.chains) { team_leave(false); return; }
 
     if constexpr (TEAM) {
         if (!is_state) {
@@ -362,7 +389,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #ifdef EPX_STAMPS
                 const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
 #endif
-                const int live = team_wait_jobs(f_job, pass, nch, lane);
+                int live;
+                if constexpr (TBAR) { team_barrier(); live = __builtin_amdgcn_readfirstlane(*f_live); }
+                else live = team_wait_jobs(f_job, pass, nch, lane);
 #ifdef EPX_STAMPS
                 {   // histogram of this wait: bins of 512 cycles, the last one open (fourth record of the stamps)
                     const unsigned long long dw_ = __builtin_amdgcn_s_memtime() - tw0_;
@@ -498,7 +527,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     for (int c = 0; c < KS; ++c) res[8 * (c >> 1) + 2 * hi + (c & 1)] = gacc[c];
                     if (hi == 0) { res[DP] = dz; res[DP + 1] = lz; }
                 }
-                duo_publish(f_res + wr, pass);
+                if constexpr (TBAR) team_barrier(); else duo_publish(f_res + wr, pass);
                 STAMP(6);
                 TSTAMP(6);
             }
@@ -823,6 +852,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 ck_store(ck_rec(t_end) + 4 * NV * 64 + lane, ckv);
                 piece_checkpoint_out();
                 *f_job = DUO_EXIT;
+                team_leave(true);
                 return;
             }
         }
@@ -929,7 +959,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     };
 
     auto rows_in = [&](int sq_) -> bool {               // the row waves' results of job sq_ are in
-        if constexpr (TEAM) return team_wait_rows(f_res, sq_, lane) == sq_;
+        if constexpr (TBAR) { team_barrier(); return true; }
+        else if constexpr (TEAM) return team_wait_rows(f_res, sq_, lane) == sq_;
         else {
             bool ok = true;
             for (int w = 0; w < RW; ++w) ok &= duo_wait(f_res + w, sq_) == sq_;
@@ -1033,7 +1064,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 FORV { const int e = lane + 64 * i; if (e < VN) slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
             }
             ++seq;
-            duo_publish(f_job, seq);
+            if constexpr (TBAR) team_barrier(); else duo_publish(f_job, seq);
             job_eps = eps_l;
             if (fast_ok) {
                 // (re)build the view of the position in flight from the vectors: start of the chain, or the
@@ -1188,7 +1219,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 if (v_lane) { slot[VOFF + ve1] = vq1 - vmu1; slot[VOFF + ve3] = vq3 - vmu3; }
             }
             ++seq;
-            duo_publish(f_job, seq);
+            if constexpr (TBAR) team_barrier(); else duo_publish(f_job, seq);
             job_eps = eps_l;
             fast_pub = true;
             if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
@@ -1361,6 +1392,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 
     // ------------------------------------------------------------- epilogue (the state wave owns the chain)
     if constexpr (!BKW) *f_job = DUO_EXIT;             // the row waves leave
+    team_leave(true);
     if (bail & 1) {
         if (lane == 0) atomicOr(a.err, 2);
         failed = 2;
@@ -1461,7 +1493,7 @@ size_t nuts_duo_lds_layout(NutsArgs &a, int cpb, int rw, int dp, int n_max) {
     a.slot_doubles = rw == 1 ? dp + 2 : (dp + 2) + vn + rw * (dp + 2) + vn;                         // as the kernel (VOFF, RESO, OVOFF)
     a.off_slot = (int)off; off += (size_t)cpb * a.slot_doubles * 8;
     const bool bkw = cpb == 1;                                                        // as the kernel (BKW)
-    a.off_flag = (int)off; off += teamm ? 32 : (size_t)cpb * (1 + rw + (bkw ? 4 : 0)) * 4;
+    a.off_flag = (int)off; off += teamm ? 48 : (size_t)cpb * (1 + rw + (bkw ? 4 : 0)) * 4;
     off = (off + 15) & ~(size_t)15;
     a.off_spec = 0;
     if (bkw) { a.off_spec = (int)off; off += (size_t)2 * ((4 * nv * 64 + 4) + (4 * nv * 64 + 4)) * 8; }
