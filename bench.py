@@ -334,6 +334,8 @@ def main():
     # how far that is from the average, last launch of this rank
     lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
     out['launch_ms_timed'] = [round(float(x), 1) for x in ms]
+    out['leapfrogs_per_transition_timed'] = [round(float(g) / (sites * args.chains * args.siter), 1) for g in ngrad]
+    out['gradients_all_launches'] = float(np.sum(M.ngrad_log))      # warm-up + timed: what a profiler pass over this command counts
     out['launch_tail'] = {'slowest_chain_leapfrogs': float(lf.max()), 'mean_chain_leapfrogs': float(lf.mean()),
                           'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(layout),
                           'lead_sites_of_a_split_launch': int(M.engine.last_split()),

@@ -6,7 +6,7 @@ Usage: python scripts/profile_summarise.py [round_tag]"""
 import glob, json, os, shutil, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'round')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 
 
 def dbs(d):
@@ -106,3 +106,38 @@ for name in ('c2', 'c3', 'stream'):
         open(os.path.join(ROOT, 'profiles', '%s_%s_bench.json' % (tag, name)), 'w').write(json.dumps(bench) + '\n')
     json.dump(summary, open(os.path.join(ROOT, 'profiles', '%s_%s_pmc_hbm.json' % (tag, name)), 'w'), indent=1)
     print(name, json.dumps({k: summary.get(k) for k in ('timed_launches', 'hbm_bytes_per_launch_corrected', 'bench_launch_ms', 'launch_ms_pmc_passes', 'algorithmic_bytes_per_launch')}))
+
+
+# ---- instruction mix of the C3 sampler (SQ counters over the driver's command), per leapfrog of a chain
+mix = {}
+for part in ('c3_mix_a', 'c3_mix_b'):
+    for db in dbs(part):
+        con, suf = kernel_rows(db)
+        if con is None:
+            continue
+        rows = con.execute("""select s.kernel_name, p.name, sum(e.value) from rocpd_pmc_event%s e
+                              join rocpd_info_pmc%s p on e.pmc_id = p.id
+                              join rocpd_kernel_dispatch%s d on e.event_id = d.event_id
+                              join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id
+                              where s.kernel_name like '%%k_nuts%%' group by s.kernel_name, p.name""" % (suf, suf, suf, suf)).fetchall()
+        for kname, cname, val in rows:
+            mix.setdefault(kname[:100], {})[cname] = val
+bench_path = os.path.join(ROOT, 'profiles', '%s_c3_bench.json' % tag)
+if mix and os.path.exists(bench_path):
+    bench = json.loads(open(bench_path).read())
+    # gradients of ALL launches of the command (warm-up + timed): the mix passes count every launch
+    logs = [open(os.path.join(SRC, 'c3_mix_a.log')).read() if os.path.exists(os.path.join(SRC, 'c3_mix_a.log')) else '']
+    out = {'command': 'rocprofv3 --pmc <SQ counters> --kernel-trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sites 0 (two passes)',
+           'kernels': mix,
+           'note': 'counter sums over ALL sampler launches of the command (5 warm-up + 20 timed); per chain-leapfrog figures need the '
+                   'gradient count of the same launches: bench.py reports the timed ones (gradients_per_launch x 20), the warm-up '
+                   'launches are lighter, so the ratios below use the timed share = timed duration / total duration of the trace'}
+    G = bench.get('gradients_all_launches')
+    if G:
+        out['gradients_of_all_launches'] = G
+        out['per_chain_leapfrog'] = {k: {c: v / G for c, v in m.items()} for k, m in mix.items()}
+        out['note'] = ('counter sums over ALL sampler launches of the command (5 warm-up + 20 timed) divided by the gradient '
+                       'evaluations of the same launches (bench.py: gradients_all_launches; the run is deterministic, so the '
+                       'profiled passes make the same ones)')
+    json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_c3_instruction_mix.json' % tag), 'w'), indent=1)
+    print('c3 instruction mix:', json.dumps({k: {c: '%.4g' % v for c, v in m.items()} for k, m in mix.items()}))
