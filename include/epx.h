@@ -63,9 +63,11 @@ typedef struct epx_sampler_opts {
                             (site, chain), 3 streaming (rows through an LDS-DMA ring, chains in lock step;
                             chosen automatically when the rows do not fit LDS or D > 32), 4 lock step with
                             the rows resident in LDS (D <= 32; default for multi-group sites), 5 one block per
-                            site with a state wave + a row wave per chain (the default for batches that fill
-                            the chip; same draws as 1), 6 one block per chain: state wave, two row waves and
-                            a bookkeeping wave) */
+                            site with a state wave + a row wave per chain (same draws as 1), 6 one block per
+                            chain: state wave, two row waves and a bookkeeping wave, 7 one block per site: a state
+                            wave per chain + four row waves that serve the site's four chains in lock step on the
+                            matrix pipe (v_mfma_f64_4x4x4; the default for batches that fill the chip since
+                            round 3; served by 5 when its padded rows do not fit the LDS) */
     int32_t reserved;    /* flags; bit 0: layout 2 without the speculative bookkeeping wave (same draws,
                             used for A/B measurements and tests);
                             bit 1: `adapt = carry` -- NOT the reference's behaviour (a fresh model.sampling per site
@@ -318,7 +320,7 @@ int epx_set_site_order(epx_ctx *ctx, const int32_t *order, int count);
  * No reference counterpart. */
 int epx_set_site_split(epx_ctx *ctx, int n_lead);
 int epx_last_split(epx_ctx *ctx);
-/* Pieced launch of the resident sampler (layout 5): with a piece queue set, a sampling call over ALL sites runs one
+/* Pieced launch of the samplers that keep one workgroup per site (layouts 5, 7 and 3): with a piece queue set, a sampling call over ALL sites runs one
  * workgroup per PIECE (piece_len transitions of one site); a workgroup claims the site with the largest predicted
  * remaining work (transitions left x rate[site], rate = predicted leapfrogs per transition, NULL = all equal) that
  * nobody holds, runs its next piece, leaves a checkpoint at the transition boundary and puts the site back -- longest
@@ -331,7 +333,7 @@ int epx_last_segments(epx_ctx *ctx);
 /* Compute units of the context's device (the host-side scheduling heuristics size themselves by it). */
 int epx_cu_count(epx_ctx *ctx);
 
-/* Thread layout the last sampling call ran with (1, 2 or 3, see epx_sampler_opts.layout; 0 before
+/* Thread layout the last sampling call ran with (1 ... 7, see epx_sampler_opts.layout; 0 before
  * the first call).  Measurement aid: layout 3 streams the rows from HBM once per leapfrog, so its
  * roofline is the HBM one (bench.py).  No reference counterpart. */
 int epx_last_layout(epx_ctx *ctx);

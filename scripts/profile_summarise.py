@@ -7,6 +7,8 @@ import glob, json, os, shutil, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'round')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+PROF = os.environ.get('PROFILES_OUT', os.path.join(ROOT, 'profiles'))     # (on the GPU box: a directory under gpurun_out/, which is what travels back)
+os.makedirs(PROF, exist_ok=True)
 
 
 def dbs(d):
@@ -60,11 +62,11 @@ for name in ('c2', 'c3', 'stream'):
         continue
     line = [l for l in open(os.path.join(SRC, name + '_bench.json')) if l.startswith('{')]
     if line:
-        open(os.path.join(ROOT, 'profiles', '%s_%s_bench.json' % (tag, name)), 'w').write(line[-1])
+        open(os.path.join(PROF, '%s_%s_bench.json' % (tag, name)), 'w').write(line[-1])
     for db in dbs(name + '_trace'):
         if kernel_rows(db)[0] is not None:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
-                                   os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.csv' % (tag, name))])
+                                   os.path.join(PROF, '%s_%s_kernel_stats.csv' % (tag, name))])
     warmup, key = {'c2': (1, [64, 16, 200, 'm4b', 4, 200]), 'c3': (5, [512, 32, 500, 'm4b', 4, 200]),
                    'stream': (2, [512, 128, 2000, 'm4b', 4, 200])}[name]
     f, f_it, f_ms = pmc_sums(name + '_fetch', warmup)
@@ -73,7 +75,7 @@ for name in ('c2', 'c3', 'stream'):
         for db in dbs(name + '_' + kind):
             if kernel_rows(db)[0] is not None:
                 subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
-                                       os.path.join(ROOT, 'profiles', '%s_%s_pmc_%s_size.csv' % (tag, name, kind))])
+                                       os.path.join(PROF, '%s_%s_pmc_%s_size.csv' % (tag, name, kind))])
     bench = json.loads(line[-1]) if line else {}
     mean = lambda v: sum(v) / len(v) if v else None
     fk, wk = mean(f_it), mean(w_it)
@@ -103,8 +105,8 @@ for name in ('c2', 'c3', 'stream'):
         # the bench line was printed before these passes ran: its traffic field is (re)filled from them
         roof['traffic'] = summary['hbm_bytes_per_launch_corrected']
         roof['traffic_source'] = 'profiles/%s_%s_pmc_hbm.json (this capture)' % (tag, name)
-        open(os.path.join(ROOT, 'profiles', '%s_%s_bench.json' % (tag, name)), 'w').write(json.dumps(bench) + '\n')
-    json.dump(summary, open(os.path.join(ROOT, 'profiles', '%s_%s_pmc_hbm.json' % (tag, name)), 'w'), indent=1)
+        open(os.path.join(PROF, '%s_%s_bench.json' % (tag, name)), 'w').write(json.dumps(bench) + '\n')
+    json.dump(summary, open(os.path.join(PROF, '%s_%s_pmc_hbm.json' % (tag, name)), 'w'), indent=1)
     print(name, json.dumps({k: summary.get(k) for k in ('timed_launches', 'hbm_bytes_per_launch_corrected', 'bench_launch_ms', 'launch_ms_pmc_passes', 'algorithmic_bytes_per_launch')}))
 
 
@@ -122,7 +124,7 @@ for part in ('c3_mix_a', 'c3_mix_b'):
                               where s.kernel_name like '%%k_nuts%%' group by s.kernel_name, p.name""" % (suf, suf, suf, suf)).fetchall()
         for kname, cname, val in rows:
             mix.setdefault(kname[:100], {})[cname] = val
-bench_path = os.path.join(ROOT, 'profiles', '%s_c3_bench.json' % tag)
+bench_path = os.path.join(PROF, '%s_c3_bench.json' % tag)
 if mix and os.path.exists(bench_path):
     bench = json.loads(open(bench_path).read())
     # gradients of ALL launches of the command (warm-up + timed): the mix passes count every launch
@@ -139,5 +141,5 @@ if mix and os.path.exists(bench_path):
         out['note'] = ('counter sums over ALL sampler launches of the command (5 warm-up + 20 timed) divided by the gradient '
                        'evaluations of the same launches (bench.py: gradients_all_launches; the run is deterministic, so the '
                        'profiled passes make the same ones)')
-    json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_c3_instruction_mix.json' % tag), 'w'), indent=1)
+    json.dump(out, open(os.path.join(PROF, '%s_c3_instruction_mix.json' % tag), 'w'), indent=1)
     print('c3 instruction mix:', json.dumps({k: {c: '%.4g' % v for c, v in m.items()} for k, m in mix.items()}))
