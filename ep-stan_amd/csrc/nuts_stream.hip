@@ -557,6 +557,9 @@ k_nuts_stream(NutsArgs a) {
         unsigned long long *tl = a.stamps + ((size_t)gridDim.x + blockIdx.x) * 8;
         tl[0] = tl_entry; tl[1] = tl_claim; tl[2] = __builtin_amdgcn_s_memrealtime();
         tl[3] = (unsigned long long)sb; tl[4] = (unsigned long long)t_begin; tl[5] = (unsigned long long)ngrad;
+        // which CU ran it: HW_ID (wave / simd / pipe / cu / sh / se fields) and XCC_ID, as the hardware registers read
+        tl[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        tl[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
     }
 #endif
     // ------------------------------------------------------------- epilogue

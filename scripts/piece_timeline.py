@@ -63,6 +63,22 @@ res['unfinished_sites_over_the_span_200_bins'] = [int(np.sum(site_end > t)) for 
 blk = np.nonzero(ok)[0]
 res['pieces_in_flight_by_block_mod_8_at_25_50_75_90_percent'] = [
     [int(np.sum((claim <= t) & (end > t) & (blk % 8 == x))) for x in range(8)] for t in (0.25 * span, 0.5 * span, 0.75 * span, 0.9 * span)]
+# per physical CU (HW_ID: cu_id bits 11:8, sh_id bit 12, se_id bits 15:13; XCC_ID bits 3:0): the gaps between the end of
+# one piece and the claim of the next one on the same CU
+hw = tl[:, 6].astype(np.int64); xcc = tl[:, 7].astype(np.int64) & 0xF
+cu_key = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)
+gaps = []
+per_cu_busy = []
+for key in np.unique(cu_key):
+    idx = np.nonzero(cu_key == key)[0]
+    o = idx[np.argsort(claim[idx])]
+    gaps.extend(list(claim[o][1:] - end[o][:-1]))
+    per_cu_busy.append(float((end[o] - claim[o]).sum()))
+gaps = np.array(gaps)
+res['physical_cus_seen'] = int(len(np.unique(cu_key)))
+res['gap_between_pieces_on_a_cu_ms'] = {'mean': float(gaps.mean() / 1e3), 'median': float(np.median(gaps) / 1e3), 'p90': float(np.percentile(gaps, 90) / 1e3),
+                                        'max': float(gaps.max() / 1e3), 'sum_over_cus_ms_per_cu': float(gaps.sum() / 1e3 / max(len(per_cu_busy), 1))}
+res['busy_ms_per_physical_cu'] = {'min': float(np.min(per_cu_busy) / 1e3), 'median': float(np.median(per_cu_busy) / 1e3), 'max': float(np.max(per_cu_busy) / 1e3)}
 # the tail: time after the last moment every CU was busy
 last_full = edges[np.nonzero(full)[0].max()] if full.any() else 0.0
 res['tail_ms_after_the_last_full_moment'] = (span - last_full) / 1e3
