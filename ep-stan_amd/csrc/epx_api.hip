@@ -695,7 +695,11 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         HIPCHK(hipMemcpyAsync(c->dyn_lens_d, lens_h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));            // (lens_h is a local)
         a.dyn_lens = c->dyn_lens_d; a.dyn_nb = nb_site;
-        a.seg_nwg = (int)total_pieces;                      // one workgroup per piece
+        a.seg_nwg = (int)total_pieces;                      // at most one workgroup per piece ...
+        a.persist = getenv("EPX_PIECE_GRID") ? 0 : 1;       // ... looping ones, as many as the device holds (the launcher cuts seg_nwg down); EPX_PIECE_GRID: the first form, for A/B
+#ifdef EPX_STAMPS
+        if (!getenv("EPX_PIECE_LOOP")) a.persist = 0;       // (the diagnostic build's records are per workgroup: one piece each unless asked otherwise)
+#endif
         a.stack = c->stack;                                  // (tree stack + cold store: one region per piece, sized above)
         a.ckpt = c->ckpt;                                    // (one record per piece boundary of a site)
         a.order = nullptr;

@@ -166,6 +166,7 @@ struct NutsArgs {
     int *err;                     // device word: set when a hand-off spin gives up (never in a healthy run)
     // pieced launch (layout 5; epx_set_piece_queue): seg_nwg workgroups, one per piece
     int seg_nwg;
+    int persist;                          // workgroups loop over claims (seg_nwg = what the device holds at a time) instead of one per piece
     double *ckpt;                 // pieced launches: per (site, chain) a record of (4 NV + 1) x 64 doubles (sample, Welford sums, metric, scalars)
     // piece queue (epx_set_piece_queue): every workgroup claims a site by largest remaining predicted work and runs
     // dyn_len transitions of it; dyn_prog[site] = 2 x transitions done + (claimed): one word, changed atomically

@@ -1,13 +1,17 @@
 // Pieced sampler launches (epx_set_piece_queue): what the resident (nuts_duo.hip) and the streaming
 // (nuts_stream.hip) kernels share -- the claim of a site, its release, and the checkpoint record's accessors.
 //
-// The launch has one workgroup per PIECE (dyn_len transitions of one site); the hardware's dispatcher is the loop.
+// The launch has as many workgroups as the device holds at a time (NutsArgs::persist; at most one per piece), and a
+// workgroup LOOPS over claims until no site has anything left.  (The first form had one workgroup per piece, "the
+// hardware's dispatcher is the loop": workgroups are dealt to the 8 XCDs by blockIdx % 8 and IN ORDER, so when the next
+// one's XCD has no CU free the free CUs of the other XCDs wait -- with pieces of unequal length 16-21 % of the CU-time,
+// 3 % for looping workgroups: scripts/probe/dispatch_gaps.hip, profiles/r03_dispatch_gaps_probe.txt.)
 // A workgroup claims -- compare-and-swap on the site's `busy` word -- the site with the largest predicted REMAINING
 // work (transitions left x predicted leapfrogs per transition) among the sites nobody holds, runs its next piece from
 // the checkpoint the piece before left, writes its own checkpoint, puts the site back and ends: longest remaining
 // processing time first, the preemptive schedule that ends all sites at about the same time, and it adapts to what
-// the sites really cost.  There are exactly as many workgroups as pieces, so a workgroup that finds every unfinished
-// site held waits for one to come back; the holders never wait.
+// the sites really cost.  A workgroup that finds every unfinished site held waits for one to come back; the holders
+// never wait, and every workgroup of the launch is resident, so nobody waits for a workgroup that has not started.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -54,10 +58,11 @@ __device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundar
 }
 
 // Claim a site (all threads of the workgroup; the LDS must not hold anything yet: smem[0..1100) is scratch, and
-// (site, first transition) stay at smem + off_piece for piece_release).  Returns false after EPX_PIECE_WAIT_S seconds without
-// one (never seen; the caller reports it and the host call fails with an error).
+// (site, first transition) stay at smem + off_piece for piece_release).  Returns 1 with a site, 0 when every site of the
+// launch has run all its transitions (a persistent workgroup's way out), -1 after EPX_PIECE_WAIT_S seconds without a site
+// (never seen; the caller reports it and the host call fails with an error).
 template <class Args>
-__device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int tid, int &q_site, int &q_t0) {
+__device__ __forceinline__ int piece_claim(Args &a, unsigned char *smem, int tid, int &q_site, int &q_t0) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     volatile double *sc = reinterpret_cast<volatile double *>(smem);
     volatile int *si = reinterpret_cast<volatile int *>(smem + 1024);
@@ -66,11 +71,12 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
     // seconds, so a workgroup that has found nothing for EPX_PIECE_WAIT_S seconds reports a lost piece instead of spinning on)
     const unsigned long long t_claim0 = __builtin_amdgcn_s_memrealtime();
     for (int attempt = 0; q_site < 0; ++attempt) {
-        double best = -1.0; int arg = -1;
+        double best = -1.0; int arg = -1, unfinished = 0;
         for (int s = tid; s < a.dyn_count; s += blockDim.x) {
             // ONE word per site: 2 x (transitions done) + (held): progress and claim change together, atomically
             const int wd = __hip_atomic_load(a.dyn_prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int pr = wd >> 1, bz = wd & 1;
+            unfinished |= pr < a.iter;
             if (bz == 0 && pr < a.iter) {
                 // (a +-12 % jitter per (workgroup, site, attempt): 256 workgroups that all went for THE largest
                 // remaining site would get it one at a time)
@@ -85,12 +91,13 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
             const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
             if (ob > best || (ob == best && oa >= 0 && (arg < 0 || oa < arg))) { best = ob; arg = oa; }
         }
-        if (lane == 0) { sc[wave] = best; si[wave] = arg; }
+        const int unf_w = __builtin_amdgcn_ballot_w64(unfinished != 0) != 0;
+        if (lane == 0) { sc[wave] = best; si[wave] = arg; si[16 + wave] = unf_w; }
         __syncthreads();
         if (tid == 0) {
-            double b = -1.0; int g = -1;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) if (sc[w] > b) { b = sc[w]; g = si[w]; }
-            int got = -2;                                  // -2: every unfinished site is held right now
+            double b = -1.0; int g = -1, unf = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { unf |= si[16 + w]; if (sc[w] > b) { b = sc[w]; g = si[w]; } }
+            int got = unf ? -2 : -4;                       // -2: every unfinished site is held right now; -4: no site has anything left
             int t0_got = 0;
             if (g >= 0) {
                 int expect = __hip_atomic_load(a.dyn_prog + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -113,7 +120,7 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
         const int got = __builtin_amdgcn_readfirstlane(si[32]);         // (wave-uniform for the compiler, too)
         if (got >= 0) { q_site = got; q_t0 = __builtin_amdgcn_readfirstlane(si[33]); }
         __syncthreads();
-        if (got == -3) break;
+        if (got == -3 || got == -4) { q_site = got; break; }
         if (got == -2) {
             // every unfinished site is held: a piece takes tens of milliseconds, so look again in ~0.2 ms (hundreds of
             // waiting workgroups polling the site words at full speed would be felt by the pieces that still run)
@@ -122,7 +129,7 @@ __device__ __forceinline__ bool piece_claim(Args &a, unsigned char *smem, int ti
     }
     // acquire at agent scope: this XCD's L2 may hold an older record of the site (from a piece that ran here earlier)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return q_site >= 0;
+    return q_site >= 0 ? 1 : (q_site == -4 ? 0 : -1);
 }
 
 // After a chain's checkpoint stores (every wave that wrote one): out of this XCD's L2 before anybody is told

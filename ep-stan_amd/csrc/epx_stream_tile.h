@@ -58,15 +58,23 @@ template <int DPB> struct StreamGeom {
 // LDS-DMA pieces as inline asm: hipcc does not count them, so it inserts no vmcnt(0) before the
 // LDS reads of the ring (it does for the builtin); completion is counted by hand (wait_vm).
 // M0 = wave-uniform LDS destination, written in the statement that uses it.
+// (the destination is made scalar behind an opaque vector copy: inside a called function -- the looping form of the pieced
+// launch -- the compiler folded __builtin_amdgcn_readfirstlane of a value it knows to be uniform and then handed the
+// inline assembly a VECTOR register for its "s" operand.  A v_readfirstlane_b32 written as inline assembly compiled and
+// faulted on the device)
+__device__ inline unsigned scalar_of(unsigned x) {
+    asm volatile("" : "+v"(x));                   // (opaque: a vector value the compiler knows nothing about)
+    return __builtin_amdgcn_readfirstlane(x);
+}
 __device__ inline void glds16(const void *src, unsigned lds_off) {
     unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_off);
+    const unsigned dst = scalar_of(lds_off);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 __device__ inline void glds4(const void *src, unsigned lds_off) {
     unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_off);
+    const unsigned dst = scalar_of(lds_off);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
@@ -181,7 +189,7 @@ __device__ inline void loader_init(PassArgs<DPB> &pa, int lane) {
 template <int DPB>
 __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, int tt, int slot, int lane) {
     using Gm = StreamGeom<DPB>;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(s.lds0 + M.ring + slot * Gm::SLOTB);
+    const unsigned dst = scalar_of(s.lds0 + M.ring + slot * Gm::SLOTB);
     const int row0 = __builtin_amdgcn_readfirstlane(*lds_i(s.lds0 + M.tdesc + tt * 8));
     const int nval = __builtin_amdgcn_readfirstlane(*lds_i(s.lds0 + M.tdesc + tt * 8 + 4)) & 255;
     if (nval == TR) {

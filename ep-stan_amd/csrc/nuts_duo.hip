@@ -1460,13 +1460,12 @@ k_nuts_duo(NutsArgs a_by_value) {
     // predicted REMAINING work (transitions left x predicted leapfrogs per transition) among the sites nobody holds,
     // runs dyn_len transitions of it, puts it back and ends -- longest remaining processing time first, the
     // preemptive schedule that ends all sites at about the same time, and it adapts to what the sites really cost.
-    // (A loop over pieces INSIDE the kernel does the same with 256 persistent workgroups, and costs the body its
-    // register allocation: everything is then live around a loop that contains both roles' inner loops, 68 -> 500 B
-    // of scratch per lane and 20 % of the time.  So there is no loop.)
-    // A claim is a compare-and-swap on the site's `busy` word.  There are exactly as many workgroups as pieces, so a
+    // This is the form WITHOUT a loop over pieces (NutsArgs::persist == 0; diagnostic builds and A/B): k_nuts_duo_loop
+    // below is what a pieced launch runs by default.
+    // A claim is a compare-and-swap on the site's word.  There are exactly as many workgroups as pieces, so a
     // workgroup that finds every unfinished site held waits for one to come back; the holders never wait.
     int q_site, q_t0;
-    if (!piece_claim(a, smem, tid, q_site, q_t0)) {                // (no site for EPX_PIECE_WAIT_S seconds: reported, never seen)
+    if (piece_claim(a, smem, tid, q_site, q_t0) <= 0) {            // (no site for EPX_PIECE_WAIT_S seconds: reported, never seen)
         if (tid == 0) atomicOr(a.err, 4);
         return;
     }
@@ -1476,6 +1475,43 @@ k_nuts_duo(NutsArgs a_by_value) {
 }
 
 #undef a
+
+// The pieced launch with LOOPING workgroups (NutsArgs::persist, the default): as many workgroups as the device holds at
+// a time, each claiming pieces until no site has anything left.  One workgroup per piece leaves CU-time to the in-order
+// dispatcher (epx_pieces.h; scripts/probe/dispatch_gaps.hip): on one box 527.5 -> 534.0 site-updates/s at C3, whose
+// pieces last about equally long, and 15.0 -> 15.8 at the C5 shard (nuts_stream.hip), whose pieces do not.
+// The piece's body is a real CALL.  Inlined into the loop (round 2) it lost its register allocation: everything is then
+// live around a loop that contains both roles' inner loops, 68 -> 500 B of scratch per lane and 20 % of the time.  As a
+// function it is compiled like the kernel without the loop -- provided its arguments are made scalar again: arguments of
+// a call travel in vector registers and count as divergent, so a pointer to the kernel arguments passed as it is turns
+// every a.field into a vector load (876 B of scratch, 13 % slower), and __builtin_amdgcn_kernarg_segment_ptr() is null
+// inside a called function.
+template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
+__device__ __attribute__((noinline)) void duo_piece_call(unsigned long long kargs_u, int q_site, int q_t0) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kargs_u), hi = __builtin_amdgcn_readfirstlane((unsigned)(kargs_u >> 32));
+    DuoArgsK *kargs_p = (DuoArgsK *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    duo_piece<NV, DP, CPB, RW, STL, COLD, true>(kargs_p, (int)threadIdx.x, true, __builtin_amdgcn_readfirstlane(q_site), __builtin_amdgcn_readfirstlane(q_t0));
+}
+
+template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
+__global__ void __launch_bounds__(64 * (CPB == 4 && RW == 4 ? 8 : CPB * (1 + RW) + (CPB == 1 ? 2 : 0)))
+k_nuts_duo_loop(NutsArgs a_by_value) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    (void)a_by_value;
+    DuoArgsK *kargs_p = (DuoArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    for (;;) {
+        int q_site, q_t0;
+        const int got = piece_claim(*kargs_p, smem, (int)threadIdx.x, q_site, q_t0);
+        if (got <= 0) {
+            if (got < 0 && threadIdx.x == 0) atomicOr(kargs_p->err, 4);
+            return;
+        }
+        duo_piece_call<NV, DP, CPB, RW, STL, COLD>((unsigned long long)(uintptr_t)kargs_p, q_site, q_t0);
+        __syncthreads();
+        if (threadIdx.x == 0) piece_release(*kargs_p, smem);
+        __syncthreads();                                 // (the next claim's scratch is the LDS this piece used)
+    }
+}
 
 // ---------------------------------------------------------------------------
 // host side: LDS layout + dispatch over the instantiated shapes
@@ -1530,10 +1566,32 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (CPB == 4 && RW == 4 ? 8 : CPB * (1 + RW) + (CPB == 1 ? 2 : 0))), a.lds_bytes, stream, a);
+        constexpr int NT = 64 * (CPB == 4 && RW == 4 ? 8 : CPB * (1 + RW) + (CPB == 1 ? 2 : 0));
+        const int nb = nblocks;
+        (void)NT;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(NT), a.lds_bytes, stream, a);
         return (int)hipGetLastError();
     };
     constexpr bool COLD = NV >= 2 || CPB > 1;
+    if constexpr (COLD && CPB > 1) {
+        if (a.dyn_prog && a.persist) {
+            // looping workgroups: as many as the device holds at a time (never more than there are pieces)
+            auto loop = [&](auto kern) -> int {
+                constexpr int NT = 64 * (CPB == 4 && RW == 4 ? 8 : CPB * (1 + RW));
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes);
+                if (e != hipSuccess) return (int)e;
+                int per_cu = 0, dev = 0, ncu = 0;
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), NT, (size_t)a.lds_bytes);
+                if (e != hipSuccess) return (int)e;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                const int hold = (per_cu > 0 ? per_cu : 1) * (ncu > 0 ? ncu : 1);
+                hipLaunchKernelGGL(kern, dim3(nblocks < hold ? nblocks : hold), dim3(NT), a.lds_bytes, stream, a);
+                return (int)hipGetLastError();
+            };
+            return a.stack_in_lds ? loop(k_nuts_duo_loop<NV, DP, CPB, RW, true, COLD>) : loop(k_nuts_duo_loop<NV, DP, CPB, RW, false, COLD>);
+        }
+    }
     if constexpr (COLD && CPB > 1) {
         if (a.dyn_prog)
             return a.stack_in_lds ? go(k_nuts_duo<NV, DP, CPB, RW, true, COLD, true>) : go(k_nuts_duo<NV, DP, CPB, RW, false, COLD, true>);

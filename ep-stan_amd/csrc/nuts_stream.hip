@@ -65,26 +65,16 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 
 constexpr int OM_UNROLL = 16;   // columns of Omega in flight per thread
 
+typedef const __attribute__((address_space(4))) NutsArgs StreamArgsK;    // the kernel arguments where they are: kernarg segment
+
+// One piece of a site's run on the streaming layout: transitions [q_t0, q_t0 + piece length) of site q_site by the waves of
+// one workgroup (PIECED), or the whole run of the site blockIdx.x names.
 // RES: the resident variant (rows in LDS for the whole site update, 4 chain waves only, D <= 32)
-// PIECED: the launch has one workgroup per piece of a site's transitions (epx_pieces.h); a template parameter so that
-// the plain kernel stays what it was
 template <int NV, int DPB, bool RES, bool PIECED>
-__global__ void __launch_bounds__(RES ? 256 : STREAM_THREADS)
-k_nuts_stream(NutsArgs a) {
+__device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, int q_t0, unsigned long long tl_entry, unsigned long long tl_claim) {
     extern __shared__ __align__(16) unsigned char smem[];
-    int q_site = -1, q_t0 = 0;
-#ifdef EPX_STAMPS
-    const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();       // (100 MHz, the same clock on every CU)
-#endif
-    if constexpr (PIECED) {
-        if (!piece_claim(a, smem, (int)threadIdx.x, q_site, q_t0)) {
-            if (threadIdx.x == 0) atomicOr(a.err, 4);
-            return;
-        }
-    }
-#ifdef EPX_STAMPS
-    const unsigned long long tl_claim = __builtin_amdgcn_s_memrealtime();
-#endif
+    StreamArgsK &a = *kargs_p;
+    (void)tl_entry; (void)tl_claim;
     const bool queued = PIECED;
     const int t_begin = queued ? q_t0 : 0;
     const int q_len = queued ? piece_len_of(a, q_site) : 0;
@@ -551,10 +541,13 @@ k_nuts_stream(NutsArgs a) {
 
 #ifdef EPX_STAMPS
     if (a.stamps && wave == 0 && lane0 == 0) {
-        for (int i = 0; i < 7; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
-        a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)ngrad;
+        // (looping workgroups: a record per piece, numbered by a counter behind the records)
+        const size_t nrec = PIECED ? (size_t)a.seg_nwg : (size_t)gridDim.x;
+        const size_t rec = (PIECED && a.persist) ? (size_t)atomicAdd(a.stamps + 3 * nrec * 8 + 15, 1ull) : (size_t)blockIdx.x;
+        for (int i = 0; i < 7; ++i) a.stamps[rec * 8 + i] = tacc[i];
+        a.stamps[rec * 8 + 7] = (unsigned long long)ngrad;
         // second record: the piece's timeline (entry, claim, end of sampling; site, first transition, leapfrogs)
-        unsigned long long *tl = a.stamps + ((size_t)gridDim.x + blockIdx.x) * 8;
+        unsigned long long *tl = a.stamps + (nrec + rec) * 8;
         tl[0] = tl_entry; tl[1] = tl_claim; tl[2] = __builtin_amdgcn_s_memrealtime();
         tl[3] = (unsigned long long)sb; tl[4] = (unsigned long long)t_begin; tl[5] = (unsigned long long)ngrad;
         // which CU ran it: HW_ID (wave / simd / pipe / cu / sh / se fields) and XCC_ID, as the hardware registers read
@@ -607,6 +600,66 @@ k_nuts_stream(NutsArgs a) {
     }
 }
 
+#ifdef EPX_STAMPS
+#define EPX_TL_NOW() __builtin_amdgcn_s_memrealtime()       /* (100 MHz, the same clock on every CU) */
+#else
+#define EPX_TL_NOW() 0ull
+#endif
+
+// PIECED: the launch has one workgroup per piece of a site's transitions (epx_pieces.h); a template parameter so that
+// the plain kernel stays what it was
+template <int NV, int DPB, bool RES, bool PIECED>
+__global__ void __launch_bounds__(RES ? 256 : STREAM_THREADS)
+k_nuts_stream(NutsArgs a_by_value) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    (void)a_by_value;
+    StreamArgsK *kargs_p = (StreamArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    int q_site = -1, q_t0 = 0;
+    const unsigned long long tl_entry = EPX_TL_NOW();
+    if constexpr (PIECED) {
+        if (piece_claim(*kargs_p, smem, (int)threadIdx.x, q_site, q_t0) <= 0) {
+            if (threadIdx.x == 0) atomicOr(kargs_p->err, 4);
+            return;
+        }
+    }
+    stream_piece<NV, DPB, RES, PIECED>(kargs_p, q_site, q_t0, tl_entry, EPX_TL_NOW());
+}
+
+// The pieced launch with LOOPING workgroups (NutsArgs::persist): as many workgroups as the device holds at a time, each
+// claiming pieces until no site has anything left.  With one workgroup per piece the in-order dispatcher (workgroup i goes
+// to XCD i % 8, and the next one waits for a CU of ITS XCD while CUs of the others are free) left ~10 % of the CU-time
+// of a C5-shard launch unused (profiles/r03_stream_piece_timeline.json; scripts/probe/dispatch_gaps.hip shows the effect
+// with no sampler in it): 15.0 -> 15.8 site-updates/s on one box.  The piece's body is a real call: inlined into the loop
+// it would be compiled with everything live around it.
+template <int NV, int DPB>
+__device__ __attribute__((noinline)) void stream_piece_call(unsigned long long kargs_u, int q_site, int q_t0, unsigned long long tl_entry, unsigned long long tl_claim) {
+    // (arguments of a call travel in VECTOR registers and count as divergent: the pointer to the kernel arguments is made
+    // scalar again -- through a vector pointer every a.field would be a vector load -- and so is the site.
+    // __builtin_amdgcn_kernarg_segment_ptr() is null inside a called function)
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kargs_u), hi = __builtin_amdgcn_readfirstlane((unsigned)(kargs_u >> 32));
+    StreamArgsK *kargs_p = (StreamArgsK *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    stream_piece<NV, DPB, false, true>(kargs_p, __builtin_amdgcn_readfirstlane(q_site), __builtin_amdgcn_readfirstlane(q_t0), tl_entry, tl_claim);
+}
+
+template <int NV, int DPB>
+__global__ void __launch_bounds__(STREAM_THREADS)
+k_nuts_stream_loop(NutsArgs a_by_value) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    (void)a_by_value;
+    StreamArgsK *kargs_p = (StreamArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    for (;;) {
+        int q_site = -1, q_t0 = 0;
+        const unsigned long long tl_entry = EPX_TL_NOW();
+        const int got = piece_claim(*kargs_p, smem, (int)threadIdx.x, q_site, q_t0);
+        if (got <= 0) {
+            if (got < 0 && threadIdx.x == 0) atomicOr(kargs_p->err, 4);
+            return;
+        }
+        stream_piece_call<NV, DPB>((unsigned long long)(uintptr_t)kargs_p, q_site, q_t0, tl_entry, EPX_TL_NOW());
+        __syncthreads();                                 // (the next claim's scratch is the LDS this piece used)
+    }
+}
+
 // LDS bytes of the streaming kernel
 size_t nuts_stream_lds_bytes(int nv, int dpb, int d, int ngmax, int ntmax, int nmax_res, int gauss) {
     const size_t pmax = 64 * (size_t)nv;
@@ -627,7 +680,24 @@ size_t nuts_stream_chain_doubles(int nv, int max_depth) {
 template <int NV, int DPB, bool RES>
 static int launch_stream_one(const NutsArgs &a, int nblocks, size_t lds, hipStream_t stream) {
     auto kern = k_nuts_stream<NV, DPB, RES, false>;
-    if constexpr (!RES) { if (a.dyn_prog) { kern = k_nuts_stream<NV, DPB, RES, true>; nblocks = a.seg_nwg; } }
+    if constexpr (!RES) {
+        if (a.dyn_prog) {
+            kern = k_nuts_stream<NV, DPB, RES, true>; nblocks = a.seg_nwg;
+            if (a.persist) {
+                // looping workgroups: as many as the device holds at a time (never more than there are pieces)
+                kern = k_nuts_stream_loop<NV, DPB>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+                int per_cu = 0, dev = 0, ncu = 0;
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), STREAM_THREADS, lds);
+                if (e != hipSuccess) return (int)e;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                const int hold = (per_cu > 0 ? per_cu : 1) * (ncu > 0 ? ncu : 1);
+                if (nblocks > hold) nblocks = hold;
+            }
+        }
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
