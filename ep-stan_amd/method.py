@@ -665,7 +665,7 @@ class Master(object):
         rest = rest[np.argsort(-np.asarray(passes)[rest], kind='stable')]
         return np.concatenate((lead, rest)).astype(np.int32), int(lead.size)
 
-    PIECES_PER_SITE = 16
+    PIECES_PER_SITE = int(os.environ.get('EPX_PIECES_PER_SITE', '16'))     # (the environment variable: A/B runs only)
 
     def _one_workgroup_per_cu(self):
         """The resident sampler keeps a site's rows (padded to 16 / 32 columns) in LDS: above half of the 160 KB

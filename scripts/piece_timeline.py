@@ -40,6 +40,7 @@ act = np.array([np.sum((claim <= t) & (end > t)) for t in edges])
 full = act >= 0.98 * min(ncu, act.max())
 res = {
     'workload': 'C5 shard: %d sites, D = %d, n_j = %d, EP iteration %d (pieced launch of k_nuts_stream, layout %d)' % (J, D, n, nit, eng.last_layout()),
+    'form': 'one workgroup per piece' if os.environ.get('EPX_PIECE_GRID') or not os.environ.get('EPX_PIECE_LOOP') else 'looping workgroups',
     'launch_ms_by_events': float(M.sampling_ms[-1]), 'span_ms_by_piece_stamps': span / 1e3, 'pieces': int(len(tl)), 'cus': int(ncu),
     'sum_of_piece_sampling_ms_over_cus': busy / 1e3 / ncu, 'sum_of_claim_waits_ms_over_cus': wait / 1e3 / ncu,
     'share_of_the_span_with_every_cu_sampling': float(full.mean()),
@@ -60,9 +61,9 @@ sites = tl[:, 3].astype(int)
 site_end = np.zeros(J)
 np.maximum.at(site_end, sites, end)
 res['unfinished_sites_over_the_span_200_bins'] = [int(np.sum(site_end > t)) for t in edges]
-blk = np.nonzero(ok)[0]
-res['pieces_in_flight_by_block_mod_8_at_25_50_75_90_percent'] = [
-    [int(np.sum((claim <= t) & (end > t) & (blk % 8 == x))) for x in range(8)] for t in (0.25 * span, 0.5 * span, 0.75 * span, 0.9 * span)]
+xcc_of = tl[:, 7].astype(np.int64) & 0xF              # (the XCD a piece ran on: blockIdx % 8 with one workgroup per piece)
+res['pieces_in_flight_by_xcd_at_25_50_75_90_percent'] = [
+    [int(np.sum((claim <= t) & (end > t) & (xcc_of == x))) for x in range(8)] for t in (0.25 * span, 0.5 * span, 0.75 * span, 0.9 * span)]
 # per physical CU (HW_ID: cu_id bits 11:8, sh_id bit 12, se_id bits 15:13; XCC_ID bits 3:0): the gaps between the end of
 # one piece and the claim of the next one on the same CU
 hw = tl[:, 6].astype(np.int64); xcc = tl[:, 7].astype(np.int64) & 0xF

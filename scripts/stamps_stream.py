@@ -22,7 +22,8 @@ lib = _lib.load()
 buf = np.zeros((4096, 8), dtype=np.uint64)
 lib.epx_dbg_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 nb = lib.epx_dbg_get_stamps(eng.ctx, buf.ctypes.data, 4096)
-st = buf[:nb].astype(np.float64)
+st = buf[:min(nb, K)].astype(np.float64)        # (first record of every workgroup: the chain wave's shares)
+st = st[st[:, 7] > 0]
 per = st[:, :7] / st[:, 7:8]
 med = np.median(per, axis=0)
 tot_ticks = st[:, 7].max()
