@@ -665,10 +665,17 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         }
     }
     if (use_queue) {
-        // A pieced launch keeps tree stack + cold store per WORKGROUP (one region per piece: 4 GB at the C5 shard) and a
-        // checkpoint record per piece boundary.  If the device cannot give that memory, the launch runs unpieced -- same
+        // A pieced launch keeps tree stack + cold store per WORKGROUP (1 GB at the C5 shard; 4 GB with one region per piece)
+        // and a checkpoint record per piece boundary.  If the device cannot give that memory, the launch runs unpieced -- same
         // draws, one workgroup per site -- instead of failing the sampling call.
-        const size_t need_stack = total_pieces * o.chains * a.stack_stride;
+        // (looping workgroups -- the default -- keep theirs per RESIDENT workgroup: never more than 8 per CU; with one
+        // workgroup per piece, EPX_PIECE_GRID, every piece has its own)
+        bool looping = !getenv("EPX_PIECE_GRID");
+#ifdef EPX_STAMPS
+        if (!getenv("EPX_PIECE_LOOP")) looping = false;     // (the diagnostic build's records are per workgroup: one piece each unless asked otherwise)
+#endif
+        const size_t regions = (looping && total_pieces > (size_t)c->n_cu * 8) ? (size_t)c->n_cu * 8 : total_pieces;
+        const size_t need_stack = regions * o.chains * a.stack_stride;
         const size_t need_ckpt = (size_t)count * nb_site * o.chains * (size_t)(4 * nv + 1) * 64;
         if (c->stack_elems < need_stack) {
             double *p = nullptr;

@@ -1585,7 +1585,7 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
                 if (e != hipSuccess) return (int)e;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-                const int hold = (per_cu > 0 ? per_cu : 1) * (ncu > 0 ? ncu : 1);
+                const int hold = (per_cu > 0 ? (per_cu < 8 ? per_cu : 8) : 1) * (ncu > 0 ? ncu : 1);      // (the host sized the workgroups' private memory for at most 8 per CU)
                 hipLaunchKernelGGL(kern, dim3(nblocks < hold ? nblocks : hold), dim3(NT), a.lds_bytes, stream, a);
                 return (int)hipGetLastError();
             };

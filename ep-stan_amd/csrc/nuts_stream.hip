@@ -693,7 +693,7 @@ static int launch_stream_one(const NutsArgs &a, int nblocks, size_t lds, hipStre
                 if (e != hipSuccess) return (int)e;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-                const int hold = (per_cu > 0 ? per_cu : 1) * (ncu > 0 ? ncu : 1);
+                const int hold = (per_cu > 0 ? (per_cu < 8 ? per_cu : 8) : 1) * (ncu > 0 ? ncu : 1);      // (the host sized the workgroups' private memory for at most 8 per CU)
                 if (nblocks > hold) nblocks = hold;
             }
         }

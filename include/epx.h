@@ -320,12 +320,15 @@ int epx_set_site_order(epx_ctx *ctx, const int32_t *order, int count);
  * No reference counterpart. */
 int epx_set_site_split(epx_ctx *ctx, int n_lead);
 int epx_last_split(epx_ctx *ctx);
-/* Pieced launch of the samplers that keep one workgroup per site (layouts 5, 7 and 3): with a piece queue set, a sampling call over ALL sites runs one
- * workgroup per PIECE (piece_len transitions of one site); a workgroup claims the site with the largest predicted
- * remaining work (transitions left x rate[site], rate = predicted leapfrogs per transition, NULL = all equal) that
- * nobody holds, runs its next piece, leaves a checkpoint at the transition boundary and puts the site back -- longest
- * remaining processing time first, which ends all sites at about the same time whatever they really cost (a launch
- * of one workgroup per site ends with the CU that drew two heavy sites).  Exactly the draws of the plain launch.
+/* Pieced launch of the samplers that keep one workgroup per site (layouts 5, 7 and 3): with a piece queue set, a
+ * sampling call over ALL sites cuts every site's run into PIECES (piece_len transitions) and runs as many workgroups as
+ * the device holds at a time; a workgroup claims the site with the largest predicted remaining work (transitions left x
+ * rate[site], rate = predicted leapfrogs per transition, NULL = all equal) that nobody holds, runs its next piece,
+ * leaves a checkpoint at the transition boundary, puts the site back and looks for the next one until no site has
+ * anything left -- longest remaining processing time first, which ends all sites at about the same time whatever they
+ * really cost (a launch of one workgroup per site ends with the CU that drew two heavy sites).  Exactly the draws of
+ * the plain launch.  (Environment, diagnostics only: EPX_PIECE_GRID=1 launches one workgroup per piece instead of
+ * looping ones -- same draws, 1-6 % slower: the device deals a grid's workgroups to its XCDs in order.)
  * piece_len <= 0 clears.  No counterpart in the reference (scheduling only). */
 int epx_set_piece_queue(epx_ctx *ctx, int piece_len, const double *rate);
 /* minus the pieces per site of the last sampling call if it ran from the piece queue, 0: one workgroup per site */

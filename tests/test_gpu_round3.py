@@ -54,6 +54,34 @@ def test_pieced_resident_launch_follows_the_oracle_run(model, D, n, layout, piec
     eng.set_piece_queue(0)
 
 
+@pytest.mark.parametrize('model,D,n,layout', [('m4b_sg', 32, 500, 7), ('m4b_sg', 16, 200, 5), ('m4b_sg', 72, 300, 0)])
+def test_looping_workgroups_and_one_workgroup_per_piece_give_the_same_draws(model, D, n, layout, monkeypatch):
+    """The pieced launch runs looping workgroups (as many as the device holds, each claiming pieces until none is left);
+    EPX_PIECE_GRID=1 brings back one workgroup per piece.  Six sites in pieces of 3 transitions (the workgroups outnumber the
+    sites, so every one of them waits, claims and loops): both forms, and the unpieced launch, bit for bit the same draws and chain statistics
+    (resident kernels and, D = 72, the streaming one)."""
+    K, it, chains = 6, 20, 4
+    X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 5 + D, K=K, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
+    seeds = np.arange(K, dtype=np.int64) * 7 + 11
+    opts = HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=layout)
+    eng.sample_batch(seeds, opts)
+    lay = eng.last_layout()
+    assert eng.last_segments() >= 0 and (layout == 0 or lay == layout)
+    plain = [eng.get_draws(k, all_params=True).copy() for k in range(K)]
+    plain_cs = eng.get_chain_stats(chains).copy()
+    for grid in (False, True):
+        if grid:
+            monkeypatch.setenv('EPX_PIECE_GRID', '1')
+        eng.set_piece_queue(3, np.linspace(1.0, 2.0, K))
+        eng.sample_batch(seeds, opts)
+        assert eng.last_layout() == lay and eng.last_segments() == -7
+        for k in range(K):
+            np.testing.assert_array_equal(eng.get_draws(k, all_params=True), plain[k])
+        np.testing.assert_array_equal(eng.get_chain_stats(chains), plain_cs)
+    eng.set_piece_queue(0)
+
+
 def test_pieced_streaming_launch_follows_the_oracle_run_at_d128():
     """The C5 shard runs pieced launches of the streaming sampler (rows through the LDS-DMA ring, chains in lock step):
     one site with D = 128 (d = 258, P = 387, seven registers per vector), a short run cut into pieces of 3
