@@ -132,9 +132,18 @@ __device__ __forceinline__ int piece_claim(Args &a, unsigned char *smem, int tid
     return q_site >= 0 ? 1 : (q_site == -4 ? 0 : -1);
 }
 
-// After a chain's checkpoint stores (every wave that wrote one): out of this XCD's L2 before anybody is told
+// After a chain's checkpoint stores (every wave that wrote one): they are complete before anybody is told.
+// The record is written with system-scope stores (ck_store: write-through, acknowledged when the write is out of this
+// XCD's L2), so waiting for them IS the release.  The release FENCE that stood here writes back every dirty line of
+// the XCD's L2 (`buffer_wbl2`) -- the tree stacks and cold stores of all 32 workgroups of the XCD, ~2 MB, at every one
+// of the ~8 700 piece ends of a C3 launch: 15 of the 18 GB a launch wrote to HBM, for lines nobody else ever reads.
+// EPX_PIECE_FENCE (compile time) brings the fences back.
 __device__ __forceinline__ void piece_checkpoint_out() {
+#ifdef EPX_PIECE_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 // The site goes back to the pool (thread 0, after a workgroup barrier behind the chains' checkpoint stores and their
@@ -145,7 +154,13 @@ __device__ __forceinline__ void piece_release(Args &a, unsigned char *smem) {
     const int r_site = pz[0], r_t0 = pz[1];
     const int r_len = piece_len_of(a, r_site);
     const int t1 = r_t0 + r_len < a.iter ? r_t0 + r_len : a.iter;
-    __hip_atomic_store(a.dyn_prog + r_site, 2 * t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // progress up, claim off: one store
+    // progress up, claim off: one store (agent scope: written through to where the other XCDs' claims read it; the
+    // checkpoint stores of every wave are complete -- piece_checkpoint_out, then the workgroup barrier in front of this)
+#ifdef EPX_PIECE_FENCE
+    __hip_atomic_store(a.dyn_prog + r_site, 2 * t1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __hip_atomic_store(a.dyn_prog + r_site, 2 * t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 }  // namespace epx
