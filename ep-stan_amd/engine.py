@@ -286,8 +286,8 @@ class HipEngine(object):
         return int(self.lib.epx_last_split(self.ctx))
 
     def set_piece_queue(self, piece_len=0, rate=None):
-        """Piece queue of the resident sampler (include/epx.h: epx_set_piece_queue): one workgroup per piece of
-        `piece_len` transitions, each claiming the site with the largest remaining predicted work; `rate`: predicted
+        """Piece queue of the resident sampler (include/epx.h: epx_set_piece_queue): the sites' runs in pieces of
+        `piece_len` transitions, looping workgroups each claiming the site with the largest remaining predicted work; `rate`: predicted
         leapfrogs per transition of every site (None: all equal); piece_len 0 clears."""
         if rate is not None:
             rate = np.ascontiguousarray(rate, dtype=np.float64)

@@ -670,7 +670,7 @@ class Master(object):
     def _one_workgroup_per_cu(self):
         """The resident sampler keeps a site's rows (padded to 16 / 32 columns) in LDS: above half of the 160 KB
         only one workgroup fits a CU; the streaming sampler (D > 32, or rows beyond the LDS) always fills it.  Then
-        a launch of one workgroup per PIECE loses nothing to occupancy."""
+        a pieced launch (one resident workgroup per CU, looping over pieces) loses nothing to occupancy."""
         n_max = int(np.max(np.diff(self.k_lim[self.k_lo:self.k_hi + 1])))
         if self.D > 32:
             return True
@@ -814,7 +814,7 @@ class Master(object):
                     eng.set_site_split(n_lead)
                     if hasattr(eng, 'set_piece_queue'):
                         # when a site fills the LDS (one workgroup per CU) and there are more sites than CUs: run the
-                        # sampler from a piece queue -- one workgroup per piece of a site's transitions, the site with
+                        # sampler from a piece queue -- looping workgroups claim pieces of a site's transitions, the site with
                         # the largest predicted remaining work first (same draws; only the dispatch changes)
                         if (eng.last_layout() in (5, 7, 3) and n_lead == 0 and self.K_local > eng.cu_count()
                                 and self._one_workgroup_per_cu()):
