@@ -171,8 +171,9 @@ __device__ inline void duo_publish(duo_flag_t *flag, int v) {
 typedef const __attribute__((address_space(4))) NutsArgs DuoArgsK;       // the kernel arguments where they are: kernarg segment
 
 // One piece of a chain's run: transitions [t_begin, t_end) of one site by the waves of one workgroup (the whole run
-// in a plain launch).  PIECED is a template parameter because the piece loop around this body costs it its register
-// allocation (76 -> 500 B of scratch per lane, 15 % of the time): the plain launch keeps the kernel without the loop.
+// in a plain launch).  PIECED is a template parameter because a piece loop around this body INLINED costs it its register
+// allocation (76 -> 500 B of scratch per lane, 15 % of the time): the plain launch keeps the kernel without the loop, and
+// the pieced launch's loop calls the body as a function (k_nuts_duo_loop / duo_piece_call below).
 
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD, bool PIECED>
 __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queued, int q_site, int q_t0) {
