@@ -340,7 +340,10 @@ def main():
                           'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(layout),
                           'lead_sites_of_a_split_launch': int(M.engine.last_split()),
                           # < 0: the launch ran from the piece queue (persistent workgroups), -pieces per site
-                          'pieces': int(M.engine.last_segments()) if hasattr(M.engine, 'last_segments') else 0}
+                          'pieces': int(M.engine.last_segments()) if hasattr(M.engine, 'last_segments') else 0,
+                          # (negative `pieces`: pieces per site of a launch from the piece queue; who takes them)
+                          'piece_form': 'one workgroup per piece (EPX_PIECE_GRID)' if os.environ.get('EPX_PIECE_GRID')
+                          else 'looping workgroups, as many as the device holds'}
     if args.cpu_sites > 0:
         try:
             out['cpu_baseline'] = cpu_baseline(M, mod, data, args.chains, args.siter, args.cpu_sites,
