@@ -70,30 +70,71 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(M, mod, data, chains, siter, n_all, n_seq, threads):
-    """The CPU port (oracle/, kind 'port') on this box's host cores, from the SAME state as the
-    timed GPU iterations: the cavities and the chains' last draws of the first sites are
-    downloaded after the timed region, and the C restatement of the sampler + the NumPy moment
-    stage run one site update each from there.  Two schedules:
-      all-cores           (site, chain) pairs spread over every host thread;
-      reference-faithful  sites strictly one after the other, the 4 chains of a site on 4 threads
-                          (PyStan n_jobs=-1 inside method.py:1005-1023), plus the reference's own
-                          "limiting sampling time" = max over sites (method.py:1043)."""
-    from oracle import ep_oracle as eo
-    from oracle import nuts_oracle as no
-    no.build()
+PARITY_SEED = 3      # seed of the one EP iteration behind the timed region that the CPU leg re-does (Master.run(1, seed=...))
+
+
+def _ess(x):
+    """Effective sample size of the chains x (chains, n) for the mean: Geyer's initial positive sequence on the
+    chain-averaged autocorrelations."""
+    c, n = x.shape
+    xc = x - x.mean(axis=1, keepdims=True)
+    var = (xc * xc).mean()
+    if not var > 0:
+        return float(c * n)
+    f = np.fft.rfft(xc, 2 * n, axis=1)
+    acov = np.fft.irfft(f * np.conj(f), 2 * n, axis=1)[:, :n].mean(axis=0) / n
+    rho = acov / acov[0]
+    tau, t = 1.0, 1
+    while t + 1 < n:
+        pair = rho[t] + rho[t + 1]
+        if pair <= 0:
+            break
+        tau += 2.0 * pair
+        t += 2
+    return float(c * n / max(tau, 1.0 / np.log10(max(c * n, 10))))
+
+
+def snapshot_for_cpu_leg(M, n_all, chains, siter):
+    """What the CPU leg starts from, taken BEFORE the parity iteration: the cavities, the chains' last draws and the
+    global approximation the device holds after its timed iterations."""
     eng = M.engine
     P = eng.P
     nkeep = siter - siter // 2
     n_all = min(n_all, M.K_local)
-    n_seq = min(n_seq, n_all)
     mus = np.stack([eng.get_cavity(k)[1] for k in range(n_all)])
     Oms = np.stack([eng.get_cavity(k)[0] for k in range(n_all)])
     last = np.stack([eng.get_draws(k, all_params=True).reshape(chains, nkeep, P)[:, -1, :] for k in range(n_all)])
     Q, r = eng.get_global()
+    return {'n_all': n_all, 'mus': mus, 'Oms': Oms, 'last': last, 'Q': Q, 'r': r}
+
+
+def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df):
+    """The CPU port (oracle/, kind 'port') on this box's host cores re-does, for the first sites of the workload, the site
+    updates of ONE EP iteration that the device has just run behind the timed region (`Master.run(1, seed=PARITY_SEED)`):
+    same cavities, same starting draws, same per-site Stan seeds (method.py:342-346), the C restatement of the sampler +
+    the NumPy moment stage.  That run is timed (`cpu_baseline`) AND compared with the device's results (`parity`:
+    north_star's same-run agreement on the posterior mean / covariance -- the tilted moments of method.py:413-437 that the
+    sites contribute, and the global moments of method.py:1211-1219 they add up to).
+    Two schedules are timed:
+      all-cores           (site, chain) pairs spread over every host thread;
+      reference-faithful  sites strictly one after the other, the 4 chains of a site on 4 threads
+                          (PyStan n_jobs=-1 inside method.py:1005-1023), plus the reference's own
+                          "limiting sampling time" = max over sites (method.py:1043)."""
+    from epstan_amd.engine import DQI
+    from epstan_amd.seeds import run_seeds, stan_seeds
+    from oracle import ep_oracle as eo
+    from oracle import nuts_oracle as no
+    no.build()
+    eng = M.engine
+    P, d = eng.P, eng.d
+    nkeep = siter - siter // 2
+    n_all = snap['n_all']
+    n_seq = min(n_seq, n_all)
+    mus, Oms, last, Q, r = snap['mus'], snap['Oms'], snap['last'], snap['Q'], snap['r']
     lim = np.asarray(M.k_lim[:n_all + 1], dtype=np.int64)
     X, y = M.X[:lim[-1]], M.y[:lim[-1]]
-    seeds = np.arange(1, n_all + 1, dtype=np.int64) * 7919
+    # the Stan seeds the device used for these sites in the parity iteration
+    seeds = stan_seeds(run_seeds(PARITY_SEED, 1, M.K)[0, M.k_lo:M.k_hi])[:n_all].astype(np.int64)
     nthr = threads if threads > 0 else no.lib().epo_num_threads()
 
     def site_update(ks, nt):
@@ -102,16 +143,15 @@ def cpu_baseline(M, mod, data, chains, siter, n_all, n_seq, threads):
         t0 = time.perf_counter()
         draws, _, stats = no.nuts_sites(M.model_name, X[l[0]:l[-1]], y[l[0]:l[-1]], l - l[0], mus[sl], Oms[sl],
                                         seeds[sl], chains=chains, iter=siter, init=last[sl], nthreads=nt)
-        for j in range(len(ks)):
-            eo.tilted_moments(np.asfortranarray(draws[j].reshape(-1, P)[:, :eng.d]), Q, r, 'sample')
-        return time.perf_counter() - t0, float(stats[:, :, 3].sum())
+        mom = [eo.tilted_moments(np.asfortranarray(draws[j].reshape(-1, P)[:, :d]), Q, r, estim) for j in range(len(ks))]
+        return time.perf_counter() - t0, float(stats[:, :, 3].sum()), draws, stats, mom
 
-    t_all, g_all = site_update(list(range(n_all)), nthr)
+    t_all, g_all, draws_c, stats_c, mom_c = site_update(list(range(n_all)), nthr)
     t_seq = [site_update([k], min(chains, nthr))[0] for k in range(n_seq)]
-    return {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': int(nthr), 'kind': 'port',
+    base = {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': int(nthr), 'kind': 'port',
             'cpu': cpu_model_name(), 'host_threads': os.cpu_count(),
-            'sample': 'one site update (C-oracle NUTS + NumPy moment stage) of the first %d sites of this workload, '
-                      'started from the cavities and last draws the GPU held after its timed iterations; '
+            'sample': 'one site update (C-oracle NUTS + NumPy moment stage) of the first %d sites of this workload: the EP '
+                      'iteration the device ran behind its timed ones, from the same cavities, last draws and Stan seeds; '
                       '(site, chain) pairs over %d threads: %.1f s wall, %.3g gradients'
                       % (n_all, nthr, t_all, g_all),
             'reference_schedule': {
@@ -123,6 +163,104 @@ def cpu_baseline(M, mod, data, chains, siter, n_all, n_seq, threads):
                 'note': 'the reference reports max over sites as its per-iteration "sampling time" '
                         '(method.py:1043), i.e. the time if every site had its own 4 cores'},
             'extrapolation': 'none: rates are per site update; an EP iteration over J sites costs J / rate'}
+
+    # ---- parity: the device's results of the same site updates
+    cs = eng.get_chain_stats(chains)[:n_all]
+    first_err, n_first, n_end, n_stats = 0.0, 0, 0, 0
+    z_mean, rel_cov, tol_cov, dq_rel = [], [], [], []
+    for k in range(n_all):
+        dev = eng.get_draws(k, all_params=True).reshape(chains, nkeep, P)
+        ref = draws_c[k]
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = np.abs(dev - ref).max(axis=2) / scale                      # (chains, nkeep)
+        for c in range(chains):
+            if err[c, 0] < 1e-4:                                         # (a decision that differs gives O(0.1 - 1))
+                n_first += 1
+                first_err = max(first_err, float(err[c, :5].max()) if np.all(err[c, :5] < 1e-4) else float(err[c, 0]))
+            if np.all(err[c] < 1e-4):
+                n_end += 1
+                n_stats += int(cs[k, c, 2] == stats_c[k, c, 2] and cs[k, c, 3] == stats_c[k, c, 3])
+        # tilted moments (method.py:413-437): both sets of draws are samples of the same tilted distribution; where the
+        # chains have parted (chaotic trajectories amplify the last-bit differences of the summation order) they are
+        # independent ones, and the tolerance is the Monte-Carlo error of both
+        g, c_ = dev[:, :, :d], ref[:, :, :d]
+        mg, mc = g.reshape(-1, d).mean(axis=0), c_.reshape(-1, d).mean(axis=0)
+        vg, vc = g.reshape(-1, d).var(axis=0, ddof=1), c_.reshape(-1, d).var(axis=0, ddof=1)
+        for i in range(d):
+            eg, ec = _ess(g[:, :, i]), _ess(c_[:, :, i])
+            vp = 0.5 * (vg[i] + vc[i])
+            z_mean.append(abs(mg[i] - mc[i]) / np.sqrt(vp * (1.0 / eg + 1.0 / ec)))
+            rel_cov.append(abs(vg[i] - vc[i]) / vp)
+            tol_cov.append(4.0 * np.sqrt(2.0 / eg + 2.0 / ec))
+        # the site delta the device formed from ITS draws against the NumPy moment stage on the same draws (deterministic)
+        dQ_dev, dr_dev = eng.get_site(DQI, k)
+        dQ_o = eo.tilted_moments(np.asfortranarray(dev.reshape(-1, P)[:, :d]), Q, r, estim)[0]
+        dq_rel.append(float(np.abs(dQ_dev - dQ_o).max() / np.abs(dQ_o).max()))
+    z_mean, rel_cov, tol_cov = np.array(z_mean), np.array(rel_cov), np.array(tol_cov)
+    # the global moments (method.py:1211-1219) the iteration leads to, with the CPU's deltas in place of the device's for
+    # the sampled sites: Q(df) = Q + df sum_k dQi (method.py:1071-1074)
+    dQ_all, dr_all = eng.get_sites(DQI)
+    glob = None
+    for damp in (df, 0.5 * df, 0.25 * df):
+        try:
+            Qg = Q + damp * dQ_all.sum(axis=2)
+            rg = r + damp * dr_all.sum(axis=1)
+            Qc, rc = Qg.copy(), rg.copy()
+            for k in range(n_all):
+                Qc += damp * (mom_c[k][0] - dQ_all[:, :, k])
+                rc += damp * (mom_c[k][1] - dr_all[:, k])
+            Sg, Sc = np.linalg.inv(Qg), np.linalg.inv(Qc)
+            np.linalg.cholesky(Sg), np.linalg.cholesky(Sc)
+            m_g, m_c = Sg.dot(rg), Sc.dot(rc)
+            sd = np.sqrt(np.diag(Sg))
+            glob = {'df': float(damp), 'mean_shift_in_sd_max': float(np.max(np.abs(m_g - m_c) / sd)),
+                    'cov_rel_err_max': float(np.abs(Sg - Sc).max() / np.abs(Sg).max())}
+            break
+        except np.linalg.LinAlgError:
+            continue
+    # one transition from the SAME state with the same step size and metric: the arithmetic itself, no chaos in between
+    q0 = np.stack([eng.get_draws(k, all_params=True).reshape(chains, nkeep, P)[:, -1, :] for k in range(n_all)])
+    eps = cs[:, :, 1]
+    inv_e = np.stack([np.repeat(eng.get_adapt(k, chains)[1][None, :], chains, axis=0) for k in range(n_all)])
+    inv_e = np.where(inv_e > 0, inv_e, 1.0)
+    mus2 = np.stack([eng.get_cavity(k)[1] for k in range(n_all)])
+    Oms2 = np.stack([eng.get_cavity(k)[0] for k in range(n_all)])
+    lay = eng.last_layout()
+    tf = None
+    if lay in (1, 2, 5, 6, 7):
+        ref_t, st_t = no.nuts_transitions(M.model_name, X, y, lim, mus2, Oms2, seeds, q0, eps, inv_e, nt=1, t_offset=7)
+        out_t, cs_t = eng.nuts_transitions(seeds, q0, eps, inv_e, nt=1, t_offset=7, layout=lay if lay in (5, 7) else 0, k0=0)
+        e_t = np.abs(out_t - ref_t).max(axis=(2, 3)) / np.maximum(1.0, np.abs(ref_t).max(axis=(2, 3)))
+        tf = {'chains': int(e_t.size), 'layout': int(eng.last_layout()), 'max_rel_err': float(e_t.max()),
+              'chains_within_1e-6': int(np.sum(e_t < 1e-6)),
+              'leapfrog_counts_equal': int(np.sum(cs_t[:, :, 3] == st_t[:, :, 3])),
+              'mean_leapfrogs': float(st_t[:, :, 3].mean())}
+    parity = {
+        'what': 'the EP iteration behind the timed ones, sites 0..%d: device (the timed kernel, piece queue and all) against the '
+                'CPU port from the same cavities, starting draws and Stan seeds' % (n_all - 1),
+        'sites': int(n_all), 'chains': int(n_all * chains),
+        # draw by draw: ONE transition of every chain from the same state, step size and metric (no chaos in between)
+        'first_draws_max_abs_err': None if tf is None else tf['max_rel_err'],
+        'first_draws': tf,
+        # the whole site update (100 warm-up + 100 kept transitions of up to 1 023 leapfrogs): HMC amplifies the last-bit
+        # differences of the summation order, so chains are compared until they part -- on these funnel-shaped posteriors
+        # most part during the warm-up, and from there on the two runs are independent samples of the same tilted distribution
+        'whole_update': {'chains_equal_at_first_kept_draw': int(n_first), 'chains_equal_to_the_last_draw': int(n_end),
+                         'equal_chains_with_equal_leapfrog_counts': int(n_stats),
+                         'max_rel_err_of_their_first_kept_draws': first_err},
+        'tilted_mean_err_in_mcse': {'max': float(z_mean.max()), 'median': float(np.median(z_mean)),
+                                    'share_within_4': float(np.mean(z_mean <= 4.0))},
+        'tilted_cov_rel_err': {'max': float(rel_cov.max()), 'median': float(np.median(rel_cov)),
+                               'share_within_tolerance': float(np.mean(rel_cov <= tol_cov))},
+        'site_delta_vs_numpy_moment_stage_max_rel_err': float(np.max(dq_rel)),
+        'global_moments_with_cpu_deltas_for_these_sites': glob,
+        'tolerance': 'first draws (one transition from the same state): 1e-6 relative; tilted mean within 4 MCSE per coordinate, '
+                     'tilted variances within 4 sqrt(2/ESS_dev + 2/ESS_cpu) relative (SURVEY.md section 8c; ESS by Geyer\'s '
+                     'initial positive sequence over the %d chains); site delta from the device\'s own draws against the NumPy '
+                     'moment stage: 1e-7' % chains,
+        'ok': bool((tf is None or tf['max_rel_err'] < 1e-6) and np.mean(z_mean <= 4.0) >= 0.99
+                   and np.mean(rel_cov <= tol_cov) >= 0.99 and np.max(dq_rel) < 1e-7)}
+    return base, parity
 
 
 def spawn_ranks(n, argv):
@@ -201,12 +339,11 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    from epstan_amd import dist as edist, models
+    # (no PyTorch in a rank: the library's own entry brackets the timed region, so the process holds ONE HIP / RCCL
+    # runtime, the ROCm installation's that libepx.so is linked against -- the one the parity tests run on)
+    from epstan_amd import _lib as elib, dist as edist, models
     from epstan_amd.method import Master
     on_gpu = _ENGINE_FACTORY is None
-    if on_gpu:
-        torch.cuda.set_device(local_rank)
     # every rank, also a single one, goes through the in-library RCCL communicator
     comm = edist.EpxComm(rank=rank, world=world) if _COMM_FACTORY is None else _COMM_FACTORY(rank, world)
 
@@ -220,10 +357,10 @@ def main():
 
     def sync():
         if on_gpu:
-            torch.cuda.synchronize()
+            elib.device_synchronize(local_rank)
         comm.barrier()
         if on_gpu:
-            torch.cuda.synchronize()
+            elib.device_synchronize(local_rank)
 
     if warm > 0:
         info = M.run(warm, verbose=False, seed=1)[0]
@@ -290,21 +427,28 @@ def main():
                 'passes_max_over_mean_site': float(np.mean([p.max() / p.mean() for p in M.pass_log[n_launch0:]])),
                 'fp64_tflops': achieved_tf}
     else:
-        tr, src = measured_traffic(('r03_%s_pmc_hbm.json' % args.config, 'r02_%s_pmc_hbm.json' % args.config))
-        lds_tbs = float(ngrad.mean()) * B_g / t_kernel / 1e12
+        tr, src = measured_traffic(('r04_%s_pmc_hbm.json' % args.config, 'r03_%s_pmc_hbm.json' % args.config,
+                                    'r02_%s_pmc_hbm.json' % args.config))
         team = layout == 7
+        # bytes the kernel reads from LDS for the rows: one sweep of the site per gradient in the one-wave-per-chain forms;
+        # layout 7 reads the rows TWICE per pass (forward and transposed product) for the FOUR gradients of a site's chains
+        passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
+        lds_bytes = float(passes.mean()) * 2.0 * B_g if team else float(ngrad.mean()) * B_g
+        lds_tbs = lds_bytes / t_kernel / 1e12
         roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
                 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_source': src,
                 'note': ('FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event duration of the '
                          'sampler launch.  Layout 7: the two products of a gradient run on v_mfma_f64_4x4x4 for the four '
                          'chains of a site in lock step (dense FP64 matrix peak = FP64 vector peak = 78.6 TFLOP/s); X is '
-                         'LDS resident, so HBM does not bound it: lds_frac / hbm_frac below') if team else
+                         'LDS resident, so HBM does not bound it: lds_frac / hbm_frac below (lds_swept: two reads of the '
+                         'rows per lock-step pass of four chains)') if team else
                         ('FP64 vector flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
                          'duration of the sampler launch.  The kernel issues no MFMA (a wave owns one chain: '
                          'matrix-vector work) and X is LDS resident, so neither the matrix pipes nor HBM '
                          'bound it: lds_frac / hbm_frac below'),
                 'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
+                'row_passes_per_launch': float(passes.mean()),
                 'lds_swept_TBps': lds_tbs, 'lds_peak_TBps': LDS_PEAK_TBS, 'lds_frac': lds_tbs / LDS_PEAK_TBS,
                 'hbm_algorithmic_bytes': hbm_alg,
                 'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}
@@ -330,6 +474,15 @@ def main():
         'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
                                                / (sites * args.chains * args.siter)),
     }
+    # what a "site update" is made of here: most transitions of the late iterations build a tree of max_treedepth
+    # (1 023 leapfrogs); the headline is a statement about such trees
+    max_lf = float(2 ** M.max_treedepth - 1)
+    out['tree_depth_note'] = ('%.0f %% of the possible %d leapfrogs per transition over the timed launches (first %.0f %%, '
+                              'last %.0f %%): these funnel-shaped site posteriors drive Stan\'s NUTS to max_treedepth in most '
+                              'transitions, so site-updates/s here is a rate of depth-%d trees'
+                              % (100 * float(ngrad.mean()) / (sites * args.chains * args.siter) / max_lf, int(max_lf),
+                                 100 * float(ngrad[0]) / (sites * args.chains * args.siter) / max_lf,
+                                 100 * float(ngrad[-1]) / (sites * args.chains * args.siter) / max_lf, M.max_treedepth))
     # the launch ends with its slowest chain (one workgroup per chain) / slowest site (chains in lock step):
     # how far that is from the average, last launch of this rank
     lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
@@ -346,11 +499,20 @@ def main():
                           else 'looping workgroups, as many as the device holds'}
     if args.cpu_sites > 0:
         try:
-            out['cpu_baseline'] = cpu_baseline(M, mod, data, args.chains, args.siter, args.cpu_sites,
-                                               args.cpu_seq_sites, args.cpu_threads)
+            # one more EP iteration on the device, behind the timed region, whose first sites the CPU port re-does from the
+            # same state and seeds: the CPU's time is the baseline, the two results are the parity record
+            snap = snapshot_for_cpu_leg(M, args.cpu_sites, args.chains, args.siter)
+            info_p = M.run(1, verbose=False, seed=PARITY_SEED)[0]
+            assert info_p == 0, 'parity EP iteration failed with info %d' % info_p
+            out['cpu_baseline'], out['parity'] = cpu_leg(M, snap, args.prec_estim, args.chains, args.siter,
+                                                         args.cpu_seq_sites, args.cpu_threads,
+                                                         M.df_log[-1] if getattr(M, 'df_log', None) else M.df0(M.iter))
         except Exception as ex:                      # the baseline must not void the GPU measurement
+            import traceback
+            traceback.print_exc()
             out['cpu_baseline'] = {'value': None, 'unit': 'site-updates/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %r' % (ex,)}
+            out['parity'] = None
     if hasattr(comm, 'close'):
         comm.close()
     sys.stdout.flush()

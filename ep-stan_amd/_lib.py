@@ -31,6 +31,7 @@ class SamplerOpts(ctypes.Structure):
 SIGNATURES = {
     'epx_last_error': (ctypes.c_char_p, []),
     'epx_device_count': (ctypes.c_int, [c_int_p]),
+    'epx_device_synchronize': (ctypes.c_int, [ctypes.c_int]),
     'epx_model_dims': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]),
     'epx_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       c_int64_p, c_double_p, c_int32_p,
@@ -147,6 +148,10 @@ def dptr(a):
         return None
     assert a.dtype == np.float64
     return a.ctypes.data_as(c_double_p)
+
+
+def device_synchronize(device=0):
+    check(load().epx_device_synchronize(int(device)))
 
 
 def device_count():

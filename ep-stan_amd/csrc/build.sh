@@ -15,6 +15,21 @@ done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libepx.so build/dense.o build/nuts.o build/nuts_duo.o build/nuts_stream.o build/epx_api.o build/epx_comm.o -ldl
 echo "built $(cd .. && pwd)/libepx.so"
+# The same library with the piece hand-off's release FENCE kept (-DEPX_PIECE_FENCE, epx_pieces.h): the A/B partner of the
+# litmus test (tests/test_gpu_round4.py), never benchmarked.  Only the two files that include epx_pieces.h differ.
+mkdir -p build_fence ../../variants
+pids=()
+for f in nuts_duo nuts_stream; do
+  if [ ! -f build_fence/$f.o ] || [ build/$f.o -nt build_fence/$f.o ]; then
+    $HIPCC $FLAGS -DEPX_PIECE_FENCE -c $f.hip -o build_fence/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+if [ ! -f ../../variants/libepx_fence.so ] || [ ../libepx.so -nt ../../variants/libepx_fence.so ]; then
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../../variants/libepx_fence.so build/dense.o build/nuts.o build_fence/nuts_duo.o build_fence/nuts_stream.o build/epx_api.o build/epx_comm.o -ldl
+fi
+echo "built $(cd ../.. && pwd)/variants/libepx_fence.so"
 if [ "$EPX_STAMPS" = "1" ]; then
   # diagnostic variant with in-kernel cycle stamps (scripts/stamps.py); never benchmarked
   mkdir -p build_stamps

@@ -39,6 +39,13 @@ int epx_device_count(int *count) {
     return 0;
 }
 
+int epx_device_synchronize(int device) {
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail("epx_device_synchronize(%d): %s", device, hipGetErrorString(e));
+    return 0;
+}
+
 int epx_model_dims(int model, int D, int *dphi, int *npar) {
     int d, P;
     const int o = (model >= EPX_M1A_SG && model <= EPX_M5A_SG) ? 1 : 0;      // log sigma in front
@@ -686,12 +693,15 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         }
         if (use_queue && c->ckpt_n < need_ckpt) {
             double *p = nullptr;
-            if (dalloc(&p, need_ckpt) == hipSuccess) {
+            // (EPX_TEST_FAIL_CKPT: the test hook of this fallback -- the allocation counts as refused)
+            if (!getenv("EPX_TEST_FAIL_CKPT") && dalloc(&p, need_ckpt) == hipSuccess) {
                 if (c->ckpt) (void)hipFree(c->ckpt);
                 c->ckpt = p; c->ckpt_n = need_ckpt;
             } else { (void)hipGetLastError(); use_queue = false; }
         }
-        if (use_queue) a.stack = c->stack;
+        // (build_nuts_args took c->stack before the re-allocation above: the launch -- pieced or, when the checkpoint records
+        // could not be had, unpieced -- must see the buffer that exists now.  The larger buffer also serves the unpieced form.)
+        a.stack = c->stack;
     }
     if (use_queue) {
         HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));

@@ -27,10 +27,32 @@ namespace epx {
     X(9, depth_sum) X(10, nleap_tot) X(11, ngrad) X(12, t) X(13, va_counter) X(14, va_wsize) X(15, va_next)       \
     X(16, ndiv) X(17, npost) X(18, kept) X(19, failed)
 
-// A checkpoint travels between CUs of DIFFERENT XCDs, whose L2s do not see each other's lines: it is written and
-// read with agent-scope accesses, the writer RELEASES at agent scope before the site is put back (piece_checkpoint_out)
-// and the claimer ACQUIRES after the claim (piece_claim): without the acquire a site that comes back to an XCD it has
-// been on earlier in the launch can hit that XCD's L2 copy of its OLDER record (seen as a rare wrong trajectory)
+// A checkpoint travels between CUs of DIFFERENT XCDs, whose L2s do not see each other's lines.  The protocol (and what
+// each step leans on):
+//   writer   1. every lane stores its part of the record with SYSTEM-scope atomic stores (ck_store: `global_store_dwordx2
+//               ... sc0 sc1`).  On gfx942 / gfx950 the sc bits of a store ARE its coherence scope (LLVM AMDGPUUsage, "Memory
+//               Model gfx942": store atomic monotonic, system scope = sc0=1 sc1=1): the XCD's L2 does not keep the line
+//               dirty for a store of agent or system scope, it forwards the write to the fabric -- that is how a monotonic
+//               atomic store becomes visible to another XCD without any fence;
+//            2. every wave that stored waits `s_waitcnt vmcnt(0)` (piece_checkpoint_out).  vmcnt counts a store until it is
+//               ACKNOWLEDGED, and a written-through store is acknowledged when the write has left the L2 -- the same
+//               guarantee the model's own release sequence leans on (`buffer_wbl2 sc1` followed by `s_waitcnt vmcnt(0)`);
+//            3. a workgroup barrier collects the waves (k_nuts_duo_loop / k_nuts_stream_loop: __syncthreads() behind the piece);
+//            4. thread 0 stores the site's word, relaxed at agent scope (`global_store_dword ... sc1`, piece_release).
+//   claimer  5. compare-and-swap on the site's word with ACQUIRE at agent scope, then an agent-scope acquire FENCE
+//               (piece_claim: `buffer_inv sc1`): this XCD's L2 drops what it holds, so no older line of a record can be hit;
+//            6. the record is read with system-scope atomic loads (ck_load: sc0 sc1, served past the L2).
+// What is NOT used between 2 and 4 is the model's release FENCE: on these parts it is `buffer_wbl2 sc1`, a write-back of
+// EVERY dirty line of the XCD's L2 -- the tree stacks and cold stores of all 32 workgroups of the XCD, which nobody else
+// ever reads (6 of the 18 GB a C3 launch wrote to HBM, section 6 of DESIGN.md).  Steps 1-2 are a release of exactly the
+// lines that travel; the form is the one /opt/skills/guides/MI355X_MICROARCH.md lists under "Valid forms" (`sc0 sc1`
+// stores drained by every storing wave's vmcnt(0), a workgroup barrier, one lane's flag store; the consumer's acquire kept),
+// measured there on gfx950 / ROCm 7.2 and marked "not an architectural guarantee".  This is an argument from the ISA's behaviour, not from the language's memory model (for which a
+// relaxed store orders nothing): it is therefore (a) confined to this header, (b) switchable -- -DEPX_PIECE_FENCE puts the
+// release fence and a release store back, build.sh ships that build as variants/libepx_fence.so -- and (c) tested on the
+// device by a litmus run (tests/test_gpu_round4.py::test_piece_handoff_litmus_*: hundreds of sites in pieces of ONE
+// transition, so that every site changes XCD dozens of times per launch, repeated, bit-equal to the uncut launch, under
+// both builds).  Every piece boundary has its own record (piece_record), so no address is ever written twice in a launch.
 __device__ inline void ck_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);

@@ -55,6 +55,18 @@ template <int DPB> struct StreamGeom {
     static constexpr int MB = DW / 16;             // backward 16-column groups per wave
 };
 
+// Cache policy of the row DMA (EPX_ROW_NT=1: non-temporal).  A site's rows are re-read every pass but never hit a cache in
+// between (2 MB per CU and pass through a 4 MB L2 that 32 CUs share, 0.66 GB per pass through the 256 MB Infinity Cache):
+// streamed with the default policy they only evict what the caches could keep -- the tree stacks, the cold store, the
+// cavity precision.
+#ifndef EPX_ROW_NT
+#define EPX_ROW_NT 0
+#endif
+#if EPX_ROW_NT
+#define EPX_NT " nt"
+#else
+#define EPX_NT ""
+#endif
 // LDS-DMA pieces as inline asm: hipcc does not count them, so it inserts no vmcnt(0) before the
 // LDS reads of the ring (it does for the builtin); completion is counted by hand (wait_vm).
 // M0 = wave-uniform LDS destination, written in the statement that uses it.
@@ -69,7 +81,7 @@ __device__ inline unsigned scalar_of(unsigned x) {
 __device__ inline void glds16(const void *src, unsigned lds_off) {
     unsigned keep;
     const unsigned dst = scalar_of(lds_off);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" EPX_NT "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 __device__ inline void glds4(const void *src, unsigned lds_off) {
@@ -201,22 +213,22 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
         unsigned keep;
         if constexpr (Gm::NI == 16) {
             asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %11, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %12, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %13, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %14, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %15, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %16, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %17, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %18, %2\n\t"
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %11, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %12, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %13, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %14, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %15, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %16, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %17, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %18, %2" EPX_NT "\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
                 : "s"(dst), "s"(sbase), "v"(s.off[0]), "v"(s.off[1]), "v"(s.off[2]), "v"(s.off[3]), "v"(s.off[4]),
@@ -225,14 +237,14 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
                 : "memory", "scc");
         } else {
             asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %2\n\t"
-                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %2\n\t"
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %2" EPX_NT "\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %2" EPX_NT "\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
                 : "s"(dst), "s"(sbase), "v"(s.off[0]), "v"(s.off[1]), "v"(s.off[2]), "v"(s.off[3]), "v"(s.off[4]),

@@ -88,23 +88,43 @@ class EpxComm(object):
 
     # ---- bootstrap
     def _store_exchange(self, uid, seq):
-        """Through torchrun's store (TORCHELASTIC_USE_AGENT_STORE): returns the id, or None when there is no such store."""
+        """Through torchrun's store (TORCHELASTIC_USE_AGENT_STORE): returns the id, or None when there is no such store.
+        Which channel carries the id is decided from the environment alone, the same way on every rank: with the store
+        announced, an error talking to it RAISES (no per-rank fallback to the socket, which rank 0 would then not be
+        serving).  The store's client is PyTorch's; it runs in a short-lived CHILD process, so that a rank never loads
+        PyTorch's bundled HIP / RCCL runtime beside the ROCm one libepx.so is linked against (the timed run and the parity
+        tests execute on one runtime)."""
         env = os.environ
         if env.get('TORCHELASTIC_USE_AGENT_STORE', '') != 'True' or 'MASTER_PORT' not in env:
             return None
-        try:
-            from datetime import timedelta
-            from torch.distributed import TCPStore
-            store = TCPStore(self.addr, int(env['MASTER_PORT']), self.world, False, timedelta(seconds=300))
-            key = 'epx_comm_id/%s/%s/%d' % (env.get('TORCHELASTIC_RUN_ID', '-'), env.get('TORCHELASTIC_RESTART_COUNT', '0'), seq)
-            if self.rank == 0:
-                store.set(key, uid)
-                return uid
-            return bytes(store.get(key))          # blocks until rank 0 has set it
-        except Exception as ex:                   # no store after all: the socket exchange below
-            import sys
-            print('epx: torchrun store not usable for the RCCL id (%r), using the socket exchange' % (ex,), file=sys.stderr)
-            return None
+        import subprocess
+        import sys
+        key = 'epx_comm_id/%s/%s/%d' % (env.get('TORCHELASTIC_RUN_ID', '-'), env.get('TORCHELASTIC_RESTART_COUNT', '0'), seq)
+        child = ('import sys\n'
+                 'from datetime import timedelta\n'
+                 'from torch.distributed import TCPStore\n'
+                 'addr, port, world, key, uid = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]\n'
+                 'store = TCPStore(addr, port, world, False, timedelta(seconds=300))\n'
+                 'if uid:\n'
+                 '    store.set(key, bytes.fromhex(uid))\n'
+                 '    print("ok")\n'
+                 'else:\n'
+                 '    print(bytes(store.get(key)).hex())\n')
+        cenv = dict(env)
+        cenv['CUDA_VISIBLE_DEVICES'] = ''          # the child talks to a TCP store: it needs no device
+        cenv['HIP_VISIBLE_DEVICES'] = ''
+        out = subprocess.run([sys.executable, '-c', child, self.addr, env['MASTER_PORT'], str(self.world), key,
+                              uid.hex() if self.rank == 0 else ''], env=cenv, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             timeout=600)
+        if out.returncode != 0:
+            raise RuntimeError('epx: the RCCL id could not travel through torchrun\'s store (%s:%s): %s'
+                               % (self.addr, env['MASTER_PORT'], out.stderr.decode('utf-8', 'replace')[-400:]))
+        if self.rank == 0:
+            return uid
+        got = bytes.fromhex(out.stdout.decode().strip().splitlines()[-1])
+        if len(got) != _lib.COMM_ID_BYTES:
+            raise RuntimeError('epx: the RCCL id from the store has %d bytes' % len(got))
+        return got
 
     def _exchange_id(self, uid):
         """Rank 0 serves `uid` to every other rank; the others fetch it (retrying while rank 0

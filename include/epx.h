@@ -93,6 +93,10 @@ enum epx_site_stat {
 
 const char *epx_last_error(void);
 int epx_device_count(int *count);
+/* Blocks until every stream of `device` is idle (hipDeviceSynchronize).  Every entry point of a context already returns
+ * with its own work finished; this is the bracket a measurement harness puts around a timed region (bench.py) without
+ * bringing a second HIP runtime -- PyTorch's bundled one -- into the process. */
+int epx_device_synchronize(int device);
 
 /* dphi and number of sampled coordinates P of a model (m*b_sg.stan parameter blocks). */
 int epx_model_dims(int model, int D, int *dphi, int *npar);

@@ -11,3 +11,4 @@ echo "built variants/stream_probe variants/mfma_layout variants/concurrent varia
 hipcc --offload-arch=gfx950 -O2 scripts/probe/mfma_rate.hip -o variants/mfma_rate
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iep-stan_amd/csrc scripts/probe/team_pass.hip -o variants/team_pass
 hipcc --offload-arch=gfx950 -O2 scripts/probe/dispatch_gaps.hip -o variants/dispatch_gaps
+hipcc --offload-arch=gfx950 -O2 scripts/probe/lds_rate.hip -o variants/lds_rate

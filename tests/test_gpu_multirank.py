@@ -149,6 +149,29 @@ def _worker(rank, world, port, mode, outdir, transport):
         info, (m_s, S_s) = M.run(6, verbose=False, seed=1)
         np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Qi=M.Qi, ri=M.ri, Q=M.Q,
                  klo=M.k_lo, khi=M.k_hi, df=np.array(M.df_log))
+    elif mode in ('c4', 'c5x2'):
+        # BASELINE config C4 at its OWN size (J = 4096, D = 32, n_j = 500: eight shards of 512 sites), or two of C5's
+        # shards (J = 1024, D = 128, n_j = 2000), every rank on device 0: the real sampler, the timed kernels and launch
+        # forms (layout 7 / 3 from the piece queue), the library's own multi-rank update
+        J, D, n, cor, estim, it = (4096, 32, 500, True, 'sample', 1) if mode == 'c4' else (1024, 128, 2000, False, 'olse', 1)
+        mod = models.m4b(J, D, n)
+        data = mod.simulate_data(Sigma_x='rand', rng=100) if cor else mod.simulate_data(rng=100)
+        _, _, Q0, r0 = mod.get_prior()
+        M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
+                   prec_estim=estim, df0=models.default_df0(J), comm=comm, device=device, sync_sites=False)
+        info, (m_s, S_s), an = M.run(it, verbose=False, return_analytics=True, seed=1)
+        lo, hi = M.k_lo, M.k_hi
+        eng = M.engine
+        stats = M.last_site_stats
+        k = 137
+        samp = eng.get_draws(k)
+        Mat, vec, nsamp = eng.get_tilted(k)
+        c = samp - samp.mean(axis=0)
+        np.savez(os.path.join(outdir, 'r%d.npz' % rank), info=info, m=m_s, S=S_s, Q=M.Q, r=M.r, Q0=M.Q0, r0=M.r0,
+                 Qi_sum=M.Qi[:, :, lo:hi].sum(axis=2), ri_sum=M.ri[:, lo:hi].sum(axis=1), klo=lo, khi=hi,
+                 fails=stats[:, 7].sum(), min_leapfrogs=stats[:, 2].min(), layout=eng.last_layout(), pieces=eng.last_segments(),
+                 nsamp=nsamp, mean_err=np.abs(vec - samp.mean(axis=0)).max(), scat_err=np.abs(Mat - c.T.dot(c)).max() / np.abs(Mat).max(),
+                 ms=M.sampling_ms[-1], msteps=an[1], mrhats=an[2], stimes=an[0])
     else:
         nsite = 16 if mode == 'nuts16' else 6
         mod = models.m4b(nsite, 3, 60)
@@ -274,3 +297,46 @@ def test_eight_ranks_equal_one_rank_with_the_real_sampler(tmp_path):
         np.testing.assert_allclose(r['Qi'], M.Qi, rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(r['msteps'], an[1], rtol=1e-12)
         np.testing.assert_allclose(r['mrhats'], an[2], rtol=1e-12)
+
+
+def _own_size_checks(res, world, J, layout):
+    per = J // world
+    assert [(int(r['klo']), int(r['khi'])) for r in res] == [(per * i, per * (i + 1)) for i in range(world)]
+    Qsum = sum(r['Qi_sum'] for r in res)
+    rsum = sum(r['ri_sum'] for r in res)
+    for r in res:
+        assert int(r['info']) == 0 and int(r['layout']) == layout and int(r['pieces']) < 0        # the timed kernel, from the piece queue
+        assert float(r['fails']) == 0 and float(r['min_leapfrogs']) > 0 and int(r['nsamp']) == 400
+        assert float(r['mean_err']) < 1e-10 and float(r['scat_err']) < 1e-8
+        m, S = r['m'][-1], r['S'][-1]
+        assert np.all(np.isfinite(m)) and np.all(np.isfinite(S))
+        np.testing.assert_allclose(S, S.T, rtol=1e-9, atol=1e-13)
+        assert np.linalg.eigvalsh(S)[0] > 0
+        # the replicated global approximation is the SAME on every rank (one all-reduce, method.py:1073-1074) ...
+        for key in ('Q', 'r', 'm', 'S', 'msteps', 'mrhats'):
+            np.testing.assert_array_equal(r[key], res[0][key])
+        # ... and is the prior plus the sum of every rank's accepted site parameters
+        np.testing.assert_allclose(r['Q'], r['Q0'] + Qsum, rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(r['r'], r['r0'] + rsum, rtol=1e-9, atol=1e-7)
+
+
+def test_c4_at_its_own_size_eight_ranks_on_one_device(tmp_path):
+    """BASELINE config C4: J = 4096 sites, D = 32, n_j = 500, sharded over 8 ranks (512 sites each, = C3 per rank), one EP
+    iteration with the real sampler -- all eight ranks on the one device of the box, the library's own multi-rank code
+    (epx_update_trial: per-rank statistics slots, global site offsets, flag reductions) with every collective handed to
+    gloo: everything that runs on the 8-GPU node except ncclAllReduce itself.  Invariants of the C3-size test on every rank,
+    bit-equal replicated Q, r, S, m, and Q = Q0 + the sum over ALL ranks' sites (method.py:1073-1074, 1145;
+    experiment/fit.py:326-335)."""
+    res = _spawn('c4', tmp_path, 'host', world=8)
+    _own_size_checks(res, 8, 4096, 7)
+    print('C4 on one device: sampling launch per rank %s ms (eight launches share the device)' % np.round([float(r['ms']) for r in res], 0))
+
+
+def test_two_c5_shards_two_ranks_on_one_device(tmp_path):
+    """Two of BASELINE config C5's eight shards (2 x 512 sites, D = 128, n_j = 2000, d = 258, prec_estim='olse') as two
+    ranks on the one device: the streaming sampler from the piece queue and the d = 258 update phase through the library's
+    multi-rank code.  (C5's own J = 4096 is eight such shards: 8 x 35 s of sampling per EP iteration on one device plus
+    8 x 8.4 GB of host data do not fit this suite's time; the per-rank code path is the one exercised here.)"""
+    res = _spawn('c5x2', tmp_path, 'host', world=2)
+    _own_size_checks(res, 2, 1024, 3)
+

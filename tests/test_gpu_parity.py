@@ -337,8 +337,10 @@ def test_nuts_full_run_matches_oracle(model, D, n, layout, it, tight):
                 assert cs[k, c, 3] == st_o[k, c, 3]                              # same gradient count
                 np.testing.assert_allclose(cs[k, c, 0], st_o[k, c, 0], rtol=1e-5)    # step-size path
                 np.testing.assert_allclose(cs[k, c, 5], st_o[k, c, 5], rtol=1e-4)    # accept_stat
-    record_slack('full run vs oracle %s D=%d n=%d layout %d: chains equal to the end' % (model, D, n, layout), n_full, '>= 9', 12)
-    assert n_full >= 9, n_full                                             # of 12 (site, chain) runs
+    # (layouts 5 and 7, the kernels the bench times: the bound is what has been observed since they exist, no slack)
+    need = 12 if layout in (5, 7) else 9
+    record_slack('full run vs oracle %s D=%d n=%d layout %d: chains equal to the end' % (model, D, n, layout), n_full, '>= %d' % need, 12)
+    assert n_full >= need, n_full                                          # of 12 (site, chain) runs
     if n_full == 12:
         np.testing.assert_allclose(stats[:, 2], st_o[:, :, 2].sum(1))
         rh = [max(no.split_rhat(draws_o[k, :, :, e]) for e in range(P)) for k in range(3)]
@@ -386,8 +388,9 @@ def test_nuts_transitions_match_oracle_teacher_forced(model, D, n, layout):
         nbad += int(np.sum(~same_tree | (err > 1e-6)))
         assert np.all(err[same_tree] < 1e-6), err
         assert st_o[:, :, 2].min() >= 1
-    record_slack('teacher-forced transitions %s D=%d n=%d layout %d: transitions that differ' % (model, D, n, layout), nbad, '<= 1', 24)
-    assert nbad <= 1, nbad
+    allow = 0 if layout in (5, 7) else 1        # (the bench's kernels: observed 0 of 24 in every case since they exist)
+    record_slack('teacher-forced transitions %s D=%d n=%d layout %d: transitions that differ' % (model, D, n, layout), nbad, '<= %d' % allow, 24)
+    assert nbad <= allow, nbad
 
 
 @pytest.mark.parametrize('model,D,n', [('m4b_sg', 16, 200), ('m1b_sg', 4, 50), ('m4b_sg', 32, 150), ('m5b_sg', 7, 33),

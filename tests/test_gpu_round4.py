@@ -1,0 +1,71 @@
+"""Round-4 device tests: the piece hand-off's litmus run under both protocols (the default build and the
+-DEPX_PIECE_FENCE one shipped as variants/libepx_fence.so), the out-of-memory fallback of the pieced launch, (the oracle bounds of
+the headline kernel are tightened in place: test_gpu_parity.py, test_gpu_round3.py).
+
+Everything goes through the C ABI (ctypes)."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from epstan_amd.engine import HipEngine
+from test_gpu_parity import _engine_with_cavity, _site_problem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FENCE_LIB = os.path.join(ROOT, 'variants', 'libepx_fence.so')
+pytestmark = pytest.mark.gpu
+
+
+def _litmus(layout, D, n, K, it, reps, lib=None):
+    env = dict(os.environ)
+    env.pop('EPX_PIECE_GRID', None)
+    if lib is not None:
+        env['EPX_LIB'] = lib
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'piece_litmus_helper.py')] +
+                         [str(v) for v in (layout, D, n, K, it, reps)], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode('utf-8', 'replace')[-3000:]
+    line = [l for l in res.stdout.decode().splitlines() if l.startswith('litmus ')][-1].split()
+    return int(line[1]), int(line[4]), line[5]
+
+
+@pytest.mark.parametrize('layout,D,n,K,it,reps', [(7, 16, 48, 320, 12, 50), (5, 16, 48, 320, 12, 25), (0, 72, 40, 96, 8, 25)])
+def test_piece_handoff_litmus_default_and_fence_builds_agree(layout, D, n, K, it, reps):
+    """csrc/epx_pieces.h hands a site's checkpoint from one XCD to another with write-through stores + vmcnt(0) + barrier +
+    a relaxed flag store (no L2 write-back fence).  Litmus: hundreds of sites cut into pieces of ONE transition (every site
+    is claimed `it` times per launch by whichever of the device's looping workgroups is free, so it crosses XCDs dozens of
+    times), repeated `reps` times: every repetition bit-equal to the uncut launch.  The same run under the build that keeps
+    the memory model's release fence (variants/libepx_fence.so) must give the same draws."""
+    lay, bad, digest = _litmus(layout, D, n, K, it, reps)
+    assert (lay == layout or layout == 0) and bad == 0, (lay, bad)
+    assert os.path.exists(FENCE_LIB), 'variants/libepx_fence.so is missing: run __graft_entry__.build()'
+    lay_f, bad_f, digest_f = _litmus(layout, D, n, K, it, max(5, reps // 5), lib=FENCE_LIB)
+    assert lay_f == lay and bad_f == 0 and digest_f == digest
+
+
+def test_pieced_launch_falls_back_to_the_uncut_one_when_the_checkpoints_cannot_be_allocated(monkeypatch):
+    """run_sampler re-allocates the tree stack for the looping workgroups and then the checkpoint records; when the second
+    allocation is refused the launch runs uncut -- on the NEW stack buffer (round 3 left the launch arguments pointing at
+    the freed one).  EPX_TEST_FAIL_CKPT makes the allocation count as refused."""
+    K, it, chains = 5, 16, 4
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 32, 500, 11, K=K, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    seeds = np.arange(K, dtype=np.int64) * 3 + 2
+    opts = HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=7)
+    monkeypatch.setenv('EPX_TEST_FAIL_CKPT', '1')
+    eng.set_piece_queue(2, None)
+    eng.sample_batch(seeds, opts)                           # first call of the context: stack grown, checkpoints refused
+    assert eng.last_layout() == 7 and eng.last_segments() == 0
+    fell_back = [eng.get_draws(k, all_params=True).copy() for k in range(K)]
+    monkeypatch.delenv('EPX_TEST_FAIL_CKPT')
+    eng.sample_batch(seeds, opts)
+    assert eng.last_segments() == -8
+    for k in range(K):
+        np.testing.assert_array_equal(eng.get_draws(k, all_params=True), fell_back[k])
+    eng.set_piece_queue(0)
+    eng.sample_batch(seeds, opts)
+    for k in range(K):
+        np.testing.assert_array_equal(eng.get_draws(k, all_params=True), fell_back[k])
