@@ -753,14 +753,15 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     {
         const int nblk = use_queue ? a.seg_nwg : count * ((o.chains + a.cpb - 1) / a.cpb);      // (a pieced launch: one workgroup per piece)
         // (two records of 8 sums per workgroup: the roles' shares, then the phases of the row team's pass)
-        if (c->stamps_n < (size_t)3 * nblk + 2) {
+        // (behind the three records of every workgroup: two records of the first diagnostic form, then six of histograms)
+        if (c->stamps_n < (size_t)3 * nblk + 8) {
             if (c->stamps) (void)hipFree(c->stamps);
-            HIPCHK(dalloc(&c->stamps, (size_t)3 * nblk * 8 + 16));
-            c->stamps_n = 3 * nblk + 2;
+            HIPCHK(dalloc(&c->stamps, (size_t)(3 * nblk + 8) * 8));
+            c->stamps_n = 3 * nblk + 8;
         }
-        HIPCHK(hipMemset(c->stamps, 0, (size_t)3 * nblk * 64 + 128));
+        HIPCHK(hipMemset(c->stamps, 0, (size_t)(3 * nblk + 8) * 64));
         a.stamps = c->stamps;
-        c->stamps_last = 3 * nblk + 2;
+        c->stamps_last = 3 * nblk + 8;
     }
 #endif
     HIPCHK(hipMemcpyAsync(c->seeds_d, seeds, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));

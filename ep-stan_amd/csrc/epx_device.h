@@ -224,6 +224,17 @@ __device__ inline double log_sum_exp2(double a, double b) {
     return b + log1p(exp(a - b));
 }
 
+// log_sum_exp2 with the lean exponential / log1p of this file (the row team's bookkeeping: the other waves of the workgroup
+// wait for the wave that completes a subtree)
+__device__ inline double exp_d(double x);
+__device__ inline double log1p_unit_d(double e);
+__device__ inline double log_sum_exp2_lean(double a, double b) {
+    if (a == -INFINITY) return b;
+    if (a == INFINITY && b == INFINITY) return INFINITY;
+    if (a > b) return a + log1p_unit_d(exp_d(b - a));
+    return b + log1p_unit_d(exp_d(a - b));
+}
+
 // Merging two log-weights a (left) and b (right): lse = log(e^a + e^b) and the
 // multinomial probability of the right one, e^b / (e^a + e^b), from ONE exp
 // (base_nuts.hpp computes log_sum_exp and exp(b - lse) separately).
@@ -379,8 +390,12 @@ __device__ inline void logistic_split2(double fa, double fb, double ya, double y
 // shows in `lin` (y f - max(f, 0)), which is how the row team's caller learns of it -- through the log density.
 __device__ inline void logistic_pair_lean(double fa, double fb, double ya, double yb, double &lina, double &linb,
                                           double &wa, double &wb, double &ga, double &gb) {
-    const double xa = -fabs(fa), xb = -fabs(fb);
-    const double ca = fmin(fmax(xa, -800.0), 800.0), cb = fmin(fmax(xb, -800.0), 800.0);
+    // -|f| clamped at -800 by ONE instruction (same value as fmin(fmax(-|f|, -800), 800): the compiler's form of it
+    // canonicalises -|f| with a v_max of its own first and keeps the idle upper clamp: three instructions)
+    double ca, cb;
+    const double lim = -800.0;
+    asm("v_max_f64 %0, -|%1|, %2" : "=v"(ca) : "v"(fa), "s"(lim));
+    asm("v_max_f64 %0, -|%1|, %2" : "=v"(cb) : "v"(fb), "s"(lim));
     const double ka = __builtin_rint(ca * 1.4426950408889634074), kb = __builtin_rint(cb * 1.4426950408889634074);
     double ra = fma(ka, -6.93147180369123816490e-01, ca), rb = fma(kb, -6.93147180369123816490e-01, cb);
     ra = fma(ka, -1.90821492927058770002e-10, ra); rb = fma(kb, -1.90821492927058770002e-10, rb);
@@ -401,6 +416,46 @@ __device__ inline void logistic_pair_lean(double fa, double fb, double ya, doubl
     const double sa = (fa >= 0) ? qa : ea * qa, sb = (fb >= 0) ? qb : eb * qb;
     lina = ya * fa - fmax(fa, 0.0); linb = yb * fb - fmax(fb, 0.0);
     ga = ya - sa; gb = yb - sb;
+}
+
+// p * x + c as the three-address instruction, whatever register class the compiler found for the constant: where the
+// scalar registers are used up (the row team's kernel) LLVM keeps polynomial coefficients in vector registers and then
+// selects the two-address v_fmac_f64 -- which overwrites its addend, so every Horner step came with a v_mov_b64 of the
+// coefficient in front of it.  Same value as fma().
+__device__ inline double fma_vc(double p, double x, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "v"(c));
+    return r;
+}
+// exp_d, bit for bit, with those steps (the state wave's view update: the exponential sits on the critical stretch)
+__device__ inline double exp_d_vc(double x) {
+    const double xc = fmin(fmax(x, -800.0), 800.0);
+    const double kf = __builtin_rint(xc * 1.4426950408889634074);
+    double r = fma(kf, -6.93147180369123816490e-01, xc);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma_vc(p, r, 2.08767569878681e-09); p = fma_vc(p, r, 2.505210838544172e-08); p = fma_vc(p, r, 2.755731922398589e-07);
+    p = fma_vc(p, r, 2.7557319223985893e-06); p = fma_vc(p, r, 2.48015873015873e-05); p = fma_vc(p, r, 1.984126984126984e-04);
+    p = fma_vc(p, r, 1.388888888888889e-03); p = fma_vc(p, r, 8.333333333333333e-03); p = fma_vc(p, r, 4.1666666666666664e-02);
+    p = fma_vc(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    const double res = ldexp(p, (int)kf);
+    return (x != x) ? x : res;
+}
+// log_ge1_d, bit for bit, with those steps (the row team's one logarithm per pass)
+__device__ inline double log_ge1_d_vc(double x) {
+    int k = 0;
+    double m = frexp(x, &k);
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? 2.0 * m : m; k = lo ? k - 1 : k;
+    const double s = (m - 1.0) * rcp_d(m + 1.0);
+    const double z = s * s;
+    double p = 4.7619047619047616e-02;
+    p = fma_vc(p, z, 5.2631578947368418e-02); p = fma_vc(p, z, 5.8823529411764705e-02); p = fma_vc(p, z, 6.6666666666666666e-02);
+    p = fma_vc(p, z, 7.6923076923076927e-02); p = fma_vc(p, z, 9.0909090909090912e-02); p = fma_vc(p, z, 1.1111111111111110e-01);
+    p = fma_vc(p, z, 1.4285714285714285e-01); p = fma_vc(p, z, 0.2); p = fma_vc(p, z, 3.3333333333333331e-01);
+    p = fma(p, z, 1.0);
+    return fma((double)k, 6.931471805599453094e-01, 2.0 * s * p);
 }
 
 }  // namespace epx

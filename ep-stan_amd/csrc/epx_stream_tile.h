@@ -55,12 +55,14 @@ template <int DPB> struct StreamGeom {
     static constexpr int MB = DW / 16;             // backward 16-column groups per wave
 };
 
-// Cache policy of the row DMA (EPX_ROW_NT=1: non-temporal).  A site's rows are re-read every pass but never hit a cache in
-// between (2 MB per CU and pass through a 4 MB L2 that 32 CUs share, 0.66 GB per pass through the 256 MB Infinity Cache):
-// streamed with the default policy they only evict what the caches could keep -- the tree stacks, the cold store, the
-// cavity precision.
+// Cache policy of the row DMA: non-temporal (EPX_ROW_NT=0 brings the default policy back for A/B).  A site's rows are re-read
+// every pass but never hit a cache in between (2 MB per CU and pass through a 4 MB L2 that 32 CUs share, 0.66 GB per pass
+// through the 256 MB Infinity Cache): streamed with the default policy they only evict what the caches could keep -- the
+// tree stacks, the cold store, the cavity precision -- and the DMA itself lands later (MI355X_MICROARCH.md, nt-weights).
+// Measured on the C5 shard, one box, order default / nt / nt / default (bench.py --config c5shard --steps 1 --warmup 1):
+// 12.84 / 15.28 / 15.44 / 12.85 site-updates/s, 152 -> 127 us per lock-step pass and CU, 54.4 -> 65.5 % of the HBM peak.
 #ifndef EPX_ROW_NT
-#define EPX_ROW_NT 0
+#define EPX_ROW_NT 1
 #endif
 #if EPX_ROW_NT
 #define EPX_NT " nt"

@@ -454,21 +454,25 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 TSTAMP(1);
                 // ---- the rows: two tiles per round (their logistic terms overlap).  The LDS reads run ahead of their
                 // use: the backward operands of a round and the forward operands of the NEXT round are requested
-                // before the round's logistic terms, so no product waits for an LDS round trip
+                // before the round's logistic terms, so no product waits for an LDS round trip.
                 double gacc[KS];
 #pragma unroll
                 for (int c = 0; c < KS; ++c) gacc[c] = 0.0;
                 double dsum = 0.0, lsum = 0.0, wprod = 1.0;
-                unsigned yb = ybits;
                 lds_v2f64 xf0[NRD], xf1[NRD];
-                unsigned pf[NRD], pb[NRD];
 #pragma unroll
                 for (int r = 0; r < NRD; ++r) {
-                    pf[r] = af[r]; pb[r] = ab[r];
-                    xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)pf[r]);
-                    xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pf[r] + TILEB));
+                    xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)af[r]);
+                    xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(af[r] + TILEB));
                 }
-                for (int t = t0; t < t1; t += 2) {
+                // one round: tiles t, t + 1 of the site = byte offset `off` from the wave's first tile pair
+                // (running LDS POINTERS, bumped once per round; the reads of a round sit at compile-time distances from them.
+                // Integer addresses converted at every use cost an extra vector add per read)
+                lds_v2f64_p pf[NRD], pb[NRD];
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) { pf[r] = reinterpret_cast<lds_v2f64_p>((uintptr_t)af[r]); pb[r] = reinterpret_cast<lds_v2f64_p>((uintptr_t)ab[r]); }
+                constexpr int TILEV = TILEB / 16;              // a tile in 16-byte units
+                auto do_round = [&](const int t, const double y0, const double y1) {
                     double f0 = alpha_c, f1 = alpha_c;
 #pragma unroll
                     for (int r = 0; r < NRD; ++r) {
@@ -482,21 +486,18 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     lds_v2f64 xb0[NRD], xb1[NRD];
 #pragma unroll
                     for (int r = 0; r < NRD; ++r) {
-                        xb0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)pb[r]);
-                        xb1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pb[r] + TILEB));
+                        xb0[r] = pb[r][0];
+                        xb1[r] = pb[r][TILEV];
                     }
                     // (the round after the last one reads what lies behind the wave's tiles: values unused)
 #pragma unroll
                     for (int r = 0; r < NRD; ++r) {
-                        xf0[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pf[r] + 2 * TILEB));
-                        xf1[r] = *reinterpret_cast<const lds_v2f64_p>((uintptr_t)(pf[r] + 3 * TILEB));
+                        xf0[r] = pf[r][2 * TILEV];
+                        xf1[r] = pf[r][3 * TILEV];
                     }
-#pragma unroll
-                    for (int r = 0; r < NRD; ++r) { pf[r] += 2 * TILEB; pb[r] += 2 * TILEB; }
                     TSTAMP(3);
                     double l0, l1, w0, w1, g0, g1;
-                    logistic_pair_lean(f0, f1, (double)(yb & 1u), (double)((yb >> 1) & 1u), l0, l1, w0, w1, g0, g1);
-                    yb >>= 2;
+                    logistic_pair_lean(f0, f1, y0, y1, l0, l1, w0, w1, g0, g1);
                     if (16 * (t + 2) > n) {                // the site's last tile(s): rows beyond n add nothing
                         const bool v0 = 16 * t + rb < n, v1 = 16 * (t + 1) + rb < n;
                         l0 = v0 ? l0 : 0.0; w0 = v0 ? w0 : 1.0; g0 = v0 ? g0 : 0.0;
@@ -514,12 +515,23 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                         gacc[2 * r] = mfma4(xb1[r].x, g1, gacc[2 * r]); gacc[2 * r + 1] = mfma4(xb1[r].y, g1, gacc[2 * r + 1]);
                     }
                     TSTAMP(5);
+                    __builtin_amdgcn_sched_barrier(0);      // (nothing moves between the rounds: the unrolled form must not stretch live ranges over them)
+                };
+                {
+                    // (the rounds are NOT unrolled to compile-time distances: two or four rounds in one body cost the wave 8 / 44
+                    // spilled registers -- the cavity operands, reloaded from scratch at the top of every pass)
+                    unsigned yb = ybits;
+                    for (int t = t0; t < t1; t += 2, yb >>= 2) {
+                        do_round(t, (double)(yb & 1u), (double)((yb >> 1) & 1u));
+#pragma unroll
+                        for (int r = 0; r < NRD; ++r) { pf[r] += 2 * TILEV; pb[r] += 2 * TILEV; }
+                    }
                 }
                 // ---- sums over the row blocks (lanes ^ 4, ^ 8), then over the rows hi of a block for the two scalars
                 // (a product with ones: D[.][j] = sum over k of B[k][j])
 #pragma unroll
                 for (int c = 0; c < KS; ++c) { gacc[c] += dpp_d<0x124>(gacc[c]); gacc[c] += dpp_d<0x128>(gacc[c]); }
-                double dz = mfma4(1.0, dsum, 0.0), lz = mfma4(1.0, lsum - log_ge1_d(wprod), 0.0);
+                double dz = mfma4(1.0, dsum, 0.0), lz = mfma4(1.0, lsum - log_ge1_d_vc(wprod), 0.0);
                 dz += dpp_d<0x124>(dz); lz += dpp_d<0x124>(lz);
                 dz += dpp_d<0x128>(dz); lz += dpp_d<0x128>(lz);
                 duo_lds_f64 *res = sl + RESO + wr * RREC;
@@ -859,6 +871,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         }
     }
     const uint32_t toff = (uint32_t)a.t_offset + 1u;
+    // (row team: the subtree-level elementary functions are the lean ones -- a wave that completes a subtree keeps the three
+    // other chains and the row team waiting at the pass's barrier, and libm's exp / log are ~10 x the instructions)
+#define SM_EXP(x) (TEAM ? exp_d(x) : exp(x))
     auto flush_dh = [&](int cnt) {
         const bool ok = lane < cnt;
         const double dh = ok ? dhb : -INFINITY;
@@ -866,11 +881,11 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         const double m_new = fmax(lw_m, mb);
         double w = 0.0, me = 0.0;
         if (ok) {
-            w = (m_new == -INFINITY) ? 0.0 : exp(dh - m_new);
-            me = dh > 0 ? 1.0 : exp(dh);
+            w = (m_new == -INFINITY) ? 0.0 : SM_EXP(dh - m_new);
+            me = dh > 0 ? 1.0 : SM_EXP(dh);
         }
         wave_sum2(w, me);
-        const double scale = (lw_m == -INFINITY) ? 0.0 : exp(lw_m - m_new);
+        const double scale = (lw_m == -INFINITY) ? 0.0 : SM_EXP(lw_m - m_new);
         lw_s = lw_s * scale + w;
         lw_m = m_new;
         sum_metro += me;
@@ -1097,7 +1112,13 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #define EPX_RESUME resume
 #define EPX_T_END (int)(double)t_end_c
 #define EPX_WAVE_SUM2(a_, b_) do { if constexpr (TEAM) wave_sum2_packed(a_, b_); else wave_sum2(a_, b_); } while (0)
+#define EPX_SM_EXP(x) (TEAM ? exp_d(x) : exp(x))
+#define EPX_SM_LOG(x) (TEAM ? log_ge1_d(x) : log(x))
+#define EPX_SM_LSE2(a_, b_) (TEAM ? log_sum_exp2_lean(a_, b_) : log_sum_exp2(a_, b_))
 #include "nuts_state_machine.inc"
+#undef EPX_SM_EXP
+#undef EPX_SM_LOG
+#undef EPX_SM_LSE2
 #undef EPX_WAVE_SUM2
 #undef EPX_RESUME
 #undef EPX_T_END
@@ -1209,7 +1230,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             const double fp1 = vp1 + 0.5 * eps_l * g1, fp2 = vp2 + 0.5 * eps_l * g2, fp3 = vp3 + 0.5 * eps_l * g3;
             vp1 = fp1 + 0.5 * eps_l * g1; vp2 = fp2 + 0.5 * eps_l * g2; vp3 = fp3 + 0.5 * eps_l * g3;
             vq1 = vq1 + eps_l * vm1 * vp1; vq2 = vq2 + eps_l * vm2 * vp2; vq3 = vq3 + eps_l * vm3 * vp3;
-            vex3 = exp_d(vq3);
+            vex3 = exp_d_vc(vq3);
             const double ba = vq1 + vq2 * vex3;
             duo_lds_f64 *job = slot + JOB;
             if (lane < DP) job[BOFF + lane] = (!TEAM || lane < D) ? ba : 0.0;
@@ -1602,6 +1623,10 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 
 template <int NV, int DP>
 static int launch_duo_shape(const NutsArgs &a, int nblocks, int cpb, int rw, hipStream_t stream) {
+#ifdef EPX_DUO_DEV      // (development builds: only the row-team instantiation of the C3 site, for quick looks at its code)
+    if (NV == 2 && DP == 32 && cpb == 4 && rw == 4) return launch_duo_one<2, 32, 4, 4>(a, nblocks, stream);
+    return -1;
+#endif
     if (cpb == 4 && rw == 1) return launch_duo_one<NV, DP, 4, 1>(a, nblocks, stream);
     if (cpb == 4 && rw == 4) return launch_duo_one<NV, DP, 4, 4>(a, nblocks, stream);
     if (cpb == 1 && rw == 2) return launch_duo_one<NV, DP, 1, 2>(a, nblocks, stream);

@@ -302,11 +302,11 @@ class HipEngine(object):
         return int(self.lib.epx_cu_count(self.ctx))
 
     def row_passes(self, chains, k0=0, count=None):
-        """Passes over the site rows made by the last sampling call: in the streaming layout the
-        (up to 4) chains of a workgroup advance in lock step and share one pass per leapfrog;
-        otherwise every gradient is its own pass (over LDS-resident rows)."""
+        """Passes over the site rows made by the last sampling call: in the lock-step layouts (3, 4: streaming / resident
+        rows; 7: the row team) the (up to 4) chains of a workgroup share one pass per leapfrog; otherwise every
+        gradient is its own pass (over LDS-resident rows)."""
         cs = self.get_chain_stats(chains, k0, count)[:, :, 3]
-        if self.last_layout() in (1, 2, 5, 6, 7):
+        if self.last_layout() in (1, 2, 5, 6):
             return cs.sum(axis=1)
         nb = (chains + 3) // 4
         pad = np.zeros((cs.shape[0], nb * 4)); pad[:, :chains] = cs

@@ -106,7 +106,12 @@ __global__ void __launch_bounds__(512) k_mix(unsigned long long *out, double *si
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (wave < 4) {
-        if (with_mfma)
+        if (with_mfma == 2)
+            for (int i = 0; i < N2 / 4; ++i) {
+                asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v1) : "v"(b), "v"(a));
+                asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v2) : "v"(b), "v"(a)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v3) : "v"(b), "v"(a));
+            }
+        else if (with_mfma)
             for (int i = 0; i < N2 / 4; ++i) {
                 c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
@@ -133,6 +138,15 @@ __global__ void __launch_bounds__(512) k_mix(unsigned long long *out, double *si
                              asm volatile("v_max_f64 %0, %0, %1" : "+v"(v2) : "v"(b)); asm volatile("v_max_f64 %0, %0, %1" : "+v"(v3) : "v"(b)); }
             if (KIND == 8) { asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v1) : "v"(b), "v"(a));
                              asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v2) : "v"(b), "v"(a)); asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v3) : "v"(b), "v"(a)); }
+            if (KIND == 10) { asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(u0) : "v"(u1) : "s10", "s11"); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(u1) : "v"(u2) : "s10", "s11");
+                              asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(u2) : "v"(u3) : "s10", "s11"); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(u3) : "v"(u0) : "s10", "s11"); }
+            if (KIND == 11) { asm volatile("v_cmp_gt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(u0) : "v"(u1), "v"(u2) : "vcc"); asm volatile("v_cmp_gt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(u1) : "v"(u2), "v"(u3) : "vcc"); }
+            if (KIND == 12) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a));
+                              asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); }
+            if (KIND == 13) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v1) : "v"(b), "v"(a));
+                              asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(b), "v"(a)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v1) : "v"(b), "v"(a)); }
+            if (KIND == 14) { asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(v0) : "v"(u0)); asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(v1) : "v"(u0));
+                              asm volatile("v_rndne_f64 %0, %0" : "+v"(v2)); asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u1) : "v"(v3)); }
             if (KIND == 9) { asm volatile("v_rcp_f64 %0, %0" : "+v"(v0)); asm volatile("v_rcp_f64 %0, %0" : "+v"(v1));
                              asm volatile("v_rcp_f64 %0, %0" : "+v"(v2)); asm volatile("v_rcp_f64 %0, %0" : "+v"(v3)); }
         }
@@ -145,15 +159,16 @@ __global__ void __launch_bounds__(512) k_mix(unsigned long long *out, double *si
 template <int KIND> void run_mix(const char *what) {
     unsigned long long *d; double *s;
     (void)hipMalloc(&d, 64); (void)hipMalloc(&s, 512 * 8);
-    double r[2][2];
-    for (int with = 0; with < 2; ++with) {
+    double r[3][2];
+    for (int with = 0; with < 3; ++with) {
         for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k_mix<KIND>, dim3(1), dim3(512), 0, 0, d, s, 1.0, with);
         (void)hipDeviceSynchronize();
         unsigned long long h[8];
         (void)hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
         r[with][0] = h[0] / (double)N2; r[with][1] = h[4] / (double)N2;
     }
-    printf("%-16s alone %5.2f cycles per instruction | beside the matrix stream %5.2f (the matrix instruction: %5.2f)\n", what, r[0][1], r[1][1], r[1][0]);
+    printf("%-22s alone %5.2f cycles per instruction | beside the matrix stream %5.2f (the matrix instruction: %5.2f) | beside a v_fma_f64 stream of the SIMD's other wave %5.2f (that stream: %5.2f)\n",
+           what, r[0][1], r[1][1], r[1][0], r[2][1], r[2][0]);
     (void)hipFree(d); (void)hipFree(s);
 }
 
@@ -180,5 +195,10 @@ int main() {
     run_mix<5>("v_cndmask_b32");
     run_mix<4>("v_fma_f32");
     run_mix<8>("v_pk_fma_f32");
+    run_mix<10>("v_cndmask_b32 e64 (sgpr mask)");
+    run_mix<11>("v_cmp + v_cndmask (pair)");
+    run_mix<12>("v_fma_f64, ONE dependent chain");
+    run_mix<13>("v_fma_f64, two chains");
+    run_mix<14>("ldexp ldexp rndne cvt");
     return 0;
 }
