@@ -154,7 +154,7 @@ k_nuts(NutsArgs a) {
     double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
     int ndiv = 0, npost = 0, kept = 0, failed = 0;
     // transition state
-    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0, init_try = 0;
     int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
     uint32_t ss_t = 0;
     double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;
@@ -476,7 +476,7 @@ k_nuts_spec(NutsArgs a) {
     double va_n = 0;
     double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
     int ndiv = 0, npost = 0, kept = 0, failed = 0;
-    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0, init_try = 0;
     int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
     uint32_t ss_t = 0;
     double H0 = 0, lsw = 0, sum_metro = 0;

@@ -286,9 +286,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         for (int s = tid; s < nslot; s += blockDim.x) {
             const int r = s / SPR, jp = s % SPR, c0 = 2 * jp;
             double2 v;
+            // (read once per piece: non-temporal, so that the 128 KB of a site do not push the workgroups' tree stacks and
+            // cold stores out of the XCD's L2 at every piece start)
             if (r >= n) { v.x = 0.0; v.y = 0.0; }
-            else if ((D & 1) == 0 && c0 + 1 < D) v = *reinterpret_cast<const double2 *>(Xg + (size_t)r * D + c0);
-            else {
+            else if ((D & 1) == 0 && c0 + 1 < D) {
+                typedef double nt_v2 __attribute__((ext_vector_type(2)));
+                const nt_v2 t2 = __builtin_nontemporal_load(reinterpret_cast<const nt_v2 *>(Xg + (size_t)r * D + c0));
+                v.x = t2.x; v.y = t2.y;
+            } else {
                 v.x = c0 < D ? Xg[(size_t)r * D + c0] : 0.0;
                 v.y = c0 + 1 < D ? Xg[(size_t)r * D + c0 + 1] : 0.0;
             }
@@ -827,7 +832,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     eps_sum = 0.0; acc_sum = 0.0; depth_sum = 0.0; nleap_tot = 0.0;
     double ngrad = 0;
     int ndiv = 0, npost = 0, kept = 0, failed = 0;
-    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0, init_try = 0;
     int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
     uint32_t ss_t = 0;
     double H0 = 0, sum_metro = 0, eps_l = 0;

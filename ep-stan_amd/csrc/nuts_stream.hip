@@ -63,7 +63,10 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 #define MODE_SS SMODE_SS
 #define MODE_TREE SMODE_TREE
 
-constexpr int OM_UNROLL = 16;   // columns of Omega in flight per thread
+#ifndef EPX_OM_UNROLL
+#define EPX_OM_UNROLL 16
+#endif
+constexpr int OM_UNROLL = EPX_OM_UNROLL;   // columns of Omega in flight per thread
 
 typedef const __attribute__((address_space(4))) NutsArgs StreamArgsK;    // the kernel arguments where they are: kernarg segment
 
@@ -244,7 +247,7 @@ __device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, i
     double va_n = 0;
     double eps_sum = 0, acc_sum = 0, depth_sum = 0, nleap_tot = 0, ngrad = 0;
     int ndiv = 0, npost = 0, kept = 0, failed = 0;
-    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0;
+    int t = 0, mode = MODE_INIT, depth = 0, leaf = 0, nleaf = 1, fwd = 1, nleap = 0, divergent = 0, init_try = 0;
     int ss_trial = 0, ss_dir = 0, ss_after_update = 0;
     uint32_t ss_t = 0;
     double H0 = 0, lsw = 0, sum_metro = 0, eps_l = 0;

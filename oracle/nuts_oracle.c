@@ -561,19 +561,24 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0.0;
 
     for (int i = 0; i < P; ++i) c.inv_e[i] = 1.0;
-    if (init) memcpy(c.qs, init, sizeof(double) * P);
-    else {
-        /* init='random': U(-2,2) on the unconstrained scale */
-        for (int i = 0; i < P; ++i) {
-            double u1, u2;
-            rng_u2(c.key, 0, K_INIT, (uint32_t)(i >> 1), 0, &u1, &u2);
-            c.qs[i] = -2.0 + 4.0 * ((i & 1) ? u2 : u1);
+    /* init='random': U(-2,2) on the unconstrained scale, drawn again -- up to 100 times -- until log density and
+     * gradient are finite (stan::services::util::initialize, Stan 2.17, behind PyStan's sampling():
+     * /root/reference/epstan/util.py:716); a given start (zeros, the previous draws) gets one attempt */
+    int finite = 0;
+    for (int attempt = 0; attempt < (init ? 1 : 100) && !finite; ++attempt) {
+        if (init) memcpy(c.qs, init, sizeof(double) * P);
+        else {
+            for (int i = 0; i < P; ++i) {
+                double u1, u2;
+                rng_u2(c.key, 0, K_INIT, (uint32_t)(i >> 1), (uint32_t)attempt, &u1, &u2);
+                c.qs[i] = -2.0 + 4.0 * ((i & 1) ? u2 : u1);
+            }
         }
+        c.lps = site_lp_grad(&site, c.qs, c.gs);
+        c.ngrad++;
+        finite = isfinite(c.lps);
+        for (int i = 0; i < P; ++i) finite = finite && isfinite(c.gs[i]);
     }
-    c.lps = site_lp_grad(&site, c.qs, c.gs);
-    c.ngrad++;
-    int finite = isfinite(c.lps);
-    for (int i = 0; i < P; ++i) finite = finite && isfinite(c.gs[i]);
     if (!finite) {
         stats[ST_FAIL] = 1.0;
         int nkeep = (iter - warmup + thin - 1) / thin;

@@ -40,19 +40,27 @@ def pmc_sums(d, warmup):
         rows = con.execute(q).fetchall()
         if not rows:
             continue
-        names = [r[0] for r in rows]
-        main = max(set(names), key=names.count)
-        starts = [r[1] for r in rows if r[0] == main]
-        per_iter = [0.0] * len(starts)
-        dur = [0.0] * len(starts)
-        kern = {}
+        # EP iterations = groups of sampler dispatches that overlap in time (a split launch runs two kernels side by side;
+        # the launches of consecutive iterations never overlap).  The first `warmup` ITERATIONS are dropped, whatever
+        # kernels they ran (the first warm-up launches are unpieced / split ones: other kernel names)
+        groups = []
         for name, t0, t1, val in rows:
-            it = min(range(len(starts)), key=lambda i: abs(starts[i] - t0))
-            per_iter[it] += val
-            dur[it] = max(dur[it], (t1 - t0) / 1e6)
+            if groups and t0 < groups[-1]['end']:
+                g = groups[-1]
+            else:
+                g = {'end': t1, 'val': 0.0, 'dur0': t0}
+                groups.append(g)
+            g['end'] = max(g['end'], t1); g['val'] += val
+        per_iter = [g['val'] for g in groups]
+        dur = [(g['end'] - g['dur0']) / 1e6 for g in groups]
+        kern = {}
+        gi = 0
+        for name, t0, t1, val in rows:
+            while gi + 1 < len(groups) and t0 >= groups[gi]['end']:
+                gi += 1
             k = kern.setdefault(name, {'dispatches': 0, 'sum_KiB': 0.0, 'timed_dispatches': 0})
             k['dispatches'] += 1; k['sum_KiB'] += val
-            k['timed_dispatches'] += int(it >= warmup)
+            k['timed_dispatches'] += int(gi >= warmup)
         return kern, per_iter[warmup:], dur[warmup:]
     return {}, [], []
 

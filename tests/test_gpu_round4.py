@@ -69,3 +69,36 @@ def test_pieced_launch_falls_back_to_the_uncut_one_when_the_checkpoints_cannot_b
     eng.sample_batch(seeds, opts)
     for k in range(K):
         np.testing.assert_array_equal(eng.get_draws(k, all_params=True), fell_back[k])
+
+
+@pytest.mark.parametrize('model,D,n,layout', [('m1b_sg', 3, 20, 0), ('m4b_sg', 16, 48, 7), ('m4b_sg', 16, 48, 5), ('m4b_sg', 16, 48, 1),
+                                              ('m4b_sg', 40, 30, 0)])
+def test_random_init_retry_follows_the_oracle(model, D, n, layout):
+    """init='random' draws the start again (up to 100 times) until log density and gradient are finite, as Stan's
+    initialize() behind /root/reference/epstan/util.py:716 does.  A cavity that is finite only for |phi_0| < 1 rejects about
+    half of the first draws; device and oracle continue from the same later draw of the chain's Philox stream (the posterior
+    is so narrow that no chain moves by more than 1e-100 afterwards), and a start that was GIVEN is not replaced."""
+    from oracle import nuts_oracle as no
+    K = 4
+    rng = np.random.RandomState(3)
+    X = rng.randn(K * n, D)
+    y = (rng.rand(K * n) < 0.5).astype(int)
+    eng = HipEngine(model, X, y, np.arange(K + 1) * n)
+    d, P = eng.d, eng.P
+    Om = np.eye(d); Om[0, 0] = np.finfo(float).max
+    for k in range(K):
+        assert eng.cavity_site(k, Om + np.eye(d), np.zeros(d), np.eye(d), np.zeros(d))
+    Om_dev = np.stack([eng.get_cavity(k)[0] for k in range(K)])
+    mu_dev = np.stack([eng.get_cavity(k)[1] for k in range(K)])
+    assert Om_dev[0, 0, 0] == np.finfo(float).max
+    seeds = np.arange(K, dtype=np.int64) + 40
+    stats, _ = eng.sample_batch(seeds, HipEngine.sampler_opts(chains=4, iter=4, warmup=2, init='random', layout=layout))
+    assert layout == 0 or eng.last_layout() == layout
+    draws_o, _, st_o = no.nuts_sites(model, X, y, np.arange(K + 1) * n, mu_dev, Om_dev, seeds, chains=4, iter=4, warmup=2)
+    first = np.array([[-2.0 + 4.0 * no.rng_probe(int(s), c, 0, 0, 0, 0)[0] for c in range(4)] for s in seeds])
+    assert (np.abs(first) >= 1.0).any() and np.all(st_o[:, :, 7] == 0)
+    cs = eng.get_chain_stats(4)
+    assert np.all(cs[:, :, 7] == 0) and stats[:, 7].sum() == 0
+    for k in range(K):
+        np.testing.assert_allclose(eng.get_draws(k, all_params=True), draws_o[k].reshape(-1, P), rtol=0, atol=1e-100)
+    eng.close()

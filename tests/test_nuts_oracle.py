@@ -243,3 +243,37 @@ def test_gaussian_family_multigroup_density(model):
         fd[i] = (no.logdensity_grad(model, X, y, mu, Om, th + e, gl=gl)[0] - no.logdensity_grad(model, X, y, mu, Om, th - e, gl=gl)[0]) / 2e-6
     mask = np.abs(th) > 1e-4 if model == 'm5a' else np.ones(P, bool)
     np.testing.assert_allclose(g[mask], fd[mask], rtol=2e-6, atol=2e-6)
+
+
+def _overflowing_cavity(d):
+    """A cavity whose log density and gradient are finite only for |phi_0| < 1: about half of the U(-2, 2) starts fail."""
+    Om = np.eye(d)
+    Om[0, 0] = np.finfo(float).max
+    return Om, np.zeros(d)
+
+
+def test_random_init_is_drawn_again_until_it_is_finite():
+    """PyStan's init='random' (util.py:716 -> stan::services::util::initialize): a start whose log density or gradient is
+    not finite is drawn again, up to 100 times.  With a cavity that is finite only for |phi_0| < 1 the chains whose first
+    draw lies outside still run, from a later draw of their Philox stream; a given start gets one attempt."""
+    model, D, n, K = 'm1b_sg', 3, 20, 4
+    rng = np.random.RandomState(3)
+    X = rng.randn(K * n, D); y = (rng.rand(K * n) < 0.5).astype(int)
+    d, P = no.dims(model, D)
+    Om, mu = _overflowing_cavity(d)
+    seeds = np.arange(K, dtype=np.int64) + 40
+    draws, last, st = no.nuts_sites(model, X, y, np.arange(K + 1) * n, np.tile(mu, (K, 1)), np.tile(Om, (K, 1, 1)), seeds,
+                                    chains=4, iter=4, warmup=2)
+    first = np.array([[-2.0 + 4.0 * no.rng_probe(int(s), c, 0, 0, 0, 0)[0] for c in range(4)] for s in seeds])
+    retried = np.abs(first) >= 1.0
+    assert retried.any() and (~retried).any()
+    assert np.all(st[:, :, 7] == 0)                                  # nobody failed
+    assert np.all(np.abs(draws[:, :, :, 0]) < 1.0)                   # every chain sits at a finite start
+    # the chains whose first draw was fine start from it; the others from a later one
+    np.testing.assert_allclose(draws[~retried][:, 0, 0], first[~retried], atol=1e-100)
+    assert np.all(np.abs(draws[retried][:, 0, 0] - first[retried]) > 1e-6)
+    # a given start is not replaced: the chain fails
+    bad = np.zeros((K, 4, P)); bad[:, :, 0] = 1.5
+    _, _, st2 = no.nuts_sites(model, X, y, np.arange(K + 1) * n, np.tile(mu, (K, 1)), np.tile(Om, (K, 1, 1)), seeds,
+                              chains=4, iter=4, warmup=2, init=bad)
+    assert np.all(st2[:, :, 7] == 1)
