@@ -362,13 +362,16 @@ def main():
         if on_gpu:
             elib.device_synchronize(local_rank)
 
+    # (EPX_BENCH_SEED_SHIFT: a diagnostic of how far the leapfrog counts of the late iterations depend on the random
+    # streams -- DESIGN.md section 6; the driver's command does not set it and the line says so when it is set)
+    shift = int(os.environ.get('EPX_BENCH_SEED_SHIFT', '0'))
     if warm > 0:
-        info = M.run(warm, verbose=False, seed=1)[0]
+        info = M.run(warm, verbose=False, seed=1 + shift)[0]
         assert info == 0, 'warm-up EP iterations failed with info %d' % info
     n_launch0 = len(M.sampling_ms)
     sync()
     t0 = time.perf_counter()
-    res = M.run(steps, verbose=False, return_analytics=True, seed=2)
+    res = M.run(steps, verbose=False, return_analytics=True, seed=2 + shift)
     sync()
     dt = time.perf_counter() - t0
     info = res[0]
@@ -464,7 +467,7 @@ def main():
                                   args.chains * (args.siter - args.siter // 2), args.prec_estim,
                                   '' if cor else ', uncorrelated covariates',
                                   '' if args.adapt == 'fresh' else ', adapt=carry (NOT the reference\'s per-update re-adaptation)'),
-                   'adapt': args.adapt,
+                   'adapt': args.adapt, **({'seed_shift_DIAGNOSTIC': shift} if shift else {}),
                    'name': args.config if (args.sites, args.D, args.n) == (None, None, None) else 'custom',
                    'parallelism': 'sites sharded over %d GPU(s), 1 RCCL all-reduce/iter inside libepx.so' % world,
                    'rccl_world_size': rccl_world},

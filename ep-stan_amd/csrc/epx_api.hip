@@ -223,7 +223,10 @@ static int ctx_create(int device, int model, int K_local, int D, const int64_t *
     HIPCHK(dalloc(&c->Qi, K * d2)); HIPCHK(dalloc(&c->ri, K * d));
     HIPCHK(dalloc(&c->Qi2, K * d2)); HIPCHK(dalloc(&c->ri2, K * d));
     HIPCHK(dalloc(&c->dQi, K * d2)); HIPCHK(dalloc(&c->dri, K * d));
-    HIPCHK(dalloc(&c->cav_Om, K * d2)); HIPCHK(dalloc(&c->cav_mu, K * d));
+    // (64 columns of zeros behind the last site's cavity precision: the streaming sampler requests its columns a round
+    // ahead, nuts_stream.hip)
+    HIPCHK(dalloc(&c->cav_Om, K * d2 + 64 * d)); HIPCHK(dalloc(&c->cav_mu, K * d));
+    HIPCHK(hipMemset(c->cav_Om + K * d2, 0, 64 * d * sizeof(double)));
     HIPCHK(dalloc(&c->tilt_mean, K * d)); HIPCHK(dalloc(&c->tilt_scatter, K * d2));
     HIPCHK(dalloc(&c->flags, K));
     HIPCHK(dalloc(&c->iflags, 4));
@@ -572,6 +575,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
                 a.stack = c->stack;
             }
             a.no_spec = seven && getenv("EPX_NO_LEAN") ? 1 : 0;       // (diagnostic: layout 7 with the full chain rule in every round)
+            { const char *y = getenv("EPX_YIELD"); a.yield_cycles = seven ? (y ? atoi(y) : EPX_YIELD_DEFAULT) : 0; }      // (A/B: EPX_YIELD=0 turns it off)
             *wpc_out = rw; *dp_out = dp; *nv_out = nv; *layout_out = layout;
             return 0;
         }
@@ -760,7 +764,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
             c->stamps_n = 3 * nblk + 8;
         }
         HIPCHK(hipMemset(c->stamps, 0, (size_t)(3 * nblk + 8) * 64));
-        a.stamps = c->stamps;
+        a.stamps = c->stamps; a.stamps_nrec = nblk;
         c->stamps_last = 3 * nblk + 8;
     }
 #endif

@@ -102,6 +102,12 @@ enum { ST_STEPSIZE_MEAN = 0, ST_STEPSIZE_FINAL, ST_NLEAP, ST_NGRAD, ST_NDIV, ST_
 enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
 enum { MAX_DEPTH_CAP = 12 };
 
+// Default of NutsArgs::yield_cycles: cycles of s_memtime since the state wave's last job went out PLUS the estimate of the
+// bookkeeping still ahead (EPX_SM_YIELD's argument) beyond which the wave lets a pass go by.  A team's pass lasts ~6 500
+// cycles; a lost pass of one chain costs the team a quarter of a pass (~2 000 cycles): DESIGN.md section 3.1g (round 4)
+#ifndef EPX_YIELD_DEFAULT
+#define EPX_YIELD_DEFAULT 8500
+#endif
 struct NutsArgs {
     int gauss;                  // Gaussian-likelihood family (m*a_sg.stan): phi[0] = log sigma, real responses in yd
     const double *yd;
@@ -136,6 +142,7 @@ struct NutsArgs {
     const double *carry_eps;      // K x chains
     const double *carry_metric;   // K x P
     unsigned long long *stamps;   // diagnostic build (-DEPX_STAMPS): per block 8 cycle sums
+    int stamps_nrec;              // ... and the host's count of records per kind (the launched grid may be smaller: looping workgroups add up their pieces)
     double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
     double *stack;                // global memory of the chains of the resident layouts, indexed by (site of the batch,
                                   // chain): stack_stride doubles each -- tree stack (max_depth * (4 NV 64 + 2)) first,
@@ -154,6 +161,10 @@ struct NutsArgs {
     int om_in_lds;
     int off_spec;                 // > 0: LDS offset of the speculative kernel's mailbox / control records (layout 2)
     int no_spec;                  // 1: keep the bookkeeping on the gradient waves (k_nuts) even when off_spec > 0
+    int yield_cycles;             // row team (layout 7): a state wave whose bookkeeping of a finished subtree / transition would
+                                  // end more than this many cycles after its job went out lets the team's pass go by WITHOUT a
+                                  // new job of its chain (one lost pass of one chain) instead of keeping the four chains
+                                  // waiting; 0 = never
     int grp;                      // 1: sites with several groups on layout 2 (k_nuts_spec<..., GRP>, nuts_gradient_groups.inc)
     int off_gl;                   // LDS offset of the site's group row limits (grp)
     // k_nuts_duo (nuts_duo.hip): row waves + state waves with LDS hand-offs

@@ -123,6 +123,17 @@ __device__ inline void wave_lds_exchange() {
 // The TEAM form's hand-off: every wave of the workgroup is in lock step with the passes anyway, so "the jobs are in"
 // and "the results are in" are the two s_barriers of a pass (LDS traffic drained first; vector-memory operations stay
 // in flight).  A waiting wave is parked by the hardware: no polls on the SIMD its partner computes on, no wake-up latency.
+//
+// BARRIER PARITY (the invariant every exit of duo_piece keeps; there is no time-out on an s_barrier, a slip is a hang):
+//   * a pass is exactly two barriers for EVERY wave of the workgroup: B1 "jobs in" (odd), B2 "results in" (even);
+//   * the live-chain word f_live is read by every wave right behind B1 and nowhere else, and changed only between a
+//     B2 and the next B1 (team_leave's decrement comes before its first barrier, which is a B1);
+//   * a ROW wave leaves only behind a B1 at which it read f_live == 0 -- the last barrier of the piece;
+//   * a STATE wave never returns with a barrier outstanding: every `return` below that a state wave can reach is
+//     preceded by team_leave(), which keeps arriving at B1/B2 pairs until it, too, reads f_live == 0 behind a B1.
+//     EPX_CHAIN_EXIT inside the state machine only breaks out of the pass loop, to the team_leave of the epilogue.
+//   Each `return` below carries a [parity] note saying which of these applies.  tests/test_gpu_round4.py's litmus and the
+//   chains < 4 / failed-chain cases of tests/test_gpu_round3.py run every one of them.
 __device__ inline void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ inline double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 __device__ inline void ck_assign(GScal &x, double v) { x = v; }
@@ -329,7 +340,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         if constexpr (BKW) { for (int idx = tid; idx < 2 * MREC; idx += blockDim.x) mbox[idx] = 0.0; }     // (entries beyond P stay 0)
     }
     __syncthreads();                                   // the only workgroup barrier of a piece
-    if (chain >= a.chains) { team_leave(false); return; }
+    if (chain >= a.chains) { team_leave(false); return; }      // [parity] a state wave without a chain: was never counted in f_live, keeps the barriers company
 
     if constexpr (TEAM) {
         if (!is_state) {
@@ -402,7 +413,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 {   // histogram of this wait: bins of 512 cycles, the last one open (fourth record of the stamps)
                     const unsigned long long dw_ = __builtin_amdgcn_s_memtime() - tw0_;
                     int bin_ = (int)(dw_ >> 9); bin_ = bin_ > 15 ? 15 : bin_;
-                    if (a.stamps && wr == 0 && lane == 0 && pass > 1) atomicAdd(&a.stamps[((size_t)3 * gridDim.x) * 8 + bin_], 1ull);
+                    if (a.stamps && wr == 0 && lane == 0 && pass > 1) atomicAdd(&a.stamps[((size_t)3 * a.stamps_nrec) * 8 + bin_], 1ull);
                 }
 #endif
                 STAMP(5);
@@ -411,17 +422,17 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     if (live < 0) { if (lane == 0) atomicOr(a.err, 1); f_res[wr] = DUO_EXIT; }
 #ifdef EPX_STAMPS
                     if (a.stamps && wr == 0 && lane == 0) {
-                        a.stamps[(size_t)blockIdx.x * 8 + 5] = tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] = tacc[6];
-                        for (int i = 0; i < 7; ++i) a.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + i] = tdet[i];
-                        a.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)(pass - 1);
+                        a.stamps[(size_t)blockIdx.x * 8 + 5] += tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] += tacc[6];
+                        for (int i = 0; i < 7; ++i) a.stamps[((size_t)a.stamps_nrec + blockIdx.x) * 8 + i] += tdet[i];
+                        a.stamps[((size_t)a.stamps_nrec + blockIdx.x) * 8 + 7] += (unsigned long long)(pass - 1);
                     }
                     // (third record: every row wave's waiting and working cycles -- who the team waits for)
                     if (a.stamps && lane == 0) {
-                        a.stamps[((size_t)2 * gridDim.x + blockIdx.x) * 8 + wr] = tacc[5];
-                        a.stamps[((size_t)2 * gridDim.x + blockIdx.x) * 8 + 4 + wr] = tacc[6];
+                        a.stamps[((size_t)2 * a.stamps_nrec + blockIdx.x) * 8 + wr] += tacc[5];
+                        a.stamps[((size_t)2 * a.stamps_nrec + blockIdx.x) * 8 + 4 + wr] += tacc[6];
                     }
 #endif
-                    return;
+                    return;                            // [parity] row wave, behind a B1 with f_live == 0: no wave waits at a barrier again
                 }
                 // ---- operands of this pass
                 double bop[KS];
@@ -576,9 +587,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             if (got != seq) {
                 if (got == DUO_TIMEOUT && lane == 0) atomicOr(a.err, 1);
 #ifdef EPX_STAMPS
-                if (a.stamps && team == 0 && wr == 0 && lane == 0) { a.stamps[(size_t)blockIdx.x * 8 + 5] = tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] = tacc[6]; }
+                if (a.stamps && team == 0 && wr == 0 && lane == 0) { a.stamps[(size_t)blockIdx.x * 8 + 5] += tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] += tacc[6]; }
 #endif
-                return;
+                return;                               // [parity] layouts 5/6 only (polled flags with DUO_SPIN_LIMIT, no barriers)
             }
             const duo_lds_f64 *job = slot + JOB;
             const double alpha = job[0];
@@ -688,7 +699,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 const int got = duo_wait(f_job, seq);
                 if (got != seq) {
                     if (got == DUO_TIMEOUT && lane == 0) atomicOr(a.err, 1);
-                    return;
+                    return;                           // [parity] layouts 5/6 only (polled flags)
                 }
                 double ov0 = 0.0, ov1 = 0.0;
                 for (int p0 = 0; p0 < npad; p0 += OUP) {
@@ -871,7 +882,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 piece_checkpoint_out();
                 *f_job = DUO_EXIT;
                 team_leave(true);
-                return;
+                return;                               // [parity] state wave: team_leave has seen the last B1
             }
         }
     }
@@ -988,6 +999,26 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             return ok;
         }
     };
+    // TEAM, barrier hand-offs: the bookkeeping of a finished SUBTREE or TRANSITION (weights, Philox draws, copies through the
+    // cold store: 5 000-17 000 cycles against ~3 500 for an ordinary leaf) outlasts the team's pass, and the row waves and
+    // the three other chains would wait for it at "results in".  At a few points of that code (EPX_SM_YIELD in
+    // nuts_state_machine.inc, each with an estimate of the cycles still ahead) the wave looks at the clock: if the cycles
+    // since its job went out plus the ones ahead exceed a.yield_cycles (a pass plus the wait that is cheaper than a lost
+    // pass of one chain) it takes the two barriers of the pass WITHOUT touching its job -- the row waves work the same job
+    // again, same results -- and goes on with the bookkeeping beside the next pass: one lost pass of ONE chain instead of
+    // a wait of all four.  The chain's arithmetic does not change (same draws); only how many passes the team makes
+    // depends on the clock.
+    // [parity] a yield is one B2 + one B1, taken where the wave's next barrier is a B2: the alternation is kept.
+    unsigned long long t_job = 0;
+    auto sm_yield = [&](int ahead) {
+        if constexpr (TBAR) {
+            if (a.yield_cycles > 0 && __builtin_amdgcn_s_memtime() - t_job + (unsigned long long)ahead > (unsigned long long)a.yield_cycles) {
+                team_barrier();
+                team_barrier();
+                t_job = __builtin_amdgcn_s_memtime();
+            }
+        }
+    };
     // (zq, zp, zg) holds the last finished leapfrog state; `pending`: its bookkeeping is still to run
     double f_lpt = 0.0, f_ks = 0.0, f_ll = 0.0;     // its log density / kinetic energy, not yet summed over the lanes
     bool pending = false;
@@ -1085,7 +1116,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 FORV { const int e = lane + 64 * i; if (e < VN) slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
             }
             ++seq;
-            if constexpr (TBAR) team_barrier(); else duo_publish(f_job, seq);
+            if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish(f_job, seq);
             job_eps = eps_l;
             if (fast_ok) {
                 // (re)build the view of the position in flight from the vectors: start of the chain, or the
@@ -1120,7 +1151,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #define EPX_SM_EXP(x) (TEAM ? exp_d(x) : exp(x))
 #define EPX_SM_LOG(x) (TEAM ? log_ge1_d(x) : log(x))
 #define EPX_SM_LSE2(a_, b_) (TEAM ? log_sum_exp2_lean(a_, b_) : log_sum_exp2(a_, b_))
+#define EPX_SM_YIELD(cycles_ahead_) sm_yield(cycles_ahead_)
 #include "nuts_state_machine.inc"
+#undef EPX_SM_YIELD
 #undef EPX_SM_EXP
 #undef EPX_SM_LOG
 #undef EPX_SM_LSE2
@@ -1246,7 +1279,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 if (v_lane) { slot[VOFF + ve1] = vq1 - vmu1; slot[VOFF + ve3] = vq3 - vmu3; }
             }
             ++seq;
-            if constexpr (TBAR) team_barrier(); else duo_publish(f_job, seq);
+            if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish(f_job, seq);
             job_eps = eps_l;
             fast_pub = true;
             if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
@@ -1401,8 +1434,8 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     }
 #ifdef EPX_STAMPS
     if (a.stamps && team == 0 && lane == 0 && is_state) {
-        for (int i = 0; i < 5; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = tacc[i];
-        a.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)seq;
+        for (int i = 0; i < 5; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] += tacc[i];
+        a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)seq;
     }
 #endif
     if constexpr (BKW) {
@@ -1413,13 +1446,13 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 if (lane == 0) atomicOr(a.err, 2);
                 *f_mail = DUO_EXIT;
             }
-            return;
+            return;                                   // [parity] BKW exists for the polled layouts only (static_assert below)
         }
     }
 
     // ------------------------------------------------------------- epilogue (the state wave owns the chain)
     if constexpr (!BKW) *f_job = DUO_EXIT;             // the row waves leave
-    team_leave(true);
+    team_leave(true);                                  // [parity] every later `return` of this state wave is behind the last B1
     if (bail & 1) {
         if (lane == 0) atomicOr(a.err, 2);
         failed = 2;

@@ -401,26 +401,41 @@ __device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, i
                     }
                 }
             } else if (tid < d) {
-                // thread = row
+                // thread = row.  The columns arrive through a RING of OM_UNROLL registers: a column is multiplied in and its
+                // register is asked for the column OM_UNROLL further on at once, so OM_UNROLL loads per thread are in flight
+                // all the time (round 3 asked for a batch, waited and multiplied: the batch drained before the next one was
+                // requested, ~9 in flight on average, and the d % OM_UNROLL columns of the remainder loop each paid a whole
+                // memory latency).  One running pointer; the requests of the last full round reach up to OM_UNROLL columns
+                // beyond the matrix (the next site's, or the padding behind the last one: epx_api.hip) and are never used.
+                // (the thread index goes through an opaque move: the addresses of the first OM_UNROLL requests do not change from
+                // leapfrog to leapfrog, LLVM computes them once, spills them, and a scratch reload in front of the loop is a
+                // vector-memory operation the loop's first wait then has to cover -- with every request behind it)
                 double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-                const double *omp = Om_g + tid;
+                int tid_o = tid;
+                asm volatile("" : "+v"(tid_o));
+                const double *omp = Om_g + tid_o;
+                double om[OM_UNROLL];
+#pragma unroll
+                for (int u = 0; u < OM_UNROLL; ++u) { om[u] = *omp; omp += d; }
                 int j = 0;
                 for (; j + OM_UNROLL <= d; j += OM_UNROLL) {
-                    double om[OM_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < OM_UNROLL; ++u) om[u] = omp[(size_t)(j + u) * d];
 #pragma unroll
                     for (int u = 0; u < OM_UNROLL; ++u) {
                         const double2 v01 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH);
                         const double2 v23 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH + 2);
                         o0 = fma(om[u], v01.x, o0); o1 = fma(om[u], v01.y, o1);
                         o2 = fma(om[u], v23.x, o2); o3 = fma(om[u], v23.y, o3);
+                        om[u] = *omp; omp += d;
                     }
                 }
-                for (; j < d; ++j) {
-                    const double om = omp[(size_t)j * d];
-                    o0 = fma(om, vs4[j * NCH], o0); o1 = fma(om, vs4[j * NCH + 1], o1);
-                    o2 = fma(om, vs4[j * NCH + 2], o2); o3 = fma(om, vs4[j * NCH + 3], o3);
+#pragma unroll
+                for (int u = 0; u < OM_UNROLL; ++u) {
+                    if (j + u < d) {
+                        const double2 v01 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH);
+                        const double2 v23 = *reinterpret_cast<const double2 *>(vs4 + (j + u) * NCH + 2);
+                        o0 = fma(om[u], v01.x, o0); o1 = fma(om[u], v01.y, o1);
+                        o2 = fma(om[u], v23.x, o2); o3 = fma(om[u], v23.y, o3);
+                    }
                 }
                 *reinterpret_cast<double2 *>(Ovs + tid * NCH) = make_double2(o0, o1);
                 *reinterpret_cast<double2 *>(Ovs + tid * NCH + 2) = make_double2(o2, o3);

@@ -25,7 +25,7 @@ def kernel_rows(db):
     return (con, suf) if n else (None, None)
 
 
-def pmc_sums(d, warmup):
+def pmc_sums(d, warmup, timed):
     """Counter value and duration of the sampler kernels per EP iteration of the profiled command
     (a split launch runs two sampler kernels side by side: both are booked to their iteration);
     returns the per-kernel totals and the list of per-iteration sums of the TIMED iterations."""
@@ -36,32 +36,31 @@ def pmc_sums(d, warmup):
         q = """select s.kernel_name, d.start, d.end, sum(e.value) from rocpd_pmc_event%s e
                join rocpd_kernel_dispatch%s d on e.event_id = d.event_id
                join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id
-               where s.kernel_name like '%%k_nuts%%' group by d.id order by d.start""" % (suf, suf, suf)
+               where s.kernel_name like '%%k_nuts%%' or s.kernel_name like '%%k_moments%%' group by d.id order by d.start""" % (suf, suf, suf)
         rows = con.execute(q).fetchall()
-        if not rows:
+        if not any('k_nuts' in r[0] for r in rows):
             continue
-        # EP iterations = groups of sampler dispatches that overlap in time (a split launch runs two kernels side by side;
-        # the launches of consecutive iterations never overlap).  The first `warmup` ITERATIONS are dropped, whatever
-        # kernels they ran (the first warm-up launches are unpieced / split ones: other kernel names)
-        groups = []
-        for name, t0, t1, val in rows:
-            if groups and t0 < groups[-1]['end']:
-                g = groups[-1]
-            else:
-                g = {'end': t1, 'val': 0.0, 'dur0': t0}
-                groups.append(g)
-            g['end'] = max(g['end'], t1); g['val'] += val
-        per_iter = [g['val'] for g in groups]
-        dur = [(g['end'] - g['dur0']) / 1e6 for g in groups]
+        # EP iterations: every iteration ends with ONE k_moments dispatch behind its sampler launch(es) -- a split launch
+        # runs two sampler kernels, side by side in the bench and one after the other under --pmc (counter collection
+        # serialises dispatches), so overlap in time cannot delimit them.  The first `warmup` ITERATIONS are dropped,
+        # whatever kernels they ran, and so is everything behind the `timed` ones (bench.py's parity iteration)
+        groups, cur = [], None
         kern = {}
-        gi = 0
         for name, t0, t1, val in rows:
-            while gi + 1 < len(groups) and t0 >= groups[gi]['end']:
-                gi += 1
+            if 'k_moments' in name:
+                cur = None
+                continue
+            if cur is None:
+                cur = {'val': 0.0, 'ms': 0.0}
+                groups.append(cur)
+            cur['val'] += val; cur['ms'] += (t1 - t0) / 1e6
+            gi = len(groups) - 1
             k = kern.setdefault(name, {'dispatches': 0, 'sum_KiB': 0.0, 'timed_dispatches': 0})
             k['dispatches'] += 1; k['sum_KiB'] += val
-            k['timed_dispatches'] += int(gi >= warmup)
-        return kern, per_iter[warmup:], dur[warmup:]
+            k['timed_dispatches'] += int(warmup <= gi < warmup + timed)
+        per_iter = [g['val'] for g in groups]
+        dur = [g['ms'] for g in groups]
+        return kern, per_iter[warmup:warmup + timed], dur[warmup:warmup + timed]
     return {}, [], []
 
 
@@ -75,10 +74,10 @@ for name in ('c2', 'c3', 'stream'):
         if kernel_rows(db)[0] is not None:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'scripts', 'rocpd_summary.py'), db,
                                    os.path.join(PROF, '%s_%s_kernel_stats.csv' % (tag, name))])
-    warmup, key = {'c2': (1, [64, 16, 200, 'm4b', 4, 200]), 'c3': (5, [512, 32, 500, 'm4b', 4, 200]),
-                   'stream': (2, [512, 128, 2000, 'm4b', 4, 200])}[name]
-    f, f_it, f_ms = pmc_sums(name + '_fetch', warmup)
-    w, w_it, w_ms = pmc_sums(name + '_write', warmup)
+    warmup, timed, key = {'c2': (1, 3, [64, 16, 200, 'm4b', 4, 200]), 'c3': (5, 20, [512, 32, 500, 'm4b', 4, 200]),
+                          'stream': (2, 2, [512, 128, 2000, 'm4b', 4, 200])}[name]        # (scripts/profile_round.sh's --warmup / --steps)
+    f, f_it, f_ms = pmc_sums(name + '_fetch', warmup, timed)
+    w, w_it, w_ms = pmc_sums(name + '_write', warmup, timed)
     for kind in ('fetch', 'write'):
         for db in dbs(name + '_' + kind):
             if kernel_rows(db)[0] is not None:
