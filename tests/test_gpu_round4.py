@@ -1,6 +1,7 @@
 """Round-4 device tests: the piece hand-off's litmus run under both protocols (the default build and the
--DEPX_PIECE_FENCE one shipped as variants/libepx_fence.so), the out-of-memory fallback of the pieced launch, (the oracle bounds of
-the headline kernel are tightened in place: test_gpu_parity.py, test_gpu_round3.py).
+-DEPX_PIECE_FENCE one shipped as variants/libepx_fence.so), the out-of-memory fallback of the pieced launch, Stan's retry of a
+random start, the row team's yielded passes (the oracle bounds of the headline kernel are tightened in place:
+test_gpu_parity.py, test_gpu_round3.py).
 
 Everything goes through the C ABI (ctypes)."""
 
@@ -101,4 +102,42 @@ def test_random_init_retry_follows_the_oracle(model, D, n, layout):
     assert np.all(cs[:, :, 7] == 0) and stats[:, 7].sum() == 0
     for k in range(K):
         np.testing.assert_allclose(eng.get_draws(k, all_params=True), draws_o[k].reshape(-1, P), rtol=0, atol=1e-100)
+    eng.close()
+
+
+@pytest.mark.parametrize('chains', [4, 3])
+def test_yielded_passes_do_not_change_the_draws(monkeypatch, chains):
+    """Layout 7: a state wave whose subtree / transition bookkeeping would outlast the team's pass lets the pass go by (two
+    barriers, its job untouched: csrc/nuts_duo.hip sm_yield).  Only the number of passes depends on the clock: never
+    (EPX_YIELD=0), by the default budget, and at EVERY yield point (EPX_YIELD=1: the barrier alternation under the most
+    yields there can be, chains leaving at different times and a workgroup with a chain missing included) give the same
+    draws, last states and statistics -- unpieced and from the piece queue."""
+    K, it = 6, 24
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 32, 500, 11, K=K, tight=1000.)
+    eng, Om_dev, mu_dev = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    seeds = np.arange(K, dtype=np.int64) * 5 + 1
+    opts = HipEngine.sampler_opts(chains=chains, iter=it, init='random', layout=7)
+
+    def run(pieces):
+        eng.set_piece_queue(pieces, None)
+        eng.sample_batch(seeds, opts)
+        assert eng.last_layout() == 7
+        return [eng.get_draws(k, all_params=True).copy() for k in range(K)], eng.get_chain_stats(chains).copy()
+
+    ref = {}
+    for y_cycles in ('0', None, '1'):
+        if y_cycles is None:
+            monkeypatch.delenv('EPX_YIELD', raising=False)
+        else:
+            monkeypatch.setenv('EPX_YIELD', y_cycles)
+        for pieces in (0, 4):
+            dr, cs = run(pieces)
+            if not ref:
+                ref['dr'], ref['cs'] = dr, cs
+                continue
+            for k in range(K):
+                np.testing.assert_array_equal(dr[k], ref['dr'][k])
+            np.testing.assert_array_equal(cs, ref['cs'])
+    monkeypatch.delenv('EPX_YIELD', raising=False)
+    eng.set_piece_queue(0)
     eng.close()
