@@ -1547,7 +1547,11 @@ k_nuts_duo(NutsArgs a_by_value) {
 // every a.field into a vector load (876 B of scratch, 13 % slower), and __builtin_amdgcn_kernarg_segment_ptr() is null
 // inside a called function.
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
+#ifdef EPX_PIECE_INLINE     // (A/B: the loop around the INLINED body -- no call, no callee-saved registers)
+__device__ __attribute__((always_inline)) void duo_piece_call(unsigned long long kargs_u, int q_site, int q_t0) {
+#else
 __device__ __attribute__((noinline)) void duo_piece_call(unsigned long long kargs_u, int q_site, int q_t0) {
+#endif
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kargs_u), hi = __builtin_amdgcn_readfirstlane((unsigned)(kargs_u >> 32));
     DuoArgsK *kargs_p = (DuoArgsK *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
     duo_piece<NV, DP, CPB, RW, STL, COLD, true>(kargs_p, (int)threadIdx.x, true, __builtin_amdgcn_readfirstlane(q_site), __builtin_amdgcn_readfirstlane(q_t0));
