@@ -593,11 +593,20 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             }
             const duo_lds_f64 *job = slot + JOB;
             const double alpha = job[0];
-            double beta_l = job[1 + (lane < DP ? lane : 0)];
-            if (lane >= D) beta_l = 0.0;
             double bs[DP];
+            if constexpr (DP <= 16) {
+                // beta to every lane by LDS reads at a uniform address (a broadcast): 8 reads beside the rows' instead of
+                // 32 v_readlane in front of them -- at 16 columns the pass is one round of fixed costs, and the vector
+                // pipe is what it runs on (layout 6 at C2: DESIGN.md section 3.1f).  The writer keeps the entries beyond
+                // D at zero.  32 columns stay on scalar registers: 64 more vector registers would spill the row wave.
 #pragma unroll
-            for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
+                for (int j = 0; j < DP; ++j) bs[j] = job[1 + j];
+            } else {
+                double beta_l = job[1 + (lane < DP ? lane : 0)];
+                if (lane >= D) beta_l = 0.0;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) bs[j] = readlane_d(beta_l, j);
+            }
             // ---- fused row pass: f = alpha + x.beta, g = y - sigmoid(f), acc += g x   (nuts_gradient.inc)
             double acc[DP];
 #pragma unroll
@@ -1109,7 +1118,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             }
             // ---- hand (alpha, beta) to the row waves
             duo_lds_f64 *job = slot + JOB;
-            if constexpr (TEAM) beta_l = lane < D ? beta_l : 0.0;         // (the padding columns of the B operand stay finite)
+            if constexpr (TEAM || DP <= 16) beta_l = lane < D ? beta_l : 0.0;         // (the padding columns of the B operand stay finite; 16 columns: the row waves read the entries as they are)
             if (lane < DP) job[BOFF + lane] = beta_l;
             if (lane == 0) job[0] = alpha;
             if constexpr (RW > 1) {
@@ -1271,7 +1280,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             vex3 = exp_d_vc(vq3);
             const double ba = vq1 + vq2 * vex3;
             duo_lds_f64 *job = slot + JOB;
-            if (lane < DP) job[BOFF + lane] = (!TEAM || lane < D) ? ba : 0.0;
+            if (lane < DP) job[BOFF + lane] = ((!TEAM && DP > 16) || lane < D) ? ba : 0.0;
             if (lane == LA) job[0] = ba;
             if constexpr (RW > 1) {
                 // v = phi - mu of the next position for the row waves' cavity term: the view holds ALL of phi
