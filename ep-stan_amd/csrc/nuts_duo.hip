@@ -42,6 +42,9 @@ namespace epx {
 #ifndef EPX_DUO_SLEEP
 #define EPX_DUO_SLEEP 1
 #endif
+#ifndef EPX_DUO_SLEEP_BKW
+#define EPX_DUO_SLEEP_BKW 0      // layout 6 (one chain per workgroup): the waves that wait on the critical chain look again at once
+#endif
 #ifndef EPX_TEAM_BARRIER
 #define EPX_TEAM_BARRIER 1       // 1: the TEAM form's hand-offs are workgroup barriers (two per pass); 0: polled LDS words (A/B)
 #endif
@@ -147,6 +150,14 @@ __device__ inline void duo_publish(duo_flag_t *flag, int v) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     *flag = v;
+}
+// The same without the wait, for the hand-offs on the critical chain of the one-chain-per-workgroup form (layout 6): the LDS
+// performs the operations of ONE wave in issue order (which is what lets `lgkmcnt(N)` count them), so the word's store is
+// performed behind the data's stores of the same wave, and a reader's data reads are issued behind its read of the word.
+template <bool NOWAIT>
+__device__ inline void duo_publish_c(duo_flag_t *flag, int v) {
+    if constexpr (NOWAIT) { asm volatile("" ::: "memory"); *flag = v; }
+    else duo_publish(flag, v);
 }
 
 // In-kernel cycle stamps exist only in the diagnostic build (-DEPX_STAMPS); its run time is never
@@ -581,8 +592,56 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         // the row pass is the longest link of a leapfrog's critical chain: it wins the SIMD's issue arbitration
         // against the state wave (of another chain) it shares the SIMD with, whose bookkeeping has slack
         __builtin_amdgcn_s_setprio(EPX_PRIO_R);
+        // One chain per workgroup, a site of at most 2 x 64 x RW rows (C2: 200): a lane's two rows are the same in every
+        // pass -- they stay in registers for the whole piece instead of being read from LDS behind every job (16 reads
+        // and their latency on the critical chain of the leapfrog)
+        constexpr bool KEEP_ROWS = BKW && DP <= 16;
+        const bool one_round = KEEP_ROWS && n <= 2 * 64 * RW;
+        double xk0[KEEP_ROWS ? DP : 1], xk1[KEEP_ROWS ? DP : 1];
+        bool k_has = false, k_two = false;
+        if constexpr (KEEP_ROWS) {
+            const int r = wr * 64 + lane, r1 = r + 64 * RW;
+            k_has = one_round && r < n; k_two = r1 < n;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) { xk0[j] = 0.0; xk1[j] = 0.0; }
+            if (k_has) {
+                const int r1c = k_two ? r1 : r;
+                const double2 *row0p = reinterpret_cast<const double2 *>(Xs + (size_t)r * DP);
+                const double2 *row1p = reinterpret_cast<const double2 *>(Xs + (size_t)r1c * DP);
+                const int sw0 = (r / RPL) & (SPR - 1), sw1 = (r1c / RPL) & (SPR - 1);
+#pragma unroll
+                for (int jp = 0; jp < SPR; ++jp) {
+                    const double2 v = row0p[jp ^ sw0], w = row1p[jp ^ sw1];
+                    xk0[2 * jp] = v.x; xk0[2 * jp + 1] = v.y;
+                    xk1[2 * jp] = w.x; xk1[2 * jp + 1] = w.y;
+                }
+            }
+        }
         for (int seq = 1;; ++seq) {
-            const int got = duo_wait(f_job, seq);
+            const duo_lds_f64 *job = slot + JOB;
+            double alpha = 0.0;
+            double bs[DP];
+            int got;
+            if constexpr (BKW && DP <= 16) {
+                // One chain per workgroup (layout 6): every look at the job's word asks for the job's DATA as well -- the LDS
+                // serves a wave's reads in order, so data requested behind a word that reads `seq` is that job's -- and the
+                // look that finds the word finds (alpha, beta) with it: one LDS round trip less on the critical chain of a
+                // leapfrog that is nothing but such links.  The compiler barriers keep
+                // the reads inside the look and in this order.
+                got = DUO_TIMEOUT;
+                for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+                    asm volatile("" ::: "memory");
+                    const int v = *f_job;
+                    asm volatile("" ::: "memory");
+                    alpha = job[0];
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) bs[j] = job[1 + j];
+                    asm volatile("" ::: "memory");
+                    const int vu = __builtin_amdgcn_readfirstlane(v);
+                    if (vu == seq || vu == DUO_EXIT) { got = vu; break; }
+                    __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
+                }
+            } else got = duo_wait(f_job, seq);
             STAMP(5);
             if (got != seq) {
                 if (got == DUO_TIMEOUT && lane == 0) atomicOr(a.err, 1);
@@ -591,10 +650,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #endif
                 return;                               // [parity] layouts 5/6 only (polled flags with DUO_SPIN_LIMIT, no barriers)
             }
-            const duo_lds_f64 *job = slot + JOB;
-            const double alpha = job[0];
-            double bs[DP];
-            if constexpr (DP <= 16) {
+            if constexpr (!(BKW && DP <= 16)) alpha = job[0];
+            if constexpr (BKW && DP <= 16) {
+                // (beta came with the look above)
+            } else if constexpr (DP <= 16) {
                 // beta to every lane by LDS reads at a uniform address (a broadcast): 8 reads beside the rows' instead of
                 // 32 v_readlane in front of them -- at 16 columns the pass is one round of fixed costs, and the vector
                 // pipe is what it runs on (layout 6 at C2: DESIGN.md section 3.1f).  The writer keeps the entries beyond
@@ -662,6 +721,12 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 }
                 r += nfull << 7;
             }
+            if constexpr (KEEP_ROWS) {
+                if (one_round) {
+                    if (k_has) round2(xk0, xk1, k_two);
+                    r = n;                                   // (no other round)
+                }
+            }
             // the other rounds.  A lane whose second row is beyond n re-reads its first row and adds zeros.
             for (; r < n; r += 2 * 64 * RW) {
                 const int r1 = r + 64 * RW;
@@ -685,11 +750,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             }
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
-            wave_sum2(da, ll);
+            // (layout 6 -- one chain per workgroup, two row waves whose partial sums the state wave adds -- never had
+            // layout 1's order of additions: its two sums take the packed form, 22 instead of 40 vector instructions of
+            // a pass that is all fixed costs; layout 5 keeps wave_sum2 and with it the draws of layout 1, bit for bit)
+            if constexpr (BKW) wave_sum2_packed(da, ll); else wave_sum2(da, ll);
             duo_lds_f64 *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
             if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
             if (lane == 0) { res[DP] = da; res[DP + 1] = ll; }
-            duo_publish(f_res + wr, seq);
+            duo_publish_c<BKW>(f_res + wr, seq);
             STAMP(6);
         }
     }
@@ -738,7 +806,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 }
                 slot[OVOFF + lane] = lane < d ? ov0 : 0.0;
                 if constexpr (NV > 1) slot[OVOFF + 64 + lane] = 64 + lane < d ? ov1 : 0.0;
-                duo_publish(f_ov, seq);
+                duo_publish_c<BKW>(f_ov, seq);
             }
         }
     }
@@ -1002,6 +1070,19 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     auto rows_in = [&](int sq_) -> bool {               // the row waves' results of job sq_ are in
         if constexpr (TBAR) { team_barrier(); return true; }
         else if constexpr (TEAM) return team_wait_rows(f_res, sq_, lane) == sq_;
+        else if constexpr (BKW) {
+            // one chain per workgroup: the words of the two row waves AND of the cavity-term wave in ONE look (lane w
+            // reads f_res[w], lane RW reads f_ov, a ballot says whether all stand at sq_).  Three waits one after the other
+            // were three LDS round trips on the critical stretch even when the second and third word had long been there.
+            duo_flag_t *mine = lane < RW ? f_res + lane : (lane == RW ? f_ov : f_res);
+            for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+                const int v = *mine;
+                if (__builtin_amdgcn_ballot_w64(v == sq_) == ~0ull) { asm volatile("" ::: "memory"); return true; }
+                if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) return false;
+                __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
+            }
+            return false;
+        }
         else {
             bool ok = true;
             for (int w = 0; w < RW; ++w) ok &= duo_wait(f_res + w, sq_) == sq_;
@@ -1074,8 +1155,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             if (ctl < 0) { bail = 1; break; }
             if (ctl != gen) {
                 if (fast_pub) {                    // the job in flight continues a trajectory nobody wants: let it land
-                    if (!rows_in(seq)) bail = 1;
-                    if (duo_wait(f_ov, seq) != seq) bail = 1;       // (the cavity-term wave reads v: it must be done, too)
+                    if (!rows_in(seq)) bail = 1;                    // (rows AND cavity-term wave: that one reads v, it must be done, too)
                     if (bail) break;
                 }
                 const double *cr = ctrl + (ctl & 1) * CREC;
@@ -1125,7 +1205,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 FORV { const int e = lane + 64 * i; if (e < VN) slot[VOFF + e] = e < d ? sq.v[i] - mu.v[i] : 0.0; }       // v for the row waves' cavity term
             }
             ++seq;
-            if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish(f_job, seq);
+            if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish_c<BKW>(f_job, seq);
             job_eps = eps_l;
             if (fast_ok) {
                 // (re)build the view of the position in flight from the vectors: start of the chain, or the
@@ -1248,13 +1328,36 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 
         STAMP(2);
         // ---- their sums are in: chain rule back to (phi, eta, etb), second half of the leapfrog
-        if (!rows_in(seq)) bail = 1;
-        if constexpr (BKW) { if (duo_wait(f_ov, seq) != seq) bail = 1; }
+        // BKW: the look that finds the three words (row waves, cavity-term wave) has asked for the sums behind them as
+        // well -- same reasoning as on the row waves' side -- in xtg's order of additions (bit-identical)
+        double pf_da = 0.0, pf_ll = 0.0, pf_t = 0.0, pf_vo1 = 0.0, pf_vo3 = 0.0;
+        if constexpr (BKW) {
+            duo_flag_t *mine = lane < RW ? f_res + lane : (lane == RW ? f_ov : f_res);
+            const int tj = lane == LA ? DP : (lane < DP ? lane : 0);
+            bool ok = false;
+            for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+                asm volatile("" ::: "memory");
+                const int v = *mine;
+                asm volatile("" ::: "memory");
+                pf_da = 0.0; pf_ll = 0.0; pf_t = 0.0;
+#pragma unroll
+                for (int w = 0; w < RW; ++w) {
+                    pf_da += slot[RESO + w * RREC + DP]; pf_ll += slot[RESO + w * RREC + DP + 1]; pf_t += slot[RESO + w * RREC + tj];
+                }
+                pf_vo1 = slot[OVOFF + ve1]; pf_vo3 = slot[OVOFF + ve3];
+                asm volatile("" ::: "memory");
+                if (__builtin_amdgcn_ballot_w64(v == seq) == ~0ull) { ok = true; break; }
+                if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) break;
+                __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
+            }
+            if (!ok) bail = 1;
+        } else if (!rows_in(seq)) bail = 1;
         STAMP(3);
         __builtin_amdgcn_s_setprio(EPX_PRIO_S_CRIT);    // chain rule, half kick, drift, publish: the row waves wait for it
         if (bail) break;
         double da, ll, dbf[NV];
-        if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
+        if constexpr (BKW) { da = pf_da; ll = pf_ll; }
+        else if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
         else {
             da = 0.0; ll = 0.0;
 #pragma unroll
@@ -1265,10 +1368,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         if constexpr (RW > 1) {
             // the cavity term of this position, from its own wave (lean: only the view's coordinates of it)
             if (!lean) { FORV { const int e = lane + 64 * i; Ov.v[i] = e < VN ? slot[OVOFF + (e < VN ? e : 0)] : 0.0; } }
-            if (fast_ok) { vo1 = slot[OVOFF + ve1]; vo3 = slot[OVOFF + ve3]; }
+            if (fast_ok) { if constexpr (BKW) { vo1 = pf_vo1; vo3 = pf_vo3; } else { vo1 = slot[OVOFF + ve1]; vo3 = slot[OVOFF + ve3]; } }
         }
         if (fast_ok) {
-            const double t = xtg(lane == LA ? DP : (lane < DP ? lane : 0));     // lane LA: sum g (as `da` above)
+            const double t = BKW ? pf_t : xtg(lane == LA ? DP : (lane < DP ? lane : 0));     // lane LA: sum g (as `da` above)
             const double pr2 = laplace ? (double)((vq2 > 0) - (vq2 < 0)) : vq2;
             const double g1 = -vo1 + t, g2 = t * vex3 - pr2, g3 = -vo3 + t * vq2 * vex3;
             // second half of this leapfrog, first half of the next one (the loop top's formulas, element by element)
@@ -1288,7 +1391,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 if (v_lane) { slot[VOFF + ve1] = vq1 - vmu1; slot[VOFF + ve3] = vq3 - vmu3; }
             }
             ++seq;
-            if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish(f_job, seq);
+            if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish_c<BKW>(f_job, seq);
             job_eps = eps_l;
             fast_pub = true;
             if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
