@@ -141,3 +141,35 @@ def test_yielded_passes_do_not_change_the_draws(monkeypatch, chains):
     monkeypatch.delenv('EPX_YIELD', raising=False)
     eng.set_piece_queue(0)
     eng.close()
+
+
+def test_layout6_handoffs_repeat_bit_for_bit():
+    """Layout 6 (one chain per workgroup, C2's kernel): a look at a hand-off word asks for the data behind it as well, and
+    words are stored without waiting for the data stores of the same wave -- both lean on the LDS performing one wave's
+    operations in issue order (csrc/nuts_duo.hip, duo_publish_c).  A read that overtook its word would show as a draw
+    that depends on timing: 64 sites x 4 chains (every CU busy, as in the C2 launch), 40 repetitions of the launch, every
+    repetition bit-equal to the first (layout 6 against the oracle: test_gpu_round2.py, test_gpu_parity.py)."""
+    K, D, n, it = 64, 16, 200, 80
+    rng = np.random.RandomState(12)
+    X = rng.randn(K * n, D)
+    y = (rng.rand(K * n) < 0.5).astype(int)
+    eng = HipEngine('m4b_sg', X, y, np.arange(K + 1) * n)
+    d, P = eng.d, eng.P
+    eng.set_prior(np.eye(d), np.zeros(d))
+    eng.set_global(np.eye(d) * 3.0, np.zeros(d))
+    assert np.all(eng.cavity_batch(0))
+    seeds = np.arange(K, dtype=np.int64) * 11 + 7
+    opts = HipEngine.sampler_opts(chains=4, iter=it, init='random', layout=6)
+
+    def state():
+        return np.stack([eng.get_draws(k, all_params=True) for k in range(K)]), eng.get_chain_stats(4).copy()
+
+    eng.sample_batch(seeds, opts)
+    assert eng.last_layout() == 6
+    dr0, cs0 = state()
+    assert np.all(np.isfinite(dr0)) and np.all(cs0[:, :, 7] == 0)
+    for rep in range(40):
+        eng.sample_batch(seeds, opts)
+        dr, cs = state()
+        assert np.array_equal(dr, dr0) and np.array_equal(cs, cs0), rep
+    eng.close()
