@@ -42,6 +42,15 @@ namespace epx {
 #ifndef EPX_DUO_SLEEP
 #define EPX_DUO_SLEEP 1
 #endif
+#ifndef EPX_T7_ROWPREF
+#define EPX_T7_ROWPREF 1         // row team: the live word is looked at behind the cavity term, not in front of the operands' reads (A/B)
+#endif
+#ifndef EPX_T7_LATELL
+#define EPX_T7_LATELL 0          // row team, lean rounds: sum g / log-likelihood fetched behind the job's publication (A/B)
+#endif
+#ifndef EPX_T7_EARLYT
+#define EPX_T7_EARLYT 1          // row team: X'g and the cavity term of the view's lanes requested first behind "the results are in" (A/B)
+#endif
 #ifndef EPX_DUO_SLEEP_BKW
 #define EPX_DUO_SLEEP_BKW 0      // layout 6 (one chain per workgroup): the waves that wait on the critical chain look again at once
 #endif
@@ -417,8 +426,19 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #ifdef EPX_STAMPS
                 const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
 #endif
-                int live;
-                if constexpr (TBAR) { team_barrier(); live = __builtin_amdgcn_readfirstlane(*f_live); }
+                // The look at the live word behind "the jobs are in" used to be an LDS round trip of its own IN FRONT of the
+                // operands' reads (read, wait, branch, then the reads): the word is requested here and looked at behind the
+                // cavity term, whose operands' reads go out right behind it.  A pass that finds no chain left has then
+                // multiplied stale operands into a slot nobody reads.  (Requesting the operands in front of the look -- as
+                // volatile reads, or pinned by empty statements -- was measured slower, -1.8 % and -2.5 %: the wait for the
+                // look then covers every operand and the rows' reads start behind it.)
+                int live, live_raw = 1;
+                double bop[KS];
+                double alpha_c = 0.0;
+                double vb[NJ];
+                constexpr bool ROWPREF = TBAR && EPX_T7_ROWPREF;
+                if constexpr (TBAR && !ROWPREF) { team_barrier(); live = __builtin_amdgcn_readfirstlane(*f_live); }
+                else if constexpr (ROWPREF) { team_barrier(); live_raw = *f_live; live = 1; }
                 else live = team_wait_jobs(f_job, pass, nch, lane);
 #ifdef EPX_STAMPS
                 {   // histogram of this wait: bins of 512 cycles, the last one open (fourth record of the stamps)
@@ -446,18 +466,16 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     return;                            // [parity] row wave, behind a B1 with f_live == 0: no wave waits at a barrier again
                 }
                 // ---- operands of this pass
-                double bop[KS];
 #pragma unroll
                 for (int r = 0; r < NRD; ++r) {
                     const lds_v2f64 v = *(lds_v2f64_p)(sl + JOB + BOFF + 8 * r + 2 * hi);
                     bop[2 * r] = v.x; bop[2 * r + 1] = v.y;
                 }
-                const double alpha_c = sl[JOB];
+                alpha_c = sl[JOB];
                 // ---- cavity term Omega V of the four chains
                 if (g_on) {
                     // (all B operands requested first: a product behind its own LDS round trip would pay the latency 17 times;
                     // k-steps beyond d meet zero A operands)
-                    double vb[NJ];
 #pragma unroll
                     for (int J = 0; J < NJ; ++J) vb[J] = sl[VOFF + 4 * J + hi];
                     double acc = 0.0, acc1 = 0.0;             // (two chains: a dependent product issues 4 cycles later than a free one)
@@ -479,6 +497,22 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     if (bb == 0) sl[OVOFF + 16 * NGF + hi] = acc;
                 }
                 TSTAMP(1);
+                if constexpr (ROWPREF) {
+                    if (__builtin_amdgcn_readfirstlane(live_raw) <= 0) {
+#ifdef EPX_STAMPS
+                        if (a.stamps && wr == 0 && lane == 0) {
+                            a.stamps[(size_t)blockIdx.x * 8 + 5] += tacc[5]; a.stamps[(size_t)blockIdx.x * 8 + 6] += tacc[6];
+                            for (int i = 0; i < 7; ++i) a.stamps[((size_t)a.stamps_nrec + blockIdx.x) * 8 + i] += tdet[i];
+                            a.stamps[((size_t)a.stamps_nrec + blockIdx.x) * 8 + 7] += (unsigned long long)(pass - 1);
+                        }
+                        if (a.stamps && lane == 0) {
+                            a.stamps[((size_t)2 * a.stamps_nrec + blockIdx.x) * 8 + wr] += tacc[5];
+                            a.stamps[((size_t)2 * a.stamps_nrec + blockIdx.x) * 8 + 4 + wr] += tacc[6];
+                        }
+#endif
+                        return;                        // [parity] row wave, behind a B1 with f_live == 0 (the look deferred behind the cavity term)
+                    }
+                }
                 // ---- the rows: two tiles per round (their logistic terms overlap).  The LDS reads run ahead of their
                 // use: the backward operands of a round and the forward operands of the NEXT round are requested
                 // before the round's logistic terms, so no product waits for an LDS round trip.
@@ -1355,23 +1389,40 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         STAMP(3);
         __builtin_amdgcn_s_setprio(EPX_PRIO_S_CRIT);    // chain rule, half kick, drift, publish: the row waves wait for it
         if (bail) break;
-        double da, ll, dbf[NV];
-        if constexpr (BKW) { da = pf_da; ll = pf_ll; }
-        else if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
-        else {
-            da = 0.0; ll = 0.0;
-#pragma unroll
-            for (int w = 0; w < RW; ++w) { da += slot[RESO + w * RREC + DP]; ll += slot[RESO + w * RREC + DP + 1]; }
+        // (TEAM, lean rounds: the next job needs X'g and the cavity term, not sum g and the log-likelihood -- those are for
+        // the books.  Summed in front of the view update they were an LDS round trip of their own: the compiler issues the
+        // reads of X'g only behind their waits.  They are fetched behind the job's publication instead; the row waves
+        // write their results at the END of the pass that starts there, thousands of cycles later.)
+        // (TEAM: the reads the view update waits for -- X'g of the lane's column, the cavity term at the view's two
+        // coordinates -- go out FIRST, in the block behind the barrier, with the sums' reads behind them: left where the
+        // source has them, behind two branches, they were issued only after the sums' waits: a second LDS round trip)
+        double et = 0.0, evo1 = 0.0, evo3 = 0.0;
+        constexpr bool EARLYT = TEAM && TBAR && EPX_T7_EARLYT;
+        if constexpr (EARLYT) {
+            et = xtg(lane == LA ? DP : (lane < DP ? lane : 0));
+            evo1 = slot[OVOFF + ve1]; evo3 = slot[OVOFF + ve3];
         }
+        const bool late_ll = TEAM && TBAR && EPX_T7_LATELL && lean && fast_ok;
+        double da = 0.0, ll = 0.0, dbf[NV];
+        auto fetch_da_ll = [&]() {
+            if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
+            else {
+                da = 0.0; ll = 0.0;
+#pragma unroll
+                for (int w = 0; w < RW; ++w) { da += slot[RESO + w * RREC + DP]; ll += slot[RESO + w * RREC + DP + 1]; }
+            }
+        };
+        if constexpr (BKW) { da = pf_da; ll = pf_ll; }
+        else if (!late_ll) fetch_da_ll();
         if (!lean) { FORV dbf[i] = xtg(jdx[i]); }   // (the shortcut reuses the slot for the next job: fetch first)
         else { FORV dbf[i] = 0.0; }
         if constexpr (RW > 1) {
             // the cavity term of this position, from its own wave (lean: only the view's coordinates of it)
             if (!lean) { FORV { const int e = lane + 64 * i; Ov.v[i] = e < VN ? slot[OVOFF + (e < VN ? e : 0)] : 0.0; } }
-            if (fast_ok) { if constexpr (BKW) { vo1 = pf_vo1; vo3 = pf_vo3; } else { vo1 = slot[OVOFF + ve1]; vo3 = slot[OVOFF + ve3]; } }
+            if (fast_ok) { if constexpr (BKW) { vo1 = pf_vo1; vo3 = pf_vo3; } else if constexpr (EARLYT) { vo1 = evo1; vo3 = evo3; } else { vo1 = slot[OVOFF + ve1]; vo3 = slot[OVOFF + ve3]; } }
         }
         if (fast_ok) {
-            const double t = BKW ? pf_t : xtg(lane == LA ? DP : (lane < DP ? lane : 0));     // lane LA: sum g (as `da` above)
+            const double t = BKW ? pf_t : (EARLYT ? et : xtg(lane == LA ? DP : (lane < DP ? lane : 0)));     // lane LA: sum g (as `da` above)
             const double pr2 = laplace ? (double)((vq2 > 0) - (vq2 < 0)) : vq2;
             const double g1 = -vo1 + t, g2 = t * vex3 - pr2, g3 = -vo3 + t * vq2 * vex3;
             // second half of this leapfrog, first half of the next one (the loop top's formulas, element by element)
@@ -1392,6 +1443,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             }
             ++seq;
             if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish_c<BKW>(f_job, seq);
+            if constexpr (TEAM) { if (late_ll) fetch_da_ll(); }
             job_eps = eps_l;
             fast_pub = true;
             if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
