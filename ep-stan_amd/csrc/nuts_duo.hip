@@ -48,6 +48,9 @@ namespace epx {
 #ifndef EPX_T7_LATELL
 #define EPX_T7_LATELL 0          // row team, lean rounds: sum g / log-likelihood fetched behind the job's publication (A/B)
 #endif
+#ifndef EPX_T7_LLAFTER
+#define EPX_T7_LLAFTER 1         // row team: the pass's log-likelihood is formed BEHIND "the results are in" and read by the books behind the next job (A/B)
+#endif
 #ifndef EPX_T7_EARLYT
 #define EPX_T7_EARLYT 1          // row team: X'g and the cavity term of the view's lanes requested first behind "the results are in" (A/B)
 #endif
@@ -592,16 +595,34 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 // (a product with ones: D[.][j] = sum over k of B[k][j])
 #pragma unroll
                 for (int c = 0; c < KS; ++c) { gacc[c] += dpp_d<0x124>(gacc[c]); gacc[c] += dpp_d<0x128>(gacc[c]); }
+                duo_lds_f64 *res = sl + RESO + wr * RREC;
+                if constexpr (TBAR && EPX_T7_LLAFTER) {
+                    // The next job needs X'g and sum g; the log-likelihood -- a logarithm of 27 dependent instructions, a
+                    // product with ones and two exchanges behind it -- is for the books only: it is formed behind "the
+                    // results are in", in the stretch this wave waits through anyway, and read by the state wave behind the
+                    // next job's barrier (which this wave passes only after the store).
+                    double dz = mfma4(1.0, dsum, 0.0);
+                    dz += dpp_d<0x124>(dz); dz += dpp_d<0x128>(dz);
+                    if (bb == 0) {
+#pragma unroll
+                        for (int c = 0; c < KS; ++c) res[8 * (c >> 1) + 2 * hi + (c & 1)] = gacc[c];
+                        if (hi == 0) res[DP] = dz;
+                    }
+                    team_barrier();
+                    double lz = mfma4(1.0, lsum - log_ge1_d_vc(wprod), 0.0);
+                    lz += dpp_d<0x124>(lz); lz += dpp_d<0x128>(lz);
+                    if (bb == 0 && hi == 0) res[DP + 1] = lz;
+                } else {
                 double dz = mfma4(1.0, dsum, 0.0), lz = mfma4(1.0, lsum - log_ge1_d_vc(wprod), 0.0);
                 dz += dpp_d<0x124>(dz); lz += dpp_d<0x124>(lz);
                 dz += dpp_d<0x128>(dz); lz += dpp_d<0x128>(lz);
-                duo_lds_f64 *res = sl + RESO + wr * RREC;
                 if (bb == 0) {
 #pragma unroll
                     for (int c = 0; c < KS; ++c) res[8 * (c >> 1) + 2 * hi + (c & 1)] = gacc[c];
                     if (hi == 0) { res[DP] = dz; res[DP + 1] = lz; }
                 }
                 if constexpr (TBAR) team_barrier(); else duo_publish(f_res + wr, pass);
+                }
                 STAMP(6);
                 TSTAMP(6);
             }
@@ -1257,6 +1278,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         if (!BKW && pending) {
             pending = false;
             // the two reductions only the bookkeeping needs: off the critical path
+            if constexpr (TEAM && TBAR && EPX_T7_LLAFTER) {
+                // (the row waves stored the log-likelihood of that leapfrog behind its "results are in" and in front of the
+                // barrier just passed)
+                double l4 = 0.0;
+#pragma unroll
+                for (int w = 0; w < RW; ++w) l4 += slot[RESO + w * RREC + DP + 1];
+                f_ll = uniform_d(l4);
+            }
             if constexpr (TEAM) wave_sum2_packed(f_lpt, f_ks); else wave_sum2(f_lpt, f_ks);
             zlp = f_lpt + f_ll;
             const double kin = 0.5 * f_ks;
@@ -1409,7 +1438,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             else {
                 da = 0.0; ll = 0.0;
 #pragma unroll
-                for (int w = 0; w < RW; ++w) { da += slot[RESO + w * RREC + DP]; ll += slot[RESO + w * RREC + DP + 1]; }
+                for (int w = 0; w < RW; ++w) {
+                    da += slot[RESO + w * RREC + DP];
+                    if constexpr (!(TEAM && TBAR && EPX_T7_LLAFTER)) ll += slot[RESO + w * RREC + DP + 1];
+                }
             }
         };
         if constexpr (BKW) { da = pf_da; ll = pf_ll; }
