@@ -54,6 +54,9 @@ namespace epx {
 #ifndef EPX_T7_EARLYT
 #define EPX_T7_EARLYT 1          // row team: X'g and the cavity term of the view's lanes requested first behind "the results are in" (A/B)
 #endif
+#ifndef EPX_L6_LLAFTER
+#define EPX_L6_LLAFTER 0         // layout 6: the row waves publish X'g and sum g first, the log-likelihood under the same word + DUO_LLBIT (A/B)
+#endif
 #ifndef EPX_DUO_SLEEP_BKW
 #define EPX_DUO_SLEEP_BKW 0      // layout 6 (one chain per workgroup): the waves that wait on the critical chain look again at once
 #endif
@@ -79,6 +82,7 @@ __device__ inline duo_flag_t *duo_flags_at(const void *generic) { return reinter
 __device__ inline duo_lds_f64 *duo_lds_at(const void *generic) { return reinterpret_cast<duo_lds_f64 *>((uintptr_t)(unsigned)(size_t)generic); }
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23, DUO_NO_MORE = 1 << 30 };
 enum { DUO_RESTART = 1, DUO_LEAVE = 2 };
+enum { DUO_LLBIT = 1 << 29 };      // layout 6: a row wave's word reads seq when its sums are in, seq | DUO_LLBIT when its log-likelihood is in as well
 
 __device__ inline int duo_wait(duo_flag_t *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -803,16 +807,32 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 }
                 round2(x0, x1, two);
             }
+            duo_lds_f64 *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
+            if constexpr (BKW && EPX_L6_LLAFTER) {
+                // Layout 6: the next job needs X'g and sum g; the log-likelihood -- a logarithm of ~27 dependent instructions
+                // and a wave sum -- is for the books.  The sums go out first (word = seq), the log-likelihood behind them
+                // (word = seq | DUO_LLBIT); the state wave looks for the second word only when it writes the mailbox entry,
+                // behind the next job's publication.  (Layout 6 never had layout 1's order of additions.)
+                butterfly<DP, 5>(acc, lane);
+                da = wave_sum(da);
+                if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
+                if (lane == 0) res[DP] = da;
+                duo_publish_c<true>(f_res + wr, seq);
+                ll -= log_ge1_d(wprod);
+                ll = wave_sum(ll);
+                if (lane == 0) res[DP + 1] = ll;
+                duo_publish_c<true>(f_res + wr, seq | DUO_LLBIT);
+            } else {
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
             // (layout 6 -- one chain per workgroup, two row waves whose partial sums the state wave adds -- never had
             // layout 1's order of additions: its two sums take the packed form, 22 instead of 40 vector instructions of
             // a pass that is all fixed costs; layout 5 keeps wave_sum2 and with it the draws of layout 1, bit for bit)
             if constexpr (BKW) wave_sum2_packed(da, ll); else wave_sum2(da, ll);
-            duo_lds_f64 *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
             if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
             if (lane == 0) { res[DP] = da; res[DP + 1] = ll; }
             duo_publish_c<BKW>(f_res + wr, seq);
+            }
             STAMP(6);
         }
     }
@@ -1130,9 +1150,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             // reads f_res[w], lane RW reads f_ov, a ballot says whether all stand at sq_).  Three waits one after the other
             // were three LDS round trips on the critical stretch even when the second and third word had long been there.
             duo_flag_t *mine = lane < RW ? f_res + lane : (lane == RW ? f_ov : f_res);
+            const int llm = (EPX_L6_LLAFTER && lane != RW) ? ~(int)DUO_LLBIT : ~0;      // (a row wave's word may already carry the log-likelihood's bit)
             for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
                 const int v = *mine;
-                if (__builtin_amdgcn_ballot_w64(v == sq_) == ~0ull) { asm volatile("" ::: "memory"); return true; }
+                if (__builtin_amdgcn_ballot_w64(v != DUO_EXIT && (v & llm) == sq_) == ~0ull) { asm volatile("" ::: "memory"); return true; }
                 if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) return false;
                 __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
             }
@@ -1143,6 +1164,24 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             for (int w = 0; w < RW; ++w) ok &= duo_wait(f_res + w, sq_) == sq_;
             return ok;
         }
+    };
+    // Layout 6 with EPX_L6_LLAFTER: the log-likelihood of job `rs` -- the row waves' words read rs | DUO_LLBIT once it is in
+    // (or rs + 1: the sums of the next job are in and its log-likelihood is not, the entry still holds this one's)
+    auto l6_ll = [&](int rs, double &out) -> bool {
+        duo_flag_t *mine = lane < RW ? f_res + lane : f_res;
+        for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
+            asm volatile("" ::: "memory");
+            const int v = *mine;
+            asm volatile("" ::: "memory");
+            double l = 0.0;
+#pragma unroll
+            for (int w = 0; w < RW; ++w) l += slot[RESO + w * RREC + DP + 1];
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_ballot_w64(v == (rs | (int)DUO_LLBIT) || v == rs + 1) == ~0ull) { out = l; return true; }
+            if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) return false;
+            __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
+        }
+        return false;
     };
     // TEAM, barrier hand-offs: the bookkeeping of a finished SUBTREE or TRANSITION (weights, Philox draws, copies through the
     // cold store: 5 000-17 000 cycles against ~3 500 for an ordinary leaf) outlasts the team's pass, and the row waves and
@@ -1396,6 +1435,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         double pf_da = 0.0, pf_ll = 0.0, pf_t = 0.0, pf_vo1 = 0.0, pf_vo3 = 0.0;
         if constexpr (BKW) {
             duo_flag_t *mine = lane < RW ? f_res + lane : (lane == RW ? f_ov : f_res);
+            const int llm = (EPX_L6_LLAFTER && lane != RW) ? ~(int)DUO_LLBIT : ~0;
             const int tj = lane == LA ? DP : (lane < DP ? lane : 0);
             bool ok = false;
             for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -1405,11 +1445,12 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 pf_da = 0.0; pf_ll = 0.0; pf_t = 0.0;
 #pragma unroll
                 for (int w = 0; w < RW; ++w) {
-                    pf_da += slot[RESO + w * RREC + DP]; pf_ll += slot[RESO + w * RREC + DP + 1]; pf_t += slot[RESO + w * RREC + tj];
+                    pf_da += slot[RESO + w * RREC + DP]; pf_t += slot[RESO + w * RREC + tj];
+                    if constexpr (!EPX_L6_LLAFTER) pf_ll += slot[RESO + w * RREC + DP + 1];
                 }
                 pf_vo1 = slot[OVOFF + ve1]; pf_vo3 = slot[OVOFF + ve3];
                 asm volatile("" ::: "memory");
-                if (__builtin_amdgcn_ballot_w64(v == seq) == ~0ull) { ok = true; break; }
+                if (__builtin_amdgcn_ballot_w64(v != DUO_EXIT && (v & llm) == seq) == ~0ull) { ok = true; break; }
                 if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) break;
                 __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
             }
@@ -1444,7 +1485,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 }
             }
         };
-        if constexpr (BKW) { da = pf_da; ll = pf_ll; }
+        if constexpr (BKW) {
+            da = pf_da; ll = pf_ll;
+            if constexpr (EPX_L6_LLAFTER) { if (!lean) { if (!l6_ll(seq, ll)) { bail = 1; break; } } }      // (a full round reads it at once; a lean one behind the job's publication)
+        }
         else if (!late_ll) fetch_da_ll();
         if (!lean) { FORV dbf[i] = xtg(jdx[i]); }   // (the shortcut reuses the slot for the next job: fetch first)
         else { FORV dbf[i] = 0.0; }
@@ -1479,6 +1523,10 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             job_eps = eps_l;
             fast_pub = true;
             if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
+            // (layout 6, lean round: the log-likelihood of the job whose sums were just used -- looked for AT ONCE behind the
+            // next job's publication: the row waves overwrite it when they finish that next job, thousands of cycles from
+            // here, and the wait for the bookkeeping wave's acknowledgement further down can last longer than that)
+            if constexpr (BKW && EPX_L6_LLAFTER) { if (lean) { if (!l6_ll(seq - 1, ll)) { bail = 1; break; } } }
             if constexpr (BKW) { ctl_pre = *f_ctl; ack_pre = *f_ack; }     // requested now, used after the chain rule: no round trip then
             __builtin_amdgcn_s_setprio(EPX_PRIO_S_BG);  // the row waves are off again: what follows has their whole pass
             if constexpr (BKW) {
