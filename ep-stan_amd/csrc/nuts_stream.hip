@@ -63,6 +63,9 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 #define MODE_SS SMODE_SS
 #define MODE_TREE SMODE_TREE
 
+#ifndef EPX_STREAM_WAVE_SCALAR
+#define EPX_STREAM_WAVE_SCALAR 1
+#endif
 #ifndef EPX_OM_UNROLL
 #define EPX_OM_UNROLL 16
 #endif
@@ -91,6 +94,7 @@ __device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, i
     constexpr int PMAX = 64 * NV;
 
     const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    const int wave0 = wave;          // (the leapfrog loop re-derives `wave` as a SCALAR per iteration: see there)
     const int wt = 0;                           // one wave per chain
     const bool is_chain = wave < NCH;
     const int bps = (a.chains + NCH - 1) / NCH;
@@ -319,6 +323,12 @@ __device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, i
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
         stk_lane = lane;
+#if EPX_STREAM_WAVE_SCALAR
+        // (and the wave index as a scalar: `tid >> 6` is a vector value for the compiler, so every per-wave LDS base
+        // (q_s + wave * PMAX, ...) was a vector register computed once, spilled, and reloaded from scratch in front
+        // of its use -- one vector-memory round trip each, five in a row in step A)
+        const int wave = __builtin_amdgcn_readfirstlane(wave0);
+#endif
         // ---- lock step: leave only when every chain of the workgroup is done
         if (finished && !counted) { if (lane == 0) atomicAdd(sh_done, 1); counted = 1; }
         lds_barrier();
