@@ -64,7 +64,7 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 #define MODE_TREE SMODE_TREE
 
 #ifndef EPX_STREAM_WAVE_SCALAR
-#define EPX_STREAM_WAVE_SCALAR 1
+#define EPX_STREAM_WAVE_SCALAR 2
 #endif
 #ifndef EPX_OM_UNROLL
 #define EPX_OM_UNROLL 16
@@ -484,6 +484,9 @@ __device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, i
         asm volatile("" : "+v"(lane_w));
         const int lane = lane_w;
         stk_lane = lane;
+#if EPX_STREAM_WAVE_SCALAR > 1
+        const int wave = __builtin_amdgcn_readfirstlane(wave0);          // (as at the loop top: a scalar for step D and the books)
+#endif
         EPX_BIND_COLD(lane);
         {
             // ---- step D (wave = chain): lp and the chain rule back to (phi, eta, etb)
