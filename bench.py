@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0
 LDS_PEAK_TBS = 150.0
+CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md: max clock (the C3 kernel holds it: SQ_WAVE_CYCLES agree with wall time x 2.4 GHz)
 
 # Hooks for tests/test_multirank_gloo.py only (None = the product path: HipEngine behind Master, RCCL inside libepx.so):
 # a CPU run of THIS file at the driver's world size executes the rank-0 JSON assembly, the barriers and the reductions
@@ -108,13 +109,18 @@ def snapshot_for_cpu_leg(M, n_all, chains, siter):
     return {'n_all': n_all, 'mus': mus, 'Oms': Oms, 'last': last, 'Q': Q, 'r': r}
 
 
-def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df):
+def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par):
     """The CPU port (oracle/, kind 'port') on this box's host cores re-does, for the first sites of the workload, the site
     updates of ONE EP iteration that the device has just run behind the timed region (`Master.run(1, seed=PARITY_SEED)`):
     same cavities, same starting draws, same per-site Stan seeds (method.py:342-346), the C restatement of the sampler +
     the NumPy moment stage.  That run is timed (`cpu_baseline`) AND compared with the device's results (`parity`:
     north_star's same-run agreement on the posterior mean / covariance -- the tilted moments of method.py:413-437 that the
     sites contribute, and the global moments of method.py:1211-1219 they add up to).
+    TWO BUILDS of the C restatement run (oracle/Makefile): the TIMED one is the fast build (-O3 -march=native, contraction
+    allowed, vectorised logistic terms and reductions: the strongest honest CPU number) on all
+    `n_all` sites; the COMPARED one is the strict build (-O2, no contraction: the checker of every parity test) on the first
+    `n_par` sites -- its time is stated beside the fast one's.  tests/test_nuts_oracle.py holds the two builds together
+    (gradients at 1e-9, a site update statistically).
     Two schedules are timed:
       all-cores           (site, chain) pairs spread over every host thread;
       reference-faithful  sites strictly one after the other, the 4 chains of a site on 4 threads
@@ -137,25 +143,42 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df):
     seeds = stan_seeds(run_seeds(PARITY_SEED, 1, M.K)[0, M.k_lo:M.k_hi])[:n_all].astype(np.int64)
     nthr = threads if threads > 0 else no.lib().epo_num_threads()
 
-    def site_update(ks, nt):
+    trace_c = [None]
+
+    def site_update(ks, nt, trace=0):
         sl = slice(ks[0], ks[-1] + 1)
         l = lim[ks[0]:ks[-1] + 2]
         t0 = time.perf_counter()
-        draws, _, stats = no.nuts_sites(M.model_name, X[l[0]:l[-1]], y[l[0]:l[-1]], l - l[0], mus[sl], Oms[sl],
-                                        seeds[sl], chains=chains, iter=siter, init=last[sl], nthreads=nt)
+        res = no.nuts_sites(M.model_name, X[l[0]:l[-1]], y[l[0]:l[-1]], l - l[0], mus[sl], Oms[sl],
+                            seeds[sl], chains=chains, iter=siter, init=last[sl], nthreads=nt, trace_sites=trace)
+        draws, stats = res[0], res[2]
+        if trace:
+            trace_c[0] = res[3]
         mom = [eo.tilted_moments(np.asfortranarray(draws[j].reshape(-1, P)[:, :d]), Q, r, estim) for j in range(len(ks))]
         return time.perf_counter() - t0, float(stats[:, :, 3].sum()), draws, stats, mom
 
-    t_all, g_all, draws_c, stats_c, mom_c = site_update(list(range(n_all)), nthr)
-    t_seq = [site_update([k], min(chains, nthr))[0] for k in range(n_seq)]
-    base = {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': int(nthr), 'kind': 'port',
-            'cpu': cpu_model_name(), 'host_threads': os.cpu_count(),
+    # the timed leg: the fast build, every host thread a (site, chain) pair when there are enough of them
+    with no.timing_build():
+        t_all, g_all, _, _, _ = site_update(list(range(n_all)), nthr)
+        t_seq = [site_update([k], min(chains, nthr))[0] for k in range(n_seq)]
+    # the compared leg: the strict build (the checker), first n_par sites
+    n_par = min(n_par, n_all)
+    t_par, g_par, draws_c, stats_c, mom_c = site_update(list(range(n_par)), nthr, trace=n_par if snap.get('trace') is not None else 0)
+    work_items = n_all * chains
+    base = {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': int(min(nthr, work_items)), 'kind': 'port',
+            'cpu': cpu_model_name(), 'host_threads': os.cpu_count(), 'work_items': int(work_items),
+            'build': 'fast: gcc -O3 -march=native -ffp-contract=fast, vectorised logistic terms (oracle/Makefile FAST_LIB); '
+                     'timing only, never the checker',
             'sample': 'one site update (C-oracle NUTS + NumPy moment stage) of the first %d sites of this workload: the EP '
                       'iteration the device ran behind its timed ones, from the same cavities, last draws and Stan seeds; '
-                      '(site, chain) pairs over %d threads: %.1f s wall, %.3g gradients'
-                      % (n_all, nthr, t_all, g_all),
+                      '%d (site, chain) pairs over %d threads: %.1f s wall, %.3g gradients, %.1f us per gradient and thread'
+                      % (n_all, work_items, nthr, t_all, g_all, t_all * 1e6 * min(nthr, work_items) / max(g_all, 1.0)),
+            'strict_build': {'what': 'the checker (gcc -O2 -ffp-contract=off, libm) on the first %d sites, %d pairs over %d '
+                                     'threads: the run the parity record compares with' % (n_par, n_par * chains, nthr),
+                             'site_updates_per_s': n_par / t_par, 'seconds': t_par, 'gradients': g_par,
+                             'us_per_gradient_and_thread': t_par * 1e6 * min(nthr, n_par * chains) / max(g_par, 1.0)},
             'reference_schedule': {
-                'what': 'sites one after the other, the %d chains of a site on %d threads (method.py:1005-1023)'
+                'what': 'sites one after the other, the %d chains of a site on %d threads (method.py:1005-1023); fast build'
                         % (chains, min(chains, nthr)),
                 'sites_timed': n_seq, 'site_updates_per_s': n_seq / float(np.sum(t_seq)),
                 'seconds_per_site': [float(t) for t in t_seq],
@@ -163,6 +186,9 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df):
                 'note': 'the reference reports max over sites as its per-iteration "sampling time" '
                         '(method.py:1043), i.e. the time if every site had its own 4 cores'},
             'extrapolation': 'none: rates are per site update; an EP iteration over J sites costs J / rate'}
+    n_all = n_par                                        # (from here on: the compared sites)
+    lim = lim[:n_all + 1]
+    X, y, seeds = X[:lim[-1]], y[:lim[-1]], seeds[:n_all]
 
     # ---- parity: the device's results of the same site updates
     cs = eng.get_chain_stats(chains)[:n_all]
@@ -235,6 +261,42 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df):
               'chains_within_1e-6': int(np.sum(e_t < 1e-6)),
               'leapfrog_counts_equal': int(np.sum(cs_t[:, :, 3] == st_t[:, :, 3])),
               'mean_leapfrogs': float(st_t[:, :, 3].mean())}
+    # transition by transition (the device's trace of the parity iteration, epx_set_trace, against the oracle's): how long the
+    # two runs of a chain stay together, and whether anything drifted in front of the transition that parted them
+    by_t = None
+    if snap.get('trace') is not None and trace_c[0] is not None:
+        td, to = snap['trace'][:n_all], trace_c[0][:n_all]
+        T = td.shape[2]
+        sc_ = np.maximum(1.0, np.abs(to[..., 8:]).max(axis=3))
+        e_t = np.abs(td[..., 8:] - to[..., 8:]).max(axis=3) / sc_
+        differ = (td[..., 1] != to[..., 1]) | (e_t > 1e-6)
+        t_star = np.where(differ.any(axis=2), differ.argmax(axis=2), T)
+        # error growth: the factor by which a chain's error grows per transition while the two runs are together
+        growth = []
+        for k in range(td.shape[0]):
+            for c in range(td.shape[1]):
+                e = np.maximum(e_t[k, c, :max(int(t_star[k, c]), 1)], 1e-17)
+                if len(e) >= 3:
+                    growth.append(float(np.exp(np.mean(np.diff(np.log(e))))))
+        first_eps = np.abs(td[:, :, 0, 5] / to[:, :, 0, 5] - 1.0)
+        edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, T, T + 1]
+        by_t = {'chains': int(t_star.size),
+                'transitions_until_parting_histogram': {('%d-%d' % (edges[i], edges[i + 1] - 1)) if edges[i + 1] <= T else 'never':
+                                                        int(np.sum((t_star >= edges[i]) & (t_star < edges[i + 1])))
+                                                        for i in range(len(edges) - 1)},
+                'median_transitions_until_parting': float(np.median(t_star)),
+                'chains_equal_through_the_first_transition': int(np.sum(t_star >= 1)),
+                'first_transition_max_rel_err_of_the_draws': float(e_t[:, :, 0].max()),
+                'first_transition_max_rel_err_of_the_adapted_step_size': float(first_eps.max()),
+                'median_error_growth_factor_per_transition': float(np.median(growth)) if growth else None,
+                'leapfrogs_of_the_compared_transitions': float(sum(to[k, c, :t_star[k, c], 1].sum()
+                                                                   for k in range(td.shape[0]) for c in range(td.shape[1]))),
+                'note': 'parting = the first transition whose leapfrog count differs or whose draw differs by more than 1e-6. '
+                        'The CPU leg starts every chain from the device\'s own cavity, last draw and Stan seed: a leg on a different '
+                        'problem parts at transition 0.  On these funnel-shaped posteriors (hundreds of leapfrogs per transition) '
+                        'the rounding differences of the two summation orders grow by the factor above per transition until they '
+                        'reach 1e-6 or flip a decision: chaos, not a difference of the algorithm -- the first transition, step-size '
+                        'search included, agrees to rounding'}
     parity = {
         'what': 'the EP iteration behind the timed ones, sites 0..%d: device (the timed kernel, piece queue and all) against the '
                 'CPU port from the same cavities, starting draws and Stan seeds' % (n_all - 1),
@@ -254,12 +316,19 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df):
                                'share_within_tolerance': float(np.mean(rel_cov <= tol_cov))},
         'site_delta_vs_numpy_moment_stage_max_rel_err': float(np.max(dq_rel)),
         'global_moments_with_cpu_deltas_for_these_sites': glob,
+        'transition_by_transition': by_t,
         'tolerance': 'first draws (one transition from the same state): 1e-6 relative; tilted mean within 4 MCSE per coordinate, '
                      'tilted variances within 4 sqrt(2/ESS_dev + 2/ESS_cpu) relative (SURVEY.md section 8c; ESS by Geyer\'s '
                      'initial positive sequence over the %d chains); site delta from the device\'s own draws against the NumPy '
-                     'moment stage: 1e-7' % chains,
+                     'moment stage: 1e-7; transition by transition: >= 90 %% of the chains equal through the first transition (step-size '
+                     'search included), its draws and adapted step sizes within 1e-6' % chains,
         'ok': bool((tf is None or tf['max_rel_err'] < 1e-6) and np.mean(z_mean <= 4.0) >= 0.99
-                   and np.mean(rel_cov <= tol_cov) >= 0.99 and np.max(dq_rel) < 1e-7)}
+                   and np.mean(rel_cov <= tol_cov) >= 0.99 and np.max(dq_rel) < 1e-7
+                   # the same problem, and no drift: nearly every chain gets through its first transition (step-size search
+                   # included) with the oracle's, and what lies in front of a parting agrees to rounding
+                   and (by_t is None or (by_t['chains_equal_through_the_first_transition'] >= 0.9 * by_t['chains']
+                                         and by_t['first_transition_max_rel_err_of_the_draws'] < 1e-6
+                                         and by_t['first_transition_max_rel_err_of_the_adapted_step_size'] < 1e-6)))}
     return base, parity
 
 
@@ -276,6 +345,175 @@ def spawn_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault('EPX_COMM_PORT', str(port2))
     return subprocess.call(cmd, env=env)
+
+
+def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom=False):
+    """One configuration: workload, Master, `warm` untimed EP iterations, then EXACTLY `steps` timed ones bracketed by
+    barrier + device synchronisation on both sides.  Returns (record, Master) on rank 0, (None, None) elsewhere."""
+    from epstan_amd import _lib as elib, models
+    from epstan_amd.method import Master
+    sites, D, n, cor, steps, warm = sizes
+    J = sites * world
+    mod, data, Q0, r0 = workload(J, D, n, args.model, bool(cor))
+    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
+               chains=args.chains, iter=args.siter, prec_estim=args.prec_estim,
+               df0=models.default_df0(J), comm=comm, device=local_rank, layout=args.layout,
+               adapt=args.adapt, sync_sites=False, **({} if on_gpu else {'_engine_factory': _ENGINE_FACTORY}))
+    rccl_rank, rccl_world = comm.size() if hasattr(comm, 'size') else (comm.rank, comm.world)
+
+    def sync():
+        if on_gpu:
+            elib.device_synchronize(local_rank)
+        comm.barrier()
+        if on_gpu:
+            elib.device_synchronize(local_rank)
+
+    # (EPX_BENCH_SEED_SHIFT: a diagnostic of how far the leapfrog counts of the late iterations depend on the random
+    # streams -- DESIGN.md section 6; the driver's command does not set it and the line says so when it is set)
+    shift = int(os.environ.get('EPX_BENCH_SEED_SHIFT', '0'))
+    if warm > 0:
+        info = M.run(warm, verbose=False, seed=1 + shift)[0]
+        assert info == 0, 'warm-up EP iterations failed with info %d' % info
+    n_launch0 = len(M.sampling_ms)
+    sync()
+    t0 = time.perf_counter()
+    res = M.run(steps, verbose=False, return_analytics=True, seed=2 + shift)
+    sync()
+    dt = time.perf_counter() - t0
+    info = res[0]
+    tmax = float(comm.allreduce_max(np.array([dt]))[0])
+    if rank != 0:
+        return None, None
+    assert info == 0, 'EP failed with info %d' % info
+
+    # dominant kernel: the sampler, timed with HIP events on the library's stream
+    ms = np.array(M.sampling_ms[n_launch0:])
+    ngrad = np.array(M.ngrad_log[n_launch0:])
+    n_rows = float(n)
+    F_g = 4.0 * n_rows * D + 12.0 * n_rows             # SURVEY.md §8d flops per gradient
+    B_g = n_rows * D * 8 + n_rows                      # ... and bytes swept per gradient (from LDS when resident)
+    flops_per_launch = float(ngrad.mean()) * F_g
+    t_kernel = float(ms.mean()) * 1e-3
+    achieved_tf = flops_per_launch / t_kernel / 1e12
+    layout = M.engine.last_layout()
+    wg_per_site = args.chains if layout in (2, 6) else 1
+    n_cu = M.engine.cu_count() if hasattr(M.engine, 'cu_count') else 256
+    P = M.engine.P
+    # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup), draws
+    # and last states out
+    hbm_alg = sites * wg_per_site * (n_rows * D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
+        + sites * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
+    key = [sites, D, n, args.model, args.chains, args.siter]
+
+    def measured_traffic(names):
+        """HBM bytes per launch from a committed rocprofv3 --pmc run of THIS command (FETCH_SIZE x 2 +
+        WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be collected inside the timed run."""
+        for name in names:
+            path = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(path):
+                pj = json.load(open(path))
+                if pj.get('workload_key', pj.get('workload')) == key:
+                    return pj['hbm_bytes_per_launch_corrected'], 'profiles/' + name
+        return None, None
+
+    if layout == 3:
+        # streaming sampler: the site rows (and the cavity precision) come from HBM once per
+        # leapfrog of a workgroup's chains in lock step -> the HBM roofline is the one that binds
+        passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
+        B_pass = n_rows * D * 8 + n_rows * 4 + M.dphi**2 * 8     # X, y (int32), Omega
+        hbm_alg = float(passes.mean()) * B_pass
+        gbs = hbm_alg / t_kernel / 1e9
+        tr, src = measured_traffic(('r05_stream_pmc_hbm.json', 'r04_stream_pmc_hbm.json', 'r02_stream_pmc_hbm.json', 'r01_stream_pmc_hbm.json'))
+        roof = {'kernel': 'k_nuts_stream (sampler)', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'traffic_source': src,
+                'note': 'algorithmic bytes = row passes x (n D 8 + n 4 + d^2 8) over the HIP-event duration '
+                        'of the sampler launch; includes the tail where few sites are still sampling',
+                'launch_ms': float(ms.mean()), 'row_passes_per_launch': float(passes.mean()),
+                'gradients_per_launch': float(ngrad.mean()),
+                'passes_max_over_mean_site': float(np.mean([p.max() / p.mean() for p in M.pass_log[n_launch0:]])),
+                'fp64_tflops': achieved_tf,
+                # build-comparable scalars (site-updates/s moves with the trajectories EP happens to take, these do not):
+                'bytes_per_row_pass': B_pass,
+                'ns_per_row_pass_per_cu': t_kernel * 1e9 * n_cu / float(passes.mean())}
+    else:
+        tr, src = measured_traffic(tuple('r%02d_%s_pmc_hbm.json' % (r, cfg_name) for r in (5, 4, 3, 2)))
+        team = layout == 7
+        # bytes the kernel reads from LDS for the rows: one sweep of the site per gradient in the one-wave-per-chain forms;
+        # layout 7 reads the rows TWICE per pass (forward and transposed product) for the FOUR gradients of a site's chains
+        passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
+        lds_bytes = float(passes.mean()) * 2.0 * B_g if team else float(ngrad.mean()) * B_g
+        lds_tbs = lds_bytes / t_kernel / 1e12
+        roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
+                'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_source': src,
+                'note': ('FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event duration of the '
+                         'sampler launch.  Layout 7: the two products of a gradient run on v_mfma_f64_4x4x4 for the four '
+                         'chains of a site in lock step (dense FP64 matrix peak = FP64 vector peak = 78.6 TFLOP/s); X is '
+                         'LDS resident, so HBM does not bound it: lds_frac / hbm_frac below (lds_swept: two reads of the '
+                         'rows per lock-step pass of four chains)') if team else
+                        ('FP64 vector flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
+                         'duration of the sampler launch.  The kernel issues no MFMA (a wave owns one chain: '
+                         'matrix-vector work) and X is LDS resident, so neither the matrix pipes nor HBM '
+                         'bound it: lds_frac / hbm_frac below'),
+                'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
+                'row_passes_per_launch': float(passes.mean()),
+                # build-comparable scalars (site-updates/s moves with the trajectories EP happens to take, these do not):
+                # time per gradient evaluation, and the cycles of one lock-step pass of a workgroup at the nominal clock --
+                # launch time x 2.4 GHz / (passes of all sites / CUs): every CU is busy for the whole launch when the sites
+                # come from the piece queue, so this is the average pass of a CU, waits and piece changes included
+                'ns_per_gradient': t_kernel * 1e9 / float(ngrad.mean()),
+                'pass_cycles': (t_kernel * CLOCK_GHZ * 1e9 * min(n_cu, sites) / max(float(passes.mean()), 1.0)) if team else None,
+                'pass_cycles_note': 'layout 7 only (lock-step passes): launch_ms x %.1f GHz x min(CUs, sites) / row_passes_per_launch' % CLOCK_GHZ,
+                'lds_swept_TBps': lds_tbs, 'lds_peak_TBps': LDS_PEAK_TBS, 'lds_frac': lds_tbs / LDS_PEAK_TBS,
+                'hbm_algorithmic_bytes': hbm_alg,
+                'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}
+    out = {
+        'metric': 'site-updates/sec', 'value': J * steps / tmax, 'unit': 'site-updates/s',
+        'n_gpus': world, 'steps': steps, 'warmup': warm,
+        'ms_per_step': tmax / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'ep_iters_per_sec': steps / tmax,
+        'config': {'workload': 'hierarchical logistic regression %s, J=%d sites (=%d/GPU), D=%d, n_j=%d, '
+                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s%s'
+                               % (args.model, J, sites, D, n, args.chains, args.siter,
+                                  args.chains * (args.siter - args.siter // 2), args.prec_estim,
+                                  '' if cor else ', uncorrelated covariates',
+                                  '' if args.adapt == 'fresh' else ', adapt=carry (NOT the reference\'s per-update re-adaptation)'),
+                   'adapt': args.adapt, **({'seed_shift_DIAGNOSTIC': shift} if shift else {}),
+                   'name': 'custom' if custom else cfg_name,
+                   'parallelism': 'sites sharded over %d GPU(s), 1 RCCL all-reduce/iter inside libepx.so' % world,
+                   'rccl_world_size': rccl_world},
+        'roofline': roof,
+        'sampler_share_of_step': float(ms.sum() * 1e-3 / dt),
+        'update_phase_ms_per_step': float(np.mean(M.othertime_log[-steps:]) * 1e3),
+        'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
+                                               / (sites * args.chains * args.siter)),
+    }
+    # what a "site update" is made of here: most transitions of the late iterations build a tree of max_treedepth
+    # (1 023 leapfrogs); the headline is a statement about such trees
+    max_lf = float(2 ** M.max_treedepth - 1)
+    out['tree_depth_note'] = ('%.0f %% of the possible %d leapfrogs per transition over the timed launches (first %.0f %%, '
+                              'last %.0f %%): these funnel-shaped site posteriors drive Stan\'s NUTS to max_treedepth in most '
+                              'transitions, so site-updates/s here is a rate of depth-%d trees'
+                              % (100 * float(ngrad.mean()) / (sites * args.chains * args.siter) / max_lf, int(max_lf),
+                                 100 * float(ngrad[0]) / (sites * args.chains * args.siter) / max_lf,
+                                 100 * float(ngrad[-1]) / (sites * args.chains * args.siter) / max_lf, M.max_treedepth))
+    # the launch ends with its slowest chain (one workgroup per chain) / slowest site (chains in lock step):
+    # how far that is from the average, last launch of this rank
+    lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
+    out['launch_ms_timed'] = [round(float(x), 1) for x in ms]
+    out['leapfrogs_per_transition_timed'] = [round(float(g) / (sites * args.chains * args.siter), 1) for g in ngrad]
+    out['gradients_all_launches'] = float(np.sum(M.ngrad_log))      # warm-up + timed: what a profiler pass over this command counts
+    out['launch_tail'] = {'slowest_chain_leapfrogs': float(lf.max()), 'mean_chain_leapfrogs': float(lf.mean()),
+                          'last_launch_us_per_leapfrog_of_the_slowest_chain': float(ms[-1]) * 1e3 / max(float(lf.max()), 1.0),
+                          'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(layout),
+                          'lead_sites_of_a_split_launch': int(M.engine.last_split()),
+                          # < 0: the launch ran from the piece queue (persistent workgroups), -pieces per site
+                          'pieces': int(M.engine.last_segments()) if hasattr(M.engine, 'last_segments') else 0,
+                          # (negative `pieces`: pieces per site of a launch from the piece queue; who takes them)
+                          'piece_form': 'one workgroup per piece (EPX_PIECE_GRID)' if os.environ.get('EPX_PIECE_GRID')
+                          else 'looping workgroups, as many as the device holds'}
+    return out, M
 
 
 def main():
@@ -295,9 +533,12 @@ def main():
     ap.add_argument('--adapt', default='fresh', choices=['fresh', 'carry'],
                     help="'fresh' = the reference's behaviour (default, the headline); 'carry' = opt-in carried adaptation")
     ap.add_argument('--cor-input', type=int, default=None, help='0: uncorrelated covariates (fit.py cor_input=False)')
-    ap.add_argument('--cpu-sites', type=int, default=32, help='sites of the all-cores cpu_baseline leg; 0 disables it')
+    ap.add_argument('--cpu-sites', type=int, default=64, help='sites of the all-cores cpu_baseline leg (fast build); 0 disables it')
+    ap.add_argument('--parity-sites', type=int, default=32, help='sites the strict build re-does for the parity record')
     ap.add_argument('--cpu-seq-sites', type=int, default=3, help='sites of the reference-faithful schedule')
     ap.add_argument('--cpu-threads', type=int, default=0)
+    ap.add_argument('--no-secondary', dest='secondary', action='store_false',
+                    help='skip the C2 / C5-shard records behind the headline (default: measured when the headline is C3 on one GPU)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launch + rendezvous only (no GPU work): checks that --gpus N starts N ranks')
     args = ap.parse_args()
@@ -347,175 +588,80 @@ def main():
     # every rank, also a single one, goes through the in-library RCCL communicator
     comm = edist.EpxComm(rank=rank, world=world) if _COMM_FACTORY is None else _COMM_FACTORY(rank, world)
 
-    J = sites * world
-    mod, data, Q0, r0 = workload(J, D, n, args.model, bool(cor))
-    M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0},
-               chains=args.chains, iter=args.siter, prec_estim=args.prec_estim,
-               df0=models.default_df0(J), comm=comm, device=local_rank, layout=args.layout,
-               adapt=args.adapt, sync_sites=False, **({} if on_gpu else {'_engine_factory': _ENGINE_FACTORY}))
-    rccl_rank, rccl_world = comm.size() if hasattr(comm, 'size') else (comm.rank, comm.world)
-
-    def sync():
-        if on_gpu:
-            elib.device_synchronize(local_rank)
-        comm.barrier()
-        if on_gpu:
-            elib.device_synchronize(local_rank)
-
-    # (EPX_BENCH_SEED_SHIFT: a diagnostic of how far the leapfrog counts of the late iterations depend on the random
-    # streams -- DESIGN.md section 6; the driver's command does not set it and the line says so when it is set)
-    shift = int(os.environ.get('EPX_BENCH_SEED_SHIFT', '0'))
-    if warm > 0:
-        info = M.run(warm, verbose=False, seed=1 + shift)[0]
-        assert info == 0, 'warm-up EP iterations failed with info %d' % info
-    n_launch0 = len(M.sampling_ms)
-    sync()
-    t0 = time.perf_counter()
-    res = M.run(steps, verbose=False, return_analytics=True, seed=2 + shift)
-    sync()
-    dt = time.perf_counter() - t0
-    info = res[0]
-    tmax = float(comm.allreduce_max(np.array([dt]))[0])
+    sizes = (sites, D, n, cor, steps, warm)
+    out, M = measure(args, args.config, sizes, comm, rank, world, local_rank, on_gpu,
+                     custom=(args.sites, args.D, args.n) != (None, None, None))
     if rank != 0:
         # rank 0's cpu_baseline leg needs nothing from the others, and they must not spin in a collective beside it
         # (an RCCL barrier busy-waits a host thread per rank): they are done -- ncclCommDestroy needs no peer
         if hasattr(comm, 'close'):
             comm.close()
         return
-    assert info == 0, 'EP failed with info %d' % info
-
-    # dominant kernel: the sampler, timed with HIP events on the library's stream
-    ms = np.array(M.sampling_ms[n_launch0:])
-    ngrad = np.array(M.ngrad_log[n_launch0:])
-    n_rows = float(n)
-    F_g = 4.0 * n_rows * D + 12.0 * n_rows             # SURVEY.md §8d flops per gradient
-    B_g = n_rows * D * 8 + n_rows                      # ... and bytes swept per gradient (from LDS when resident)
-    flops_per_launch = float(ngrad.mean()) * F_g
-    t_kernel = float(ms.mean()) * 1e-3
-    achieved_tf = flops_per_launch / t_kernel / 1e12
-    layout = M.engine.last_layout()
-    wg_per_site = args.chains if layout in (2, 6) else 1
-    P = M.engine.P
-    # HBM bytes one sampler launch has to move: X, y and the cavity in (once per workgroup), draws
-    # and last states out
-    hbm_alg = sites * wg_per_site * (n_rows * D * 8 + n_rows + (M.dphi**2 + M.dphi) * 8) \
-        + sites * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
-    key = [sites, D, n, args.model, args.chains, args.siter]
-
-    def measured_traffic(names):
-        """HBM bytes per launch from a committed rocprofv3 --pmc run of THIS command (FETCH_SIZE x 2 +
-        WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be collected inside the timed run."""
-        for name in names:
-            path = os.path.join(ROOT, 'profiles', name)
-            if os.path.exists(path):
-                pj = json.load(open(path))
-                if pj.get('workload_key', pj.get('workload')) == key:
-                    return pj['hbm_bytes_per_launch_corrected'], 'profiles/' + name
-        return None, None
-
-    if layout == 3:
-        # streaming sampler: the site rows (and the cavity precision) come from HBM once per
-        # leapfrog of a workgroup's chains in lock step -> the HBM roofline is the one that binds
-        passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
-        B_pass = n_rows * D * 8 + n_rows * 4 + M.dphi**2 * 8     # X, y (int32), Omega
-        hbm_alg = float(passes.mean()) * B_pass
-        gbs = hbm_alg / t_kernel / 1e9
-        tr, src = measured_traffic(('r02_stream_pmc_hbm.json', 'r01_stream_pmc_hbm.json'))
-        roof = {'kernel': 'k_nuts_stream (sampler)', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'traffic_source': src,
-                'note': 'algorithmic bytes = row passes x (n D 8 + n 4 + d^2 8) over the HIP-event duration '
-                        'of the sampler launch; includes the tail where few sites are still sampling',
-                'launch_ms': float(ms.mean()), 'row_passes_per_launch': float(passes.mean()),
-                'gradients_per_launch': float(ngrad.mean()),
-                'passes_max_over_mean_site': float(np.mean([p.max() / p.mean() for p in M.pass_log[n_launch0:]])),
-                'fp64_tflops': achieved_tf}
-    else:
-        tr, src = measured_traffic(('r04_%s_pmc_hbm.json' % args.config, 'r03_%s_pmc_hbm.json' % args.config,
-                                    'r02_%s_pmc_hbm.json' % args.config))
-        team = layout == 7
-        # bytes the kernel reads from LDS for the rows: one sweep of the site per gradient in the one-wave-per-chain forms;
-        # layout 7 reads the rows TWICE per pass (forward and transposed product) for the FOUR gradients of a site's chains
-        passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
-        lds_bytes = float(passes.mean()) * 2.0 * B_g if team else float(ngrad.mean()) * B_g
-        lds_tbs = lds_bytes / t_kernel / 1e12
-        roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
-                'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_source': src,
-                'note': ('FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event duration of the '
-                         'sampler launch.  Layout 7: the two products of a gradient run on v_mfma_f64_4x4x4 for the four '
-                         'chains of a site in lock step (dense FP64 matrix peak = FP64 vector peak = 78.6 TFLOP/s); X is '
-                         'LDS resident, so HBM does not bound it: lds_frac / hbm_frac below (lds_swept: two reads of the '
-                         'rows per lock-step pass of four chains)') if team else
-                        ('FP64 vector flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event '
-                         'duration of the sampler launch.  The kernel issues no MFMA (a wave owns one chain: '
-                         'matrix-vector work) and X is LDS resident, so neither the matrix pipes nor HBM '
-                         'bound it: lds_frac / hbm_frac below'),
-                'launch_ms': float(ms.mean()), 'gradients_per_launch': float(ngrad.mean()),
-                'row_passes_per_launch': float(passes.mean()),
-                'lds_swept_TBps': lds_tbs, 'lds_peak_TBps': LDS_PEAK_TBS, 'lds_frac': lds_tbs / LDS_PEAK_TBS,
-                'hbm_algorithmic_bytes': hbm_alg,
-                'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}
-    out = {
-        'metric': 'site-updates/sec', 'value': J * steps / tmax, 'unit': 'site-updates/s',
-        'n_gpus': world, 'steps': steps, 'warmup': warm,
-        'ms_per_step': tmax / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'ep_iters_per_sec': steps / tmax,
-        'config': {'workload': 'hierarchical logistic regression %s, J=%d sites (=%d/GPU), D=%d, n_j=%d, '
-                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s%s'
-                               % (args.model, J, sites, D, n, args.chains, args.siter,
-                                  args.chains * (args.siter - args.siter // 2), args.prec_estim,
-                                  '' if cor else ', uncorrelated covariates',
-                                  '' if args.adapt == 'fresh' else ', adapt=carry (NOT the reference\'s per-update re-adaptation)'),
-                   'adapt': args.adapt, **({'seed_shift_DIAGNOSTIC': shift} if shift else {}),
-                   'name': args.config if (args.sites, args.D, args.n) == (None, None, None) else 'custom',
-                   'parallelism': 'sites sharded over %d GPU(s), 1 RCCL all-reduce/iter inside libepx.so' % world,
-                   'rccl_world_size': rccl_world},
-        'roofline': roof,
-        'sampler_share_of_step': float(ms.sum() * 1e-3 / dt),
-        'update_phase_ms_per_step': float(np.mean(M.othertime_log[-steps:]) * 1e3),
-        'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
-                                               / (sites * args.chains * args.siter)),
-    }
-    # what a "site update" is made of here: most transitions of the late iterations build a tree of max_treedepth
-    # (1 023 leapfrogs); the headline is a statement about such trees
-    max_lf = float(2 ** M.max_treedepth - 1)
-    out['tree_depth_note'] = ('%.0f %% of the possible %d leapfrogs per transition over the timed launches (first %.0f %%, '
-                              'last %.0f %%): these funnel-shaped site posteriors drive Stan\'s NUTS to max_treedepth in most '
-                              'transitions, so site-updates/s here is a rate of depth-%d trees'
-                              % (100 * float(ngrad.mean()) / (sites * args.chains * args.siter) / max_lf, int(max_lf),
-                                 100 * float(ngrad[0]) / (sites * args.chains * args.siter) / max_lf,
-                                 100 * float(ngrad[-1]) / (sites * args.chains * args.siter) / max_lf, M.max_treedepth))
-    # the launch ends with its slowest chain (one workgroup per chain) / slowest site (chains in lock step):
-    # how far that is from the average, last launch of this rank
-    lf = M.engine.get_chain_stats(args.chains)[:, :, 3]
-    out['launch_ms_timed'] = [round(float(x), 1) for x in ms]
-    out['leapfrogs_per_transition_timed'] = [round(float(g) / (sites * args.chains * args.siter), 1) for g in ngrad]
-    out['gradients_all_launches'] = float(np.sum(M.ngrad_log))      # warm-up + timed: what a profiler pass over this command counts
-    out['launch_tail'] = {'slowest_chain_leapfrogs': float(lf.max()), 'mean_chain_leapfrogs': float(lf.mean()),
-                          'max_over_mean': float(lf.max() / max(lf.mean(), 1.0)), 'layout': int(layout),
-                          'lead_sites_of_a_split_launch': int(M.engine.last_split()),
-                          # < 0: the launch ran from the piece queue (persistent workgroups), -pieces per site
-                          'pieces': int(M.engine.last_segments()) if hasattr(M.engine, 'last_segments') else 0,
-                          # (negative `pieces`: pieces per site of a launch from the piece queue; who takes them)
-                          'piece_form': 'one workgroup per piece (EPX_PIECE_GRID)' if os.environ.get('EPX_PIECE_GRID')
-                          else 'looping workgroups, as many as the device holds'}
     if args.cpu_sites > 0:
         try:
             # one more EP iteration on the device, behind the timed region, whose first sites the CPU port re-does from the
             # same state and seeds: the CPU's time is the baseline, the two results are the parity record
             snap = snapshot_for_cpu_leg(M, args.cpu_sites, args.chains, args.siter)
+            n_tr = min(args.parity_sites, snap['n_all'])
+            if hasattr(M.engine, 'set_trace'):
+                M.engine.set_trace(n_tr)             # every transition of the compared sites' chains, warm-up included
             info_p = M.run(1, verbose=False, seed=PARITY_SEED)[0]
             assert info_p == 0, 'parity EP iteration failed with info %d' % info_p
+            snap['trace'] = None
+            if hasattr(M.engine, 'set_trace'):
+                snap['trace'] = M.engine.get_trace(args.chains, args.siter)
+                M.engine.set_trace(0)
             out['cpu_baseline'], out['parity'] = cpu_leg(M, snap, args.prec_estim, args.chains, args.siter,
                                                          args.cpu_seq_sites, args.cpu_threads,
-                                                         M.df_log[-1] if getattr(M, 'df_log', None) else M.df0(M.iter))
+                                                         M.df_log[-1] if getattr(M, 'df_log', None) else M.df0(M.iter),
+                                                         args.parity_sites)
         except Exception as ex:                      # the baseline must not void the GPU measurement
             import traceback
             traceback.print_exc()
             out['cpu_baseline'] = {'value': None, 'unit': 'site-updates/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %r' % (ex,)}
             out['parity'] = None
+    # ---- secondary records: the other two single-GPU configurations of BASELINE.json, driver-timed in the same process
+    # (configs[1] = C2: 64 sites, D = 16, n = 200, layout 6; one 512-site shard of configs[4] = C5: D = 128, n = 2000, the
+    # streaming sampler against the HBM roofline).  Headline keys stay the default workload's.  One GPU only: a rank of a
+    # multi-GPU run has nothing to add to them.
+    if args.secondary and world == 1 and on_gpu and args.config == 'c3' and (args.sites, args.D, args.n) == (None, None, None):
+        import gc
+        out['secondary'] = []
+        try:
+            M.engine.close()
+        except Exception:
+            pass
+        del M
+        gc.collect()
+        for name, (st_, wm_) in (('c2', (20, 5)), ('c5shard', (1, 1))):
+            try:
+                t_s = time.perf_counter()
+                sz = CONFIGS[name][:4] + (st_, wm_)
+                comm2 = edist.EpxComm(rank=0, world=1)       # (a communicator of its own: the headline's is bound to the engine just closed)
+                rec, M2 = measure(args, name, sz, comm2, rank, world, local_rank, on_gpu)
+                rf = rec['roofline']
+                keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launch_ms', 'row_passes_per_launch',
+                        'gradients_per_launch', 'ns_per_gradient', 'pass_cycles', 'bytes_per_row_pass',
+                        'ns_per_row_pass_per_cu', 'traffic', 'traffic_source')
+                out['secondary'].append({
+                    'config': rec['config'], 'value': rec['value'], 'unit': rec['unit'], 'steps': st_, 'warmup': wm_,
+                    'ms_per_step': rec['ms_per_step'], 'ep_iters_per_sec': rec['ep_iters_per_sec'],
+                    'roofline': {k: rf[k] for k in keep if k in rf},
+                    'launch_tail': rec['launch_tail'], 'mean_leapfrogs_per_transition': rec['mean_leapfrogs_per_transition'],
+                    'wall_s_with_setup': time.perf_counter() - t_s})
+                try:
+                    if hasattr(comm2, 'close'):
+                        comm2.close()
+                    M2.engine.close()
+                except Exception:
+                    pass
+                del M2
+                gc.collect()
+            except Exception as ex:
+                import traceback
+                traceback.print_exc()
+                out['secondary'].append({'config': {'name': name}, 'value': None, 'error': repr(ex)})
     if hasattr(comm, 'close'):
         comm.close()
     sys.stdout.flush()

@@ -88,6 +88,8 @@ SIGNATURES = {
                                       c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p, ctypes.c_int,
                                       c_double_p]),
     'epx_set_piece_queue': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
+    'epx_set_trace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'epx_get_trace': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_longlong]),
     'epx_last_segments': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),

@@ -276,7 +276,7 @@ int epx_ctx_destroy(epx_ctx *c) {
     void *ptrs[] = {c->dyn_lens_d, c->ckpt, c->dyn_rate, c->dyn_words, c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
-                    c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj};
+                    c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj, c->trace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -645,6 +645,21 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     if (want_carry) { a.carry_eps = c->carry_eps; a.carry_metric = c->carry_metric; }
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
     c->last_segments = 0;
+    c->trace_chains = 0;
+    if (c->trace_sites > 0 && !eps_dev) {
+        // test hook (epx_set_trace): a record of every transition of the first sites' chains, warm-up included
+        const int ts = c->trace_sites < count ? c->trace_sites : count;
+        const size_t need = (size_t)ts * o.chains * o.iter * (size_t)(8 + c->P);
+        if (c->trace_n < need) {
+            if (c->trace) (void)hipFree(c->trace);
+            c->trace = nullptr; c->trace_n = 0;
+            HIPCHK(dalloc(&c->trace, need));
+            c->trace_n = need;
+        }
+        HIPCHK(hipMemsetAsync(c->trace, 0, need * 8, c->stream));
+        a.trace = c->trace; a.trace_sites = ts;
+        c->trace_chains = o.chains; c->trace_iter = o.iter;
+    }
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
     bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
                      o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
@@ -981,6 +996,23 @@ int epx_set_piece_queue(epx_ctx *c, int piece_len, const double *rate) {
         c->dyn_rate_h->assign(rate, rate + c->K);
     }
     c->dyn_len = piece_len;
+    return 0;
+}
+
+int epx_set_trace(epx_ctx *c, int sites) {
+    CTX(c);
+    if (sites < 0 || sites > c->K) return fail("trace of %d sites outside 0..%d", sites, c->K);
+    c->trace_sites = sites;
+    return 0;
+}
+
+int epx_get_trace(epx_ctx *c, double *out, long long n_out) {
+    CTX(c);
+    if (!c->trace || c->trace_chains <= 0) return fail("no trace: epx_set_trace before the sampling call");
+    const int ts = c->trace_sites < c->K ? c->trace_sites : c->K;
+    const size_t n = (size_t)ts * c->trace_chains * c->trace_iter * (size_t)(8 + c->P);
+    if ((long long)n != n_out) return fail("trace has %zu doubles, the caller expects %lld", n, n_out);
+    HIPCHK(hipMemcpy(out, c->trace, n * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

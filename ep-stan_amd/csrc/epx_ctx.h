@@ -103,5 +103,9 @@ struct epx_ctx {
     double *comm_stage;       // device staging of the small host-side collectives
     size_t comm_stage_n;
     int *err_flag;            // device word the sampler kernels set when a hand-off spin gives up
+    // per-transition trace of the sampler (epx_set_trace, test hook): the first trace_sites sites of a sampling call
+    int trace_sites, trace_chains, trace_iter;
+    double *trace;
+    size_t trace_n;
 };
 

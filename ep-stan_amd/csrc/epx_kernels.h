@@ -144,6 +144,8 @@ struct NutsArgs {
     unsigned long long *stamps;   // diagnostic build (-DEPX_STAMPS): per block 8 cycle sums
     int stamps_nrec;              // ... and the host's count of records per kind (the launched grid may be smaller: looping workgroups add up their pieces)
     double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
+    double *trace;                // test hook (epx_set_trace): per (site of the batch < trace_sites, chain, transition) a record of 8 + P doubles
+    int trace_sites;
     double *stack;                // global memory of the chains of the resident layouts, indexed by (site of the batch,
                                   // chain): stack_stride doubles each -- tree stack (max_depth * (4 NV 64 + 2)) first,
                                   // then the state wave's cold store (nuts_duo.hip); one stride for every kernel of a

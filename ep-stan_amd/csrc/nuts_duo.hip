@@ -33,44 +33,14 @@ namespace epx {
 
 // s_setprio levels (A/B, scripts/ab_duo.py): with the critical-path shortcut the state wave is the longer of the
 // two, so the row wave must NOT outrank it (row wave 2 / state wave 0: 1 390 ms; all equal: 1 175 ms per launch)
-#ifndef EPX_ROW_IMM
-#define EPX_ROW_IMM 0            // 1: full rounds of the row pass by ds_read_b128 with immediate row offsets (A/B)
-#endif
-#ifndef EPX_PUBLISH_NOWAIT
-#define EPX_PUBLISH_NOWAIT 0
-#endif
-#ifndef EPX_DUO_SLEEP
-#define EPX_DUO_SLEEP 1
-#endif
-#ifndef EPX_T7_ROWPREF
-#define EPX_T7_ROWPREF 1         // row team: the live word is looked at behind the cavity term, not in front of the operands' reads (A/B)
-#endif
-#ifndef EPX_T7_LATELL
-#define EPX_T7_LATELL 0          // row team, lean rounds: sum g / log-likelihood fetched behind the job's publication (A/B)
-#endif
-#ifndef EPX_T7_LLAFTER
-#define EPX_T7_LLAFTER 1         // row team: the pass's log-likelihood is formed BEHIND "the results are in" and read by the books behind the next job (A/B)
-#endif
-#ifndef EPX_T7_EARLYT
-#define EPX_T7_EARLYT 1          // row team: X'g and the cavity term of the view's lanes requested first behind "the results are in" (A/B)
-#endif
-#ifndef EPX_L6_LLAFTER
-#define EPX_L6_LLAFTER 0         // layout 6: the row waves publish X'g and sum g first, the log-likelihood under the same word + DUO_LLBIT (A/B)
-#endif
-#ifndef EPX_DUO_SLEEP_BKW
+// Tuning constants.  (The A/B switches of rounds 2-4 whose losing side was measured are gone: polled hand-offs of the row
+// team, EPX_T7_ROWPREF / _LLAFTER / _EARLYT / _LATELL, EPX_ROW_IMM, EPX_PUBLISH_NOWAIT, EPX_L6_LLAFTER, EPX_PIECE_INLINE --
+// the measurements are in HISTORY.md.  What stays switchable: EPX_PIECE_FENCE, EPX_STAMPS, and EPX_YIELD at run time.)
+#define EPX_DUO_SLEEP 1          // s_sleep between two looks at a polled word (layouts 5 / 6)
 #define EPX_DUO_SLEEP_BKW 0      // layout 6 (one chain per workgroup): the waves that wait on the critical chain look again at once
-#endif
-#ifndef EPX_TEAM_BARRIER
-#define EPX_TEAM_BARRIER 1       // 1: the TEAM form's hand-offs are workgroup barriers (two per pass); 0: polled LDS words (A/B)
-#endif
-#ifndef EPX_TEAM_SLEEP
-#define EPX_TEAM_SLEEP 2         // the state waves' looks at the row team's words (a pass takes thousands of cycles)
-#endif
-#ifndef EPX_PRIO_R
 #define EPX_PRIO_R 0
 #define EPX_PRIO_S_BG 0
 #define EPX_PRIO_S_CRIT 2
-#endif
 // Hand-off words and slots live in LDS and are reached through address_space(3) pointers: through a generic pointer
 // the compiler emits flat_load / flat_store, which are counted in vmcnt AND lgkmcnt -- a wait for a polled flag or for
 // a result then also waits for every global store in flight (the tree stack's, ~1-2 us each)
@@ -82,7 +52,6 @@ __device__ inline duo_flag_t *duo_flags_at(const void *generic) { return reinter
 __device__ inline duo_lds_f64 *duo_lds_at(const void *generic) { return reinterpret_cast<duo_lds_f64 *>((uintptr_t)(unsigned)(size_t)generic); }
 enum { DUO_EXIT = -7, DUO_TIMEOUT = -99, DUO_SPIN_LIMIT = 1 << 23, DUO_NO_MORE = 1 << 30 };
 enum { DUO_RESTART = 1, DUO_LEAVE = 2 };
-enum { DUO_LLBIT = 1 << 29 };      // layout 6: a row wave's word reads seq when its sums are in, seq | DUO_LLBIT when its log-likelihood is in as well
 
 __device__ inline int duo_wait(duo_flag_t *flag, int want) {
     for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -105,32 +74,6 @@ __device__ inline int duo_wait_ge(duo_flag_t *flag, int want) {
 // rounds are pairs of tiles at compile-time distances), the tiles behind the site's rows hold zeros
 __host__ __device__ inline int team_tiles_per_wave(int n) { const int t = ((n + 15) / 16 + 3) / 4; return (t + 1) & ~1; }
 __host__ __device__ inline int team_rows(int n) { return 4 * team_tiles_per_wave(n) * 16; }
-// Row team (TEAM form): every chain of the workgroup has posted job `pass` or has left; returns the number of chains
-// still running, -1 when the wait gives up
-// (one LDS read and two vector compares per look: lane l reads word l & 3, the verdict is a ballot -- a polling wave
-// shares its SIMD's vector pipe with a wave that computes)
-__device__ inline int team_wait_jobs(duo_flag_t *f_job4, int pass, int nch, int lane) {
-    const int c = lane & 3;
-    for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
-        const int v = f_job4[c];
-        const bool gone = v == DUO_EXIT || c >= nch;
-        const unsigned long long live = __builtin_amdgcn_ballot_w64(!gone) & 0xFull;
-        if (__builtin_amdgcn_ballot_w64(gone || v == pass) == ~0ull) { asm volatile("" ::: "memory"); return __builtin_popcountll(live); }
-        __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP);
-    }
-    return -1;
-}
-// State wave (TEAM form): all four row waves have published pass `seq`
-__device__ inline int team_wait_rows(duo_flag_t *f_team4, int seq, int lane) {
-    const int w = lane & 3;
-    for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
-        const int v = f_team4[w];
-        if (__builtin_amdgcn_ballot_w64(v == seq) == ~0ull) { asm volatile("" ::: "memory"); return seq; }
-        if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) return DUO_EXIT;
-        __builtin_amdgcn_s_sleep(EPX_TEAM_SLEEP);
-    }
-    return DUO_TIMEOUT;
-}
 // Lanes of ONE wave exchange values through LDS: for the compiler that is a data race unless the stores are released
 // and the loads acquire (without it a load behind `if (lane writes) store` is taken to return what an earlier load of
 // the address returned in the lanes that did not store).  No instruction beyond the wait for the stores.
@@ -159,12 +102,7 @@ __device__ inline void ck_assign(GScal &x, double v) { x = v; }
 __device__ inline void ck_assign(RScal &x, double v) { x = v; }
 // everything this wave wrote to LDS is visible before the flag that follows
 __device__ inline void duo_publish(duo_flag_t *flag, int v) {
-#if EPX_PUBLISH_NOWAIT
-    // the LDS serves the instructions of one wave in order: the flag's store is performed behind the data's
-    asm volatile("" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     *flag = v;
 }
 // The same without the wait, for the hand-offs on the critical chain of the one-chain-per-workgroup form (layout 6): the LDS
@@ -248,7 +186,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     // RW > 1 form: they sum the four waves' partial results in wave order.
     constexpr bool TEAM = CPB == 4 && RW == 4;
     constexpr int BOFF = TEAM ? 2 : 1;                // beta behind alpha in the job (TEAM: 16-byte aligned pairs)
-    constexpr bool TBAR = TEAM && EPX_TEAM_BARRIER;   // hand-offs by workgroup barriers (see team_barrier)
+    constexpr bool TBAR = TEAM;                       // the TEAM form's hand-offs are workgroup barriers (see team_barrier)
     constexpr int MREC = 4 * NV * 64 + 4;             // mailbox entry: q, p, grad, per-element log-density terms; ll, -, generation, -
     constexpr int CREC = 4 * NV * 64 + 4;             // control record: q, p, grad, metric, eps_l, command
     constexpr int NFLAG = TEAM ? 1 : 1 + RW + (BKW ? 4 : 0);     // per chain: job, results, (mail, acknowledged, control generation, cavity term); TEAM: the job word, the team's four words behind the chains'
@@ -387,7 +325,6 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             constexpr int NJT = (NJ + 3) / 4;
             static_assert(NGF <= 4, "one 16-row group of the cavity term per row wave");
             const int lo = lane & 3, bb = (lane >> 2) & 3, hi = lane >> 4;
-            const int nch = a.chains - cb * CPB < CPB ? a.chains - cb * CPB : CPB;
             const int tpw = team_tiles_per_wave(n);       // (even; tiles beyond the site's rows are zeros and masked)
             const int t0 = wr * tpw, t1 = t0 + tpw;
             const int sdb = a.slot_doubles;
@@ -430,6 +367,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             TSTAMP_INIT;
             __builtin_amdgcn_s_setprio(EPX_PRIO_R);
             for (int pass = 1;; ++pass) {
+                (void)pass;
 #ifdef EPX_STAMPS
                 const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -443,10 +381,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 double bop[KS];
                 double alpha_c = 0.0;
                 double vb[NJ];
-                constexpr bool ROWPREF = TBAR && EPX_T7_ROWPREF;
-                if constexpr (TBAR && !ROWPREF) { team_barrier(); live = __builtin_amdgcn_readfirstlane(*f_live); }
-                else if constexpr (ROWPREF) { team_barrier(); live_raw = *f_live; live = 1; }
-                else live = team_wait_jobs(f_job, pass, nch, lane);
+                team_barrier(); live_raw = *f_live; live = 1;
 #ifdef EPX_STAMPS
                 {   // histogram of this wait: bins of 512 cycles, the last one open (fourth record of the stamps)
                     const unsigned long long dw_ = __builtin_amdgcn_s_memtime() - tw0_;
@@ -504,7 +439,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     if (bb == 0) sl[OVOFF + 16 * NGF + hi] = acc;
                 }
                 TSTAMP(1);
-                if constexpr (ROWPREF) {
+                {
                     if (__builtin_amdgcn_readfirstlane(live_raw) <= 0) {
 #ifdef EPX_STAMPS
                         if (a.stamps && wr == 0 && lane == 0) {
@@ -600,7 +535,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #pragma unroll
                 for (int c = 0; c < KS; ++c) { gacc[c] += dpp_d<0x124>(gacc[c]); gacc[c] += dpp_d<0x128>(gacc[c]); }
                 duo_lds_f64 *res = sl + RESO + wr * RREC;
-                if constexpr (TBAR && EPX_T7_LLAFTER) {
+                {
                     // The next job needs X'g and sum g; the log-likelihood -- a logarithm of 27 dependent instructions, a
                     // product with ones and two exchanges behind it -- is for the books only: it is formed behind "the
                     // results are in", in the stretch this wave waits through anyway, and read by the state wave behind the
@@ -616,16 +551,6 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     double lz = mfma4(1.0, lsum - log_ge1_d_vc(wprod), 0.0);
                     lz += dpp_d<0x124>(lz); lz += dpp_d<0x128>(lz);
                     if (bb == 0 && hi == 0) res[DP + 1] = lz;
-                } else {
-                double dz = mfma4(1.0, dsum, 0.0), lz = mfma4(1.0, lsum - log_ge1_d_vc(wprod), 0.0);
-                dz += dpp_d<0x124>(dz); lz += dpp_d<0x124>(lz);
-                dz += dpp_d<0x128>(dz); lz += dpp_d<0x128>(lz);
-                if (bb == 0) {
-#pragma unroll
-                    for (int c = 0; c < KS; ++c) res[8 * (c >> 1) + 2 * hi + (c & 1)] = gacc[c];
-                    if (hi == 0) { res[DP] = dz; res[DP + 1] = lz; }
-                }
-                if constexpr (TBAR) team_barrier(); else duo_publish(f_res + wr, pass);
                 }
                 STAMP(6);
                 TSTAMP(6);
@@ -642,11 +567,6 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             for (int r = wr * 64 + lane; r < n; r += 64 * RW, ++it)
                 if (a.y[row0 + r]) ybits |= 1ull << it;
         }
-        // LDS byte address of this lane's first row with the row's swizzle in the slot bits: slot jp of the
-        // row sits at xa ^ (jp << 4) (a row starts on a multiple of its size: the slot bits of its base are 0)
-        const unsigned xa = (unsigned)(size_t)Xs + (unsigned)(wr * 64 + lane) * (DP * 8) +
-                            (unsigned)((((wr * 64 + lane) / RPL) & (SPR - 1)) << 4);
-        (void)xa;
         STAMP_INIT;
         // the row pass is the longest link of a leapfrog's critical chain: it wins the SIMD's issue arbitration
         // against the state wave (of another chain) it shares the SIMD with, whose bookkeeping has slack
@@ -751,35 +671,6 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 for (int j = 0; j < DP; ++j) acc[j] = fma(gb, x1[j], fma(ga, x0[j], acc[j]));
             };
             int r = wr * 64 + lane;
-            if constexpr (RW == 1 && EPX_ROW_IMM) {
-                // Rounds whose 128 rows all exist: the swizzle of a row depends on r mod 16 only and r advances by
-                // multiples of 64, so slot jp of every row of this lane is `xa ^ (jp << 4)` plus a compile-time
-                // distance: one XOR per slot and round, `ds_read_b128 v, vaddr offset:imm` for both rows.
-                constexpr unsigned ROWB = DP * 8, RNDB = 128 * ROWB, HALF = 64 * ROWB;
-                constexpr int GR = 65536 / RNDB;                 // rounds per 64 KB (2 at DP = 32, 4 at DP = 16)
-                const int nfull = n >> 7;
-                for (int g0 = 0; g0 < nfull; g0 += GR) {
-                    const unsigned adv = (unsigned)g0 * RNDB;
-#pragma unroll
-                    for (int gg = 0; gg < GR; ++gg) {
-                        if (g0 + gg < nfull) {
-                            unsigned ab = xa + adv;
-                            asm volatile("" : "+v"(ab));        // the 16 slot addresses are re-derived per round, not kept
-                            double x0[DP], x1[DP];
-#pragma unroll
-                            for (int jp = 0; jp < SPR; ++jp) {
-                                const uintptr_t t = (uintptr_t)(ab ^ (unsigned)(jp << 4));
-                                const lds_v2f64 v = *reinterpret_cast<const lds_v2f64_p>(t + gg * RNDB);
-                                const lds_v2f64 w = *reinterpret_cast<const lds_v2f64_p>(t + gg * RNDB + HALF);
-                                x0[2 * jp] = v.x; x0[2 * jp + 1] = v.y;
-                                x1[2 * jp] = w.x; x1[2 * jp + 1] = w.y;
-                            }
-                            round2(x0, x1, true);
-                        }
-                    }
-                }
-                r += nfull << 7;
-            }
             if constexpr (KEEP_ROWS) {
                 if (one_round) {
                     if (k_has) round2(xk0, xk1, k_two);
@@ -808,21 +699,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 round2(x0, x1, two);
             }
             duo_lds_f64 *res = slot + (RW == 1 ? 0 : RESO + wr * RREC);
-            if constexpr (BKW && EPX_L6_LLAFTER) {
-                // Layout 6: the next job needs X'g and sum g; the log-likelihood -- a logarithm of ~27 dependent instructions
-                // and a wave sum -- is for the books.  The sums go out first (word = seq), the log-likelihood behind them
-                // (word = seq | DUO_LLBIT); the state wave looks for the second word only when it writes the mailbox entry,
-                // behind the next job's publication.  (Layout 6 never had layout 1's order of additions.)
-                butterfly<DP, 5>(acc, lane);
-                da = wave_sum(da);
-                if ((lane & ((1 << (6 - LOG)) - 1)) == 0) res[lane >> (6 - LOG)] = acc[0];
-                if (lane == 0) res[DP] = da;
-                duo_publish_c<true>(f_res + wr, seq);
-                ll -= log_ge1_d(wprod);
-                ll = wave_sum(ll);
-                if (lane == 0) res[DP + 1] = ll;
-                duo_publish_c<true>(f_res + wr, seq | DUO_LLBIT);
-            } else {
+            {
             ll -= log_ge1_d(wprod);
             butterfly<DP, 5>(acc, lane);
             // (layout 6 -- one chain per workgroup, two row waves whose partial sums the state wave adds -- never had
@@ -1144,13 +1021,12 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 
     auto rows_in = [&](int sq_) -> bool {               // the row waves' results of job sq_ are in
         if constexpr (TBAR) { team_barrier(); return true; }
-        else if constexpr (TEAM) return team_wait_rows(f_res, sq_, lane) == sq_;
         else if constexpr (BKW) {
             // one chain per workgroup: the words of the two row waves AND of the cavity-term wave in ONE look (lane w
             // reads f_res[w], lane RW reads f_ov, a ballot says whether all stand at sq_).  Three waits one after the other
             // were three LDS round trips on the critical stretch even when the second and third word had long been there.
             duo_flag_t *mine = lane < RW ? f_res + lane : (lane == RW ? f_ov : f_res);
-            const int llm = (EPX_L6_LLAFTER && lane != RW) ? ~(int)DUO_LLBIT : ~0;      // (a row wave's word may already carry the log-likelihood's bit)
+            const int llm = ~0;
             for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
                 const int v = *mine;
                 if (__builtin_amdgcn_ballot_w64(v != DUO_EXIT && (v & llm) == sq_) == ~0ull) { asm volatile("" ::: "memory"); return true; }
@@ -1164,24 +1040,6 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             for (int w = 0; w < RW; ++w) ok &= duo_wait(f_res + w, sq_) == sq_;
             return ok;
         }
-    };
-    // Layout 6 with EPX_L6_LLAFTER: the log-likelihood of job `rs` -- the row waves' words read rs | DUO_LLBIT once it is in
-    // (or rs + 1: the sums of the next job are in and its log-likelihood is not, the entry still holds this one's)
-    auto l6_ll = [&](int rs, double &out) -> bool {
-        duo_flag_t *mine = lane < RW ? f_res + lane : f_res;
-        for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
-            asm volatile("" ::: "memory");
-            const int v = *mine;
-            asm volatile("" ::: "memory");
-            double l = 0.0;
-#pragma unroll
-            for (int w = 0; w < RW; ++w) l += slot[RESO + w * RREC + DP + 1];
-            asm volatile("" ::: "memory");
-            if (__builtin_amdgcn_ballot_w64(v == (rs | (int)DUO_LLBIT) || v == rs + 1) == ~0ull) { out = l; return true; }
-            if (__builtin_amdgcn_ballot_w64(v == DUO_EXIT) != 0ull) return false;
-            __builtin_amdgcn_s_sleep(EPX_DUO_SLEEP_BKW);
-        }
-        return false;
     };
     // TEAM, barrier hand-offs: the bookkeeping of a finished SUBTREE or TRANSITION (weights, Philox draws, copies through the
     // cold store: 5 000-17 000 cycles against ~3 500 for an ordinary leaf) outlasts the team's pass, and the row waves and
@@ -1317,7 +1175,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         if (!BKW && pending) {
             pending = false;
             // the two reductions only the bookkeeping needs: off the critical path
-            if constexpr (TEAM && TBAR && EPX_T7_LLAFTER) {
+            if constexpr (TBAR) {
                 // (the row waves stored the log-likelihood of that leapfrog behind its "results are in" and in front of the
                 // barrier just passed)
                 double l4 = 0.0;
@@ -1435,7 +1293,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         double pf_da = 0.0, pf_ll = 0.0, pf_t = 0.0, pf_vo1 = 0.0, pf_vo3 = 0.0;
         if constexpr (BKW) {
             duo_flag_t *mine = lane < RW ? f_res + lane : (lane == RW ? f_ov : f_res);
-            const int llm = (EPX_L6_LLAFTER && lane != RW) ? ~(int)DUO_LLBIT : ~0;
+            const int llm = ~0;
             const int tj = lane == LA ? DP : (lane < DP ? lane : 0);
             bool ok = false;
             for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -1446,7 +1304,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #pragma unroll
                 for (int w = 0; w < RW; ++w) {
                     pf_da += slot[RESO + w * RREC + DP]; pf_t += slot[RESO + w * RREC + tj];
-                    if constexpr (!EPX_L6_LLAFTER) pf_ll += slot[RESO + w * RREC + DP + 1];
+                    pf_ll += slot[RESO + w * RREC + DP + 1];
                 }
                 pf_vo1 = slot[OVOFF + ve1]; pf_vo3 = slot[OVOFF + ve3];
                 asm volatile("" ::: "memory");
@@ -1467,12 +1325,11 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         // coordinates -- go out FIRST, in the block behind the barrier, with the sums' reads behind them: left where the
         // source has them, behind two branches, they were issued only after the sums' waits: a second LDS round trip)
         double et = 0.0, evo1 = 0.0, evo3 = 0.0;
-        constexpr bool EARLYT = TEAM && TBAR && EPX_T7_EARLYT;
+        constexpr bool EARLYT = TBAR;
         if constexpr (EARLYT) {
             et = xtg(lane == LA ? DP : (lane < DP ? lane : 0));
             evo1 = slot[OVOFF + ve1]; evo3 = slot[OVOFF + ve3];
         }
-        const bool late_ll = TEAM && TBAR && EPX_T7_LATELL && lean && fast_ok;
         double da = 0.0, ll = 0.0, dbf[NV];
         auto fetch_da_ll = [&]() {
             if constexpr (RW == 1) { da = slot[DP]; ll = slot[DP + 1]; }
@@ -1481,15 +1338,14 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #pragma unroll
                 for (int w = 0; w < RW; ++w) {
                     da += slot[RESO + w * RREC + DP];
-                    if constexpr (!(TEAM && TBAR && EPX_T7_LLAFTER)) ll += slot[RESO + w * RREC + DP + 1];
+                    if constexpr (!TBAR) ll += slot[RESO + w * RREC + DP + 1];
                 }
             }
         };
         if constexpr (BKW) {
             da = pf_da; ll = pf_ll;
-            if constexpr (EPX_L6_LLAFTER) { if (!lean) { if (!l6_ll(seq, ll)) { bail = 1; break; } } }      // (a full round reads it at once; a lean one behind the job's publication)
         }
-        else if (!late_ll) fetch_da_ll();
+        else fetch_da_ll();
         if (!lean) { FORV dbf[i] = xtg(jdx[i]); }   // (the shortcut reuses the slot for the next job: fetch first)
         else { FORV dbf[i] = 0.0; }
         if constexpr (RW > 1) {
@@ -1519,14 +1375,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             }
             ++seq;
             if constexpr (TBAR) { team_barrier(); t_job = __builtin_amdgcn_s_memtime(); } else duo_publish_c<BKW>(f_job, seq);
-            if constexpr (TEAM) { if (late_ll) fetch_da_ll(); }
             job_eps = eps_l;
             fast_pub = true;
             if (lean || TEAM) STAMP(2);  // (... slot 2 = the view's update and the job's publication; TEAM: results in -> job out)
-            // (layout 6, lean round: the log-likelihood of the job whose sums were just used -- looked for AT ONCE behind the
-            // next job's publication: the row waves overwrite it when they finish that next job, thousands of cycles from
-            // here, and the wait for the bookkeeping wave's acknowledgement further down can last longer than that)
-            if constexpr (BKW && EPX_L6_LLAFTER) { if (lean) { if (!l6_ll(seq - 1, ll)) { bail = 1; break; } } }
             if constexpr (BKW) { ctl_pre = *f_ctl; ack_pre = *f_ack; }     // requested now, used after the chain rule: no round trip then
             __builtin_amdgcn_s_setprio(EPX_PRIO_S_BG);  // the row waves are off again: what follows has their whole pass
             if constexpr (BKW) {
@@ -1791,11 +1642,7 @@ k_nuts_duo(NutsArgs a_by_value) {
 // every a.field into a vector load (876 B of scratch, 13 % slower), and __builtin_amdgcn_kernarg_segment_ptr() is null
 // inside a called function.
 template <int NV, int DP, int CPB, int RW, bool STL, bool COLD>
-#ifdef EPX_PIECE_INLINE     // (A/B: the loop around the INLINED body -- no call, no callee-saved registers)
-__device__ __attribute__((always_inline)) void duo_piece_call(unsigned long long kargs_u, int q_site, int q_t0) {
-#else
 __device__ __attribute__((noinline)) void duo_piece_call(unsigned long long kargs_u, int q_site, int q_t0) {
-#endif
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kargs_u), hi = __builtin_amdgcn_readfirstlane((unsigned)(kargs_u >> 32));
     DuoArgsK *kargs_p = (DuoArgsK *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
     duo_piece<NV, DP, CPB, RW, STL, COLD, true>(kargs_p, (int)threadIdx.x, true, __builtin_amdgcn_readfirstlane(q_site), __builtin_amdgcn_readfirstlane(q_t0));
@@ -1909,10 +1756,6 @@ static int launch_duo_one(const NutsArgs &a, int nblocks, hipStream_t stream) {
 
 template <int NV, int DP>
 static int launch_duo_shape(const NutsArgs &a, int nblocks, int cpb, int rw, hipStream_t stream) {
-#ifdef EPX_DUO_DEV      // (development builds: only the row-team instantiation of the C3 site, for quick looks at its code)
-    if (NV == 2 && DP == 32 && cpb == 4 && rw == 4) return launch_duo_one<2, 32, 4, 4>(a, nblocks, stream);
-    return -1;
-#endif
     if (cpb == 4 && rw == 1) return launch_duo_one<NV, DP, 4, 1>(a, nblocks, stream);
     if (cpb == 4 && rw == 4) return launch_duo_one<NV, DP, 4, 4>(a, nblocks, stream);
     if (cpb == 1 && rw == 2) return launch_duo_one<NV, DP, 1, 2>(a, nblocks, stream);

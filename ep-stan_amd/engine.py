@@ -295,6 +295,18 @@ class HipEngine(object):
                 raise ValueError('rate: one value per site')
         check(self.lib.epx_set_piece_queue(self.ctx, int(piece_len), None if rate is None else dptr(rate)))
 
+    def set_trace(self, sites=0):
+        """Test hook: record every transition (warm-up included) of the first `sites` sites of the next sampling calls."""
+        self._trace_sites = int(sites)
+        check(self.lib.epx_set_trace(self.ctx, int(sites)))
+
+    def get_trace(self, chains, iter):
+        """(sites, chains, iter, 8 + P): [eps used, leapfrogs, accept, depth, divergent, eps after adaptation,
+        sum of the metric, log density, sample] of every transition of the last sampling call's traced sites."""
+        out = np.zeros((min(self._trace_sites, self.K), int(chains), int(iter), 8 + self.P))
+        check(self.lib.epx_get_trace(self.ctx, dptr(out), out.size))
+        return out
+
     def last_segments(self):
         return int(self.lib.epx_last_segments(self.ctx))
 

@@ -335,6 +335,18 @@ int epx_last_split(epx_ctx *ctx);
  * looping ones -- same draws, 1-6 % slower: the device deals a grid's workgroups to its XCDs in order.)
  * piece_len <= 0 clears.  No counterpart in the reference (scheduling only). */
 int epx_set_piece_queue(epx_ctx *ctx, int piece_len, const double *rate);
+/* TEST HOOK: a per-transition trace of the sampler.  With sites > 0 every sampling call (epx_tilted_batch /
+ * epx_sample_batch) also records, for its first `sites` sites, ONE RECORD PER TRANSITION of every chain -- the warm-up
+ * included, which the draws returned to the caller (method.py:88-104: post-warm-up only) never show:
+ *   [0] step size used  [1] leapfrogs  [2] accept statistic  [3] tree depth  [4] divergent
+ *   [5] step size after stepsize_adaptation::learn_stepsize / complete_adaptation (in front of the step-size search that
+ *       follows a new metric)  [6] sum of the diagonal metric after var_adaptation::learn_variance  [7] log density
+ *   [8 .. 8 + P) the new sample.
+ * epx_get_trace copies sites x chains x iter x (8 + P) doubles.  What stands behind it in the reference is PyStan's own
+ * sampler state (get_sampler_params(inc_warmup=True), /root/reference/epstan/method.py:99-102 reads stepsize__ from it);
+ * tests/test_gpu_round5.py and bench.py's parity record compare it with the same trace of oracle/nuts_oracle.c. */
+int epx_set_trace(epx_ctx *ctx, int sites);
+int epx_get_trace(epx_ctx *ctx, double *out, long long n_out);
 /* minus the pieces per site of the last sampling call if it ran from the piece queue, 0: one workgroup per site */
 int epx_last_segments(epx_ctx *ctx);
 /* Compute units of the context's device (the host-side scheduling heuristics size themselves by it). */

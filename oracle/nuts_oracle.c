@@ -163,6 +163,41 @@ static void site_bind_scratch(site_t *s, double *w) {
     s->beta = w; s->db = w + (size_t)s->ng * s->D; s->da = s->db + (size_t)s->ng * s->D; s->Ov = s->da + s->ng;
 }
 
+#ifdef EPO_FAST
+/* TIMING BUILD ONLY (oracle/Makefile, FAST_LIB; bench.py's cpu_baseline): the logistic terms of a block of rows with
+ * branch-free polynomial exp / log1p that the compiler vectorises (libm's exp and log1p are scalar calls: 60 % of a
+ * gradient of the strict build).  Same mathematics, ~1e-16 relative; never used as the checker -- the strict build
+ * below keeps libm.  tests/test_nuts_oracle.py compares the two builds. */
+static inline double epo_exp_nonpos(double x) {          /* exp(x), x <= 0 */
+    const double xc = x < -700.0 ? -700.0 : x;
+    const double kf = rint(xc * 1.4426950408889634074);
+    double r = fma(kf, -6.93147180369123816490e-01, xc);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09); p = fma(p, r, 2.505210838544172e-08); p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06); p = fma(p, r, 2.48015873015873e-05); p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03); p = fma(p, r, 8.333333333333333e-03); p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01); p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    /* 2^k through the exponent field (k >= -1010): kf + 1.5 * 2^52 has k in its low mantissa bits */
+    union { double d; uint64_t u; } t, sc;
+    t.d = kf + 6755399441055744.0;
+    sc.u = (t.u - 0x4338000000000000ull + 1023ull) << 52;
+    return p * sc.d;
+}
+static inline double epo_log1p_unit(double e) {         /* log(1 + e), 0 <= e <= 1: 2 atanh((m-1)/(m+1)), m folded into [1/sqrt2, sqrt2] */
+    const double m = 1.0 + e;
+    const int big = m > 1.4142135623730951;
+    const double a = big ? fma(0.5, m, -1.0) : e, b = big ? fma(0.5, m, 1.0) : 2.0 + e;
+    const double sq = a / b, z = sq * sq;
+    double p = 4.7619047619047616e-02;
+    p = fma(p, z, 5.2631578947368418e-02); p = fma(p, z, 5.8823529411764705e-02); p = fma(p, z, 6.6666666666666666e-02);
+    p = fma(p, z, 7.6923076923076927e-02); p = fma(p, z, 9.0909090909090912e-02); p = fma(p, z, 1.1111111111111110e-01);
+    p = fma(p, z, 1.4285714285714285e-01); p = fma(p, z, 0.2); p = fma(p, z, 3.3333333333333331e-01); p = fma(p, z, 1.0);
+    const double rr = 2.0 * sq * p;
+    return big ? rr + 6.931471805599453094e-01 : rr;
+}
+#define EPO_BLK 16
+#endif
 /* log(1+exp(-|f|)) and sigmoid(f) sharing one exp */
 static inline void logistic_terms(double f, double y, double *ll, double *g) {
     double e = exp(-fabs(f));
@@ -201,7 +236,41 @@ static double site_lp_grad(const site_t *s, const double *th, double *grad) {
         double da = 0.0;
         for (int c = 0; c < D; ++c) db[c] = 0.0;
         const int64_t lo = s->gl ? s->gl[j] : 0, hi = s->gl ? s->gl[j + 1] : s->n;
+#ifdef EPO_FAST
+        int64_t i0 = lo;
+        if (!gauss) {
+            /* blocks of EPO_BLK rows: dot products, the logistic terms of the block in one vectorised loop, rank-1 updates */
+            for (; i0 + EPO_BLK <= hi; i0 += EPO_BLK) {
+                double fb[EPO_BLK], gb[EPO_BLK], lb[EPO_BLK];
+                for (int b = 0; b < EPO_BLK; ++b) {
+                    const double *x = s->X + (size_t)(i0 + b) * D;
+                    double f = alpha;
+#pragma omp simd reduction(+ : f)
+                    for (int c = 0; c < D; ++c) f += x[c] * beta[c];
+                    fb[b] = f;
+                }
+#pragma omp simd
+                for (int b = 0; b < EPO_BLK; ++b) {
+                    const double f = fb[b], yv = (double)s->y[i0 + b];
+                    const double e = epo_exp_nonpos(-fabs(f));
+                    const double inv = 1.0 / (1.0 + e);
+                    const double sg = (f >= 0) ? inv : e * inv;
+                    lb[b] = yv * f - (fmax(f, 0.0) + epo_log1p_unit(e));
+                    gb[b] = yv - sg;
+                }
+                for (int b = 0; b < EPO_BLK; ++b) {
+                    const double *x = s->X + (size_t)(i0 + b) * D;
+                    const double g = gb[b];
+                    ll += lb[b]; da += g;
+#pragma omp simd
+                    for (int c = 0; c < D; ++c) db[c] += g * x[c];
+                }
+            }
+        }
+        for (int64_t i = i0; i < hi; ++i) {
+#else
         for (int64_t i = lo; i < hi; ++i) {
+#endif
             const double *x = s->X + (size_t)i * D;
             double f = alpha;
             for (int c = 0; c < D; ++c) f += x[c] * beta[c];
@@ -220,6 +289,9 @@ static double site_lp_grad(const site_t *s, const double *th, double *grad) {
     for (int i = 0; i < d; ++i) {
         double acc = 0.0;
         const double *row = s->Om + (size_t)i * d;
+#ifdef EPO_FAST
+#pragma omp simd reduction(+ : acc)
+#endif
         for (int j = 0; j < d; ++j) acc += row[j] * (th[j] - s->mu[j]);
         s->Ov[i] = acc;
         quad += (th[i] - s->mu[i]) * acc;
@@ -335,6 +407,9 @@ typedef struct {
 
 static inline double kinetic(const chain_t *c, const double *p) {
     double t = 0.0;
+#ifdef EPO_FAST
+#pragma omp simd reduction(+ : t)
+#endif
     for (int i = 0; i < c->P; ++i) t += c->inv_e[i] * p[i] * p[i];
     return 0.5 * t;
 }
@@ -352,6 +427,9 @@ static void leapfrog(chain_t *c, double eps) {
 static inline int criterion(const chain_t *c, const double *psm, const double *psp,
                             const double *rho) {
     double a = 0.0, b = 0.0;
+#ifdef EPO_FAST
+#pragma omp simd reduction(+ : a, b)
+#endif
     for (int i = 0; i < c->P; ++i) { a += psp[i] * rho[i]; b += psm[i] * rho[i]; }
     return a > 0 && b > 0;
 }
@@ -534,11 +612,20 @@ static int va_learn(var_adapt *v, double *var, const double *q, int P) {
     return 0;
 }
 
+/* Per-transition trace (test hook, mirrors epx_set_trace of include/epx.h): when set, the sampling entry points record,
+ * for the first g_trace_sites sites, one record of 8 + Pm doubles per (site, chain, transition) -- warm-up included:
+ * [eps used, leapfrogs, accept, depth, divergent, eps after learn_stepsize / complete_adaptation, sum of the metric after
+ * learn_variance, log density, sample].  Not thread-safe against concurrent callers (the chains of ONE call write
+ * disjoint records). */
+static double *g_trace = NULL;
+static int g_trace_sites = 0;
+void epo_set_trace(double *buf, int sites) { g_trace = buf; g_trace_sites = sites; }
+
 /* One chain of one site update: warm-up + sampling. draws: nkeep x P row-major. */
 static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter, int warmup,
                       int thin, int max_depth, const double *init, double *draws,
                       double *last, double *stats, double eps_in, const double *inv_e_in,
-                      int t_offset, double carry_eps, const double *carry_inv_e) {
+                      int t_offset, double carry_eps, const double *carry_inv_e, double *trace, int trace_stride) {
     const int P = site_in->P, D = site_in->D, d = site_in->d;
     site_t site = *site_in;
     const size_t nvec = 24 + 4 * (size_t)EPO_MAX_DEPTH_CAP;
@@ -611,8 +698,10 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     double eps_sum = 0.0, acc_sum = 0.0, depth_sum = 0.0;
     long nleap = 0; int kept = 0, ndiv = 0, npost = 0;
     for (int t = 0; t < iter; ++t) {
+        const double eps_used = c.eps;
         trans_info ti = transition(&c, (uint32_t)(t + t_offset + 1));
         eps_sum += c.eps;
+        double eps_learned = c.eps;
         nleap += ti.nleap;
         if (t < warmup) {
             /* learn_stepsize */
@@ -624,18 +713,27 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
             double x_eta = pow(da_count, -kappa);
             x_bar = (1.0 - x_eta) * x_bar + x_eta * x;
             c.eps = exp(x);
+            eps_learned = c.eps;
             if (!carry && va_learn(&va, c.inv_e, c.qs, P)) {
                 init_stepsize(&c, (uint32_t)(t + 1));
                 da_mu = log(10.0 * c.eps);
                 da_count = 0; s_bar = 0; x_bar = 0;
             }
-            if (t == warmup - 1) c.eps = exp(x_bar);    /* complete_adaptation */
+            if (t == warmup - 1) { c.eps = exp(x_bar); eps_learned = c.eps; }    /* complete_adaptation */
         } else {
             acc_sum += ti.accept; depth_sum += ti.depth; ndiv += ti.divergent; ++npost;
             if ((t - warmup) % thin == 0) {
                 memcpy(draws + (size_t)kept * P, c.qs, sizeof(double) * P);
                 ++kept;
             }
+        }
+        if (trace) {
+            double *tr = trace + (size_t)t * trace_stride;
+            double ms = 0.0;
+            for (int i = 0; i < P; ++i) ms += c.inv_e[i];
+            tr[0] = eps_used; tr[1] = ti.nleap; tr[2] = ti.accept; tr[3] = ti.depth; tr[4] = ti.divergent;
+            tr[5] = eps_learned; tr[6] = ms; tr[7] = c.lps;
+            memcpy(tr + 8, c.qs, sizeof(double) * P);
         }
     }
     memcpy(last, c.qs, sizeof(double) * P);
@@ -729,7 +827,8 @@ int epo_nuts_sites_carry(int model, int nsites, int D, const int64_t *k_lim, con
         if (init) memcpy(in0, init + jc * Pm, sizeof(double) * s.P);
         run_chain(&s, (uint64_t)seeds[k], c, iter, warmup, thin, max_depth,
                   init ? in0 : NULL, dr, la, stats + jc * ST_COUNT, -1.0, NULL, 0,
-                  carry_eps ? carry_eps[jc] : -1.0, carry_metric ? carry_metric + (size_t)k * Pm : NULL);
+                  carry_eps ? carry_eps[jc] : -1.0, carry_metric ? carry_metric + (size_t)k * Pm : NULL,
+                  (g_trace && k < g_trace_sites) ? g_trace + jc * (size_t)iter * (8 + Pm) : NULL, 8 + Pm);
         for (int t = 0; t < nkeep; ++t) {
             double *dst = draws + (jc * nkeep + t) * Pm;
             memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);
@@ -795,7 +894,7 @@ int epo_nuts_transitions_groups(int model, int nsites, int D, const int64_t *k_l
         memcpy(in0, q0 + jc * Pm, sizeof(double) * s.P);
         memcpy(ie, inv_e + jc * Pm, sizeof(double) * s.P);
         run_chain(&s, (uint64_t)seeds[k], c, nt, 0, 1, max_depth, in0, dr, la, stats + jc * ST_COUNT, eps[jc],
-                  ie, t_offset, -1.0, NULL);
+                  ie, t_offset, -1.0, NULL, NULL, 0);
         for (int t = 0; t < nt; ++t) {
             double *dst = draws + (jc * nt + t) * Pm;
             memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);

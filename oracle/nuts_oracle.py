@@ -32,16 +32,67 @@ def build(force=False):
     return LIB
 
 
+def _restypes(L):
+    L.epo_dphi.restype = ctypes.c_int
+    L.epo_npar.restype = ctypes.c_int
+    L.epo_npar_groups.restype = ctypes.c_int
+    L.epo_num_threads.restype = ctypes.c_int
+    return L
+
+
 def lib():
+    """The library the wrappers below call: the STRICT build (-O2, no contraction: the checker), unless a caller has
+    switched to the fast build for a timing (`timing_build`)."""
     global _lib
+    if _fast_on:
+        return fast_lib()
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(LIB)
-        _lib.epo_dphi.restype = ctypes.c_int
-        _lib.epo_npar.restype = ctypes.c_int
-        _lib.epo_npar_groups.restype = ctypes.c_int
-        _lib.epo_num_threads.restype = ctypes.c_int
+        _lib = _restypes(ctypes.CDLL(LIB))
     return _lib
+
+
+_fast = None
+_fast_on = False
+
+
+def fast_lib():
+    """The same source built -O3 -march=native with contraction allowed, ON this machine (the file name carries a hash
+    of the CPU model: the GPU box's host is not this container's).  For TIMING only: bench.py's cpu_baseline."""
+    global _fast
+    if _fast is None:
+        import hashlib
+        cpu = 'unknown'
+        try:
+            for line in open('/proc/cpuinfo'):
+                if line.startswith('model name') or line.startswith('flags'):
+                    cpu += line
+                    if line.startswith('flags'):
+                        break
+        except OSError:
+            pass
+        name = 'libepx_oracle_fast_%s.so' % hashlib.sha1(cpu.encode()).hexdigest()[:10]
+        path = os.path.join(HERE, name)
+        src = os.path.join(HERE, 'nuts_oracle.c')
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(['make', '-s', '-C', HERE, name, 'FAST_LIB=' + name])
+        _fast = _restypes(ctypes.CDLL(path))
+    return _fast
+
+
+class timing_build:
+    """`with timing_build():` -- the wrappers of this module call the fast build inside the block."""
+
+    def __enter__(self):
+        global _fast_on
+        fast_lib()
+        self.was, _fast_on = _fast_on, True
+        return self
+
+    def __exit__(self, *exc):
+        global _fast_on
+        _fast_on = self.was
+        return False
 
 
 def _p(a, t=ctypes.c_double):
@@ -122,10 +173,13 @@ def carry_history(draws, stats):
 
 def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=None,
                thin=1, max_depth=10, init=None, nthreads=0, g_cnt=None, g_lim=None,
-               carry_eps=None, carry_metric=None):
+               carry_eps=None, carry_metric=None, trace_sites=0):
     """Sample every site; returns (draws (K,chains,nkeep,P), last (K,chains,P),
     stats (K,chains,8)). mu (K,d), Omega (K,d,d) symmetric.  With groups (g_cnt, g_lim) P is the
-    largest coordinate count over the sites and shorter sites are zero padded."""
+    largest coordinate count over the sites and shorter sites are zero padded.
+    trace_sites > 0: a fourth result, the per-transition trace of the first sites (sites, chains, iter, 8 + P), warm-up
+    included: [eps used, leapfrogs, accept, depth, divergent, eps after adaptation, sum of the metric, log density,
+    sample] -- the counterpart of the device library's epx_set_trace / epx_get_trace."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
     y = _y(model, y)
@@ -152,15 +206,31 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
         carry_eps = np.ascontiguousarray(carry_eps, dtype=np.float64).reshape(K, chains)
         carry_metric = np.ascontiguousarray(carry_metric, dtype=np.float64).reshape(K, P)
         ce, cm = _p(carry_eps), _p(carry_metric)
-    rc = L.epo_nuts_sites_carry(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
+    trace = None
+    if trace_sites > 0:
+        trace = np.zeros((min(int(trace_sites), K), chains, iter, 8 + P))
+        L.epo_set_trace(_p(trace), trace.shape[0])
+    try:
+        rc = _nuts_sites_call(L, model, K, D, k_lim, g_cnt, g_lim, X, y, mu, Om, seeds, chains, iter, warmup, thin, max_depth,
+                              ip, draws, last, stats, nthreads, ce, cm)
+    finally:
+        if trace is not None:
+            L.epo_set_trace(None, 0)
+    if rc != 0:
+        raise ValueError('epo_nuts_sites rc=%d' % rc)
+    if trace is not None:
+        return draws, last, stats, trace
+    return draws, last, stats
+
+
+def _nuts_sites_call(L, model, K, D, k_lim, g_cnt, g_lim, X, y, mu, Om, seeds, chains, iter, warmup, thin, max_depth,
+                     ip, draws, last, stats, nthreads, ce, cm):
+    return L.epo_nuts_sites_carry(MODEL_IDS[model], K, D, _p(k_lim, ctypes.c_int64),
                                 None if g_cnt is None else _p(g_cnt, ctypes.c_int32),
                                 None if g_cnt is None else _p(g_lim, ctypes.c_int64), _p(X),
                                 _yp(y), _p(mu), _p(Om), _p(seeds, ctypes.c_int64),
-                                chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
-                                _p(stats), nthreads, ce, cm)
-    if rc != 0:
-        raise ValueError('epo_nuts_sites rc=%d' % rc)
-    return draws, last, stats
+                                  chains, iter, warmup, thin, max_depth, ip, _p(draws), _p(last),
+                                  _p(stats), nthreads, ce, cm)
 
 
 def nuts_transitions(model, X, y, k_lim, mu, Omega, seeds, q0, eps, inv_e, nt=1, t_offset=0,

@@ -277,3 +277,35 @@ def test_random_init_is_drawn_again_until_it_is_finite():
     _, _, st2 = no.nuts_sites(model, X, y, np.arange(K + 1) * n, np.tile(mu, (K, 1)), np.tile(Om, (K, 1, 1)), seeds,
                               chains=4, iter=4, warmup=2, init=bad)
     assert np.all(st2[:, :, 7] == 1)
+
+
+def test_timing_build_agrees_with_the_strict_build():
+    """bench.py's cpu_baseline times a second build of the same source (oracle/Makefile FAST_LIB: -O3 -march=native,
+    contraction allowed, vectorised logistic terms); the strict build stays the checker.  The two agree on the log density
+    and its gradient at 1e-9, their traces of a site update agree transition by transition until a decision parts them,
+    and the tilted moments of a whole site update agree statistically."""
+    model, D, n = 'm4b_sg', 12, 150
+    X, y, mu, Om, d, P, rng = _problem(model, D, n, 11)
+    for _ in range(4):
+        th = rng.randn(P) * 0.7
+        lp, g = no.logdensity_grad(model, X, y, mu, Om, th)
+        with no.timing_build():
+            lp2, g2 = no.logdensity_grad(model, X, y, mu, Om, th)
+        assert abs(lp - lp2) <= 1e-9 * max(1.0, abs(lp))
+        np.testing.assert_allclose(g2, g, rtol=1e-9, atol=1e-9)
+    args = (model, X, y, [0, n], (0.3 * mu)[None], (Om * 50.0)[None], [5])
+    d1, _, s1, t1 = no.nuts_sites(*args, chains=4, iter=120, trace_sites=1)
+    with no.timing_build():
+        d2, _, s2, t2 = no.nuts_sites(*args, chains=4, iter=120, trace_sites=1)
+    # transition by transition until a decision parts them (a dominant cavity: most chains stay together to the end)
+    err = np.abs(t1[0, :, :, 8:] - t2[0, :, :, 8:]).max(axis=2)
+    part = (err > 1e-6) | (t1[0, :, :, 1] != t2[0, :, :, 1])
+    first = np.where(part.any(axis=1), part.argmax(axis=1), 120)
+    assert np.median(first) >= 30, first
+    for c in range(4):
+        assert first[c] == 0 or err[c, :first[c]].max() < 1e-6
+    # ... and statistically as a whole (mean within 5 MCSE-ish, sd within 35 %)
+    a, b = d1[0].reshape(-1, P)[:, :d], d2[0].reshape(-1, P)[:, :d]
+    sd = 0.5 * (a.std(axis=0) + b.std(axis=0))
+    assert np.all(np.abs(a.mean(axis=0) - b.mean(axis=0)) < 5 * sd / np.sqrt(30.0))
+    assert np.all(np.abs(a.std(axis=0) / b.std(axis=0) - 1.0) < 0.35)
