@@ -31,6 +31,7 @@ class SamplerOpts(ctypes.Structure):
 SIGNATURES = {
     'epx_last_error': (ctypes.c_char_p, []),
     'epx_device_count': (ctypes.c_int, [c_int_p]),
+    'epx_runtime_info': (ctypes.c_int, [ctypes.c_int, c_int_p, ctypes.c_char_p, ctypes.c_int]),
     'epx_device_synchronize': (ctypes.c_int, [ctypes.c_int]),
     'epx_model_dims': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p]),
     'epx_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -89,6 +90,7 @@ SIGNATURES = {
                                       c_double_p]),
     'epx_set_piece_queue': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
     'epx_set_trace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'epx_sample_piece': (ctypes.c_int, [ctypes.c_void_p, c_int64_p, ctypes.POINTER(SamplerOpts), ctypes.c_int, c_double_p, c_double_p]),
     'epx_get_trace': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_longlong]),
     'epx_last_segments': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
@@ -121,20 +123,56 @@ class EpxError(RuntimeError):
     """An entry point of libepx.so returned an error."""
 
 
+# The piece hand-off of the default build drops the release fence (csrc/epx_pieces.h): measured behaviour of THIS
+# architecture under THIS runtime, litmus-tested there (tests/test_gpu_round4.py).  Anywhere else the loader takes the
+# build that keeps the fence.  EPX_LIB overrides (a failing litmus can be answered with EPX_LIB=variants/libepx_fence.so
+# at run time, no rebuild); EPX_PIECE_FENCE=1 asks for the fence build by name.
+VALIDATED_ARCH, VALIDATED_HIP = 'gfx950', (7, 2)
+FENCE_LIB_PATH = os.path.join(os.path.dirname(HERE), 'variants', 'libepx_fence.so')
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def runtime_info(lib=None, device=0):
+    """((major, minor) of the HIP runtime, gcnArchName of the device) or (None, None) without a device."""
+    lib = lib or load()
+    n = ctypes.c_int(0)
+    if lib.epx_device_count(ctypes.byref(n)) != 0 or n.value < 1:
+        return None, None
+    v = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(64)
+    if lib.epx_runtime_info(int(device), ctypes.byref(v), buf, 64) != 0:
+        return None, None
+    return (v.value // 10000000, (v.value // 100000) % 100), buf.value.decode()
+
+
 def load():
-    """Load libepx.so; raises (never falls back) when it is missing."""
+    """Load libepx.so; raises (never falls back to a CPU path) when it is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH
+        if 'EPX_LIB' not in os.environ and os.environ.get('EPX_PIECE_FENCE', '') == '1' and os.path.exists(FENCE_LIB_PATH):
+            path = FENCE_LIB_PATH
+        if not os.path.exists(path):
             raise EpxError(
                 'libepx.so not found at {}: build it with '
                 '`python -c "import __graft_entry__ as g; g.build()"` '
-                '(there is no CPU fallback)'.format(LIB_PATH))
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
-            fn.restype = res
-            fn.argtypes = args
+                '(there is no CPU fallback)'.format(path))
+        lib = _bind(path)
+        if 'EPX_LIB' not in os.environ and path != FENCE_LIB_PATH and os.path.exists(FENCE_LIB_PATH):
+            ver, arch = runtime_info(lib)
+            if arch is not None and not (arch.startswith(VALIDATED_ARCH) and ver == VALIDATED_HIP):
+                import sys
+                print('epstan_amd: %s / HIP %s is not the platform the fence-free piece hand-off was validated on (%s / HIP %d.%d): '
+                      'loading %s' % (arch, ver, VALIDATED_ARCH, VALIDATED_HIP[0], VALIDATED_HIP[1], FENCE_LIB_PATH), file=sys.stderr)
+                lib = _bind(FENCE_LIB_PATH)
         _lib = lib
     return _lib
 

@@ -39,6 +39,20 @@ int epx_device_count(int *count) {
     return 0;
 }
 
+int epx_runtime_info(int device, int *hip_runtime_version, char *arch, int arch_len) {
+    int v = 0;
+    hipError_t e = hipRuntimeGetVersion(&v);
+    if (e != hipSuccess) return fail("hipRuntimeGetVersion: %s", hipGetErrorString(e));
+    if (hip_runtime_version) *hip_runtime_version = v;
+    if (arch && arch_len > 0) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) return fail("hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+        snprintf(arch, (size_t)arch_len, "%s", prop.gcnArchName);
+    }
+    return 0;
+}
+
 int epx_device_synchronize(int device) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -225,8 +239,8 @@ static int ctx_create(int device, int model, int K_local, int D, const int64_t *
     HIPCHK(dalloc(&c->dQi, K * d2)); HIPCHK(dalloc(&c->dri, K * d));
     // (64 columns of zeros behind the last site's cavity precision: the streaming sampler requests its columns a round
     // ahead, nuts_stream.hip)
-    HIPCHK(dalloc(&c->cav_Om, K * d2 + 64 * d)); HIPCHK(dalloc(&c->cav_mu, K * d));
-    HIPCHK(hipMemset(c->cav_Om + K * d2, 0, 64 * d * sizeof(double)));
+    HIPCHK(dalloc(&c->cav_Om, K * d2 + (size_t)EPX_OM_PAD_COLS * d)); HIPCHK(dalloc(&c->cav_mu, K * d));
+    HIPCHK(hipMemset(c->cav_Om + K * d2, 0, (size_t)EPX_OM_PAD_COLS * d * sizeof(double)));
     HIPCHK(dalloc(&c->tilt_mean, K * d)); HIPCHK(dalloc(&c->tilt_scatter, K * d2));
     HIPCHK(dalloc(&c->flags, K));
     HIPCHK(dalloc(&c->iflags, 4));
@@ -661,8 +675,11 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         c->trace_chains = o.chains; c->trace_iter = o.iter;
     }
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
-    bool use_queue = c->dyn_len > 0 && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
+    const bool hook = c->hook_t0 > 0;          // epx_sample_piece: ONE transition per site from injected checkpoint records
+    bool use_queue = (c->dyn_len > 0 || hook) && (layout == 5 || layout == 7 || layout == 3) && k0 == 0 && count == c->K &&
                      o.chains <= a.cpb && !eps_dev && !a.dbg && (o.layout == 0 || o.layout == layout);
+    if (hook && (!use_queue || c->hook_t0 >= o.iter))
+        return fail("epx_sample_piece: needs a piece-capable layout (5, 7, 3; got %d) over all sites and 0 < t0 < iter", layout);
     // Piece lengths are per site.  Default: piece_len transitions for every site.  With EPX_EQUAL_WORK_PIECES set (A/B only)
     // a site gets pieces of  piece_len x (mean rate / its rate)  transitions, within [piece_len / 4, 4 piece_len], so that
     // the workgroups of the launch last about equally long -- tried against the 10 % of idle CUs that the piece timeline of
@@ -672,8 +689,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     size_t total_pieces = 0;
     int nb_site = 0;
     if (use_queue) {
-        lens_h.assign((size_t)count, c->dyn_len);
-        if (getenv("EPX_EQUAL_WORK_PIECES") && c->dyn_has_rate && c->dyn_rate_h && (int)c->dyn_rate_h->size() >= count) {
+        lens_h.assign((size_t)count, hook ? 1 : c->dyn_len);
+        if (!hook && getenv("EPX_EQUAL_WORK_PIECES") && c->dyn_has_rate && c->dyn_rate_h && (int)c->dyn_rate_h->size() >= count) {
             double mean = 0.0;
             for (int k = 0; k < count; ++k) mean += (*c->dyn_rate_h)[k];
             mean /= count;
@@ -696,7 +713,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         // draws, one workgroup per site -- instead of failing the sampling call.
         // (looping workgroups -- the default -- keep theirs per RESIDENT workgroup: never more than 8 per CU; with one
         // workgroup per piece, EPX_PIECE_GRID, every piece has its own)
-        bool looping = !getenv("EPX_PIECE_GRID");
+        bool looping = !getenv("EPX_PIECE_GRID") && !hook;
 #ifdef EPX_STAMPS
         if (!getenv("EPX_PIECE_LOOP")) looping = false;     // (the diagnostic build's records are per workgroup: one piece each unless asked otherwise)
 #endif
@@ -723,23 +740,37 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         a.stack = c->stack;
     }
     if (use_queue) {
+        if (!c->dyn_words) HIPCHK(dalloc(&c->dyn_words, 2 * (size_t)c->K));
         HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
         a.dyn_prog = c->dyn_words; a.dyn_busy = c->dyn_words + count;
-        a.dyn_rate = c->dyn_has_rate ? c->dyn_rate : nullptr;
-        a.dyn_len = c->dyn_len; a.dyn_count = count;
+        a.dyn_rate = (c->dyn_has_rate && !hook) ? c->dyn_rate : nullptr;
+        a.dyn_len = hook ? 1 : c->dyn_len; a.dyn_count = count;
+        if (!c->dyn_words) return fail("piece queue words missing");
         if (!c->dyn_lens_d) HIPCHK(dalloc(&c->dyn_lens_d, (size_t)c->K));
         HIPCHK(hipMemcpyAsync(c->dyn_lens_d, lens_h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));            // (lens_h is a local)
         a.dyn_lens = c->dyn_lens_d; a.dyn_nb = nb_site;
         a.seg_nwg = (int)total_pieces;                      // at most one workgroup per piece ...
         a.persist = getenv("EPX_PIECE_GRID") ? 0 : 1;       // ... looping ones, as many as the device holds (the launcher cuts seg_nwg down); EPX_PIECE_GRID: the first form, for A/B
+        if (hook) {
+            // every site stands at transition t0 with the caller's records at that boundary; `count` workgroups of the
+            // one-piece-per-workgroup form claim one site each, run ONE transition, leave the record of boundary t0 + 1
+            a.seg_nwg = count; a.persist = 0;
+            std::vector<int> prog((size_t)count, 2 * c->hook_t0);
+            HIPCHK(hipMemcpy(c->dyn_words, prog.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice));
+            const size_t rec = (size_t)(4 * nv + 1) * 64;
+            for (int k = 0; k < count; ++k)
+                HIPCHK(hipMemcpy(c->ckpt + (((size_t)k * nb_site + c->hook_t0) * o.chains) * rec,
+                                 c->hook_in + (size_t)k * o.chains * rec, (size_t)o.chains * rec * 8, hipMemcpyHostToDevice));
+        }
 #ifdef EPX_STAMPS
         if (!getenv("EPX_PIECE_LOOP")) a.persist = 0;       // (the diagnostic build's records are per workgroup: one piece each unless asked otherwise)
 #endif
         a.stack = c->stack;                                  // (tree stack + cold store: one region per piece, sized above)
         a.ckpt = c->ckpt;                                    // (one record per piece boundary of a site)
         a.order = nullptr;
-        c->last_segments = -((o.iter + c->dyn_len - 1) / c->dyn_len);      // (negative: pieces per site of a queued launch, at the nominal length)
+        { const int nominal = hook ? 1 : c->dyn_len; c->last_segments = -((o.iter + nominal - 1) / nominal); }      // (negative: pieces per site of a queued launch, at the nominal length)
     }
     // Split launch (epx_set_site_split): the leading sites of the order -- the ones expected to
     // need the most leapfrogs -- run one workgroup per chain (layout 2, shorter leapfrog) on a
@@ -823,6 +854,12 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         HIPCHK(e);
         HIPCHK(es);
     }
+    if (hook && c->hook_out && !herr) {
+        const size_t rec = (size_t)(4 * nv + 1) * 64;
+        for (int k = 0; k < count; ++k)
+            HIPCHK(hipMemcpy(c->hook_out + (size_t)k * o.chains * rec,
+                             c->ckpt + (((size_t)k * nb_site + c->hook_t0 + 1) * o.chains) * rec, (size_t)o.chains * rec * 8, hipMemcpyDeviceToHost));
+    }
     if (herr) {
         HIPCHK(hipMemset(c->err_flag, 0, sizeof(int)));
         return fail("sampler: a hand-off between the waves of a chain timed out (code %d); the draws of this call are void", herr);
@@ -861,6 +898,18 @@ int epx_sample_batch(epx_ctx *c, int k0, int count, const int64_t *seeds, const 
     if (run_sampler(c, k0, count, seeds, o, elapsed_ms)) return -1;
     if (stats) HIPCHK(hipMemcpy(stats, c->site_stats, (size_t)count * 8 * 8, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int epx_sample_piece(epx_ctx *c, const int64_t *seeds, const epx_sampler_opts *opts, int t0,
+                     const double *records_in, double *records_out) {
+    CTX(c);
+    epx_sampler_opts o;
+    if (norm_opts(opts, &o)) return -1;
+    if (t0 <= 0 || !records_in) return fail("epx_sample_piece: t0 > 0 and the records of that boundary are required");
+    c->hook_t0 = t0; c->hook_in = records_in; c->hook_out = records_out;
+    const int rc = run_sampler(c, 0, c->K, seeds, o, nullptr);
+    c->hook_t0 = 0; c->hook_in = nullptr; c->hook_out = nullptr;
+    return rc ? -1 : 0;
 }
 
 int epx_tilted_batch(epx_ctx *c, int k0, int count, const int64_t *seeds, const epx_sampler_opts *opts,

@@ -103,6 +103,10 @@ struct epx_ctx {
     double *comm_stage;       // device staging of the small host-side collectives
     size_t comm_stage_n;
     int *err_flag;            // device word the sampler kernels set when a hand-off spin gives up
+    // epx_sample_piece (test hook): one piece of ONE transition from injected checkpoint records
+    int hook_t0;              // > 0 while such a call runs
+    const double *hook_in;    // host: K x chains records (csrc/epx_pieces.h layout)
+    double *hook_out;         // host: the records the piece leaves at boundary hook_t0 + 1
     // per-transition trace of the sampler (epx_set_trace, test hook): the first trace_sites sites of a sampling call
     int trace_sites, trace_chains, trace_iter;
     double *trace;

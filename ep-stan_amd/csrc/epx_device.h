@@ -41,6 +41,8 @@ __device__ inline void philox4x32(RngKey key, uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// uniform on the OPEN interval (0, 1): (v + 1/2) 2^-53 for a 53-bit integer v, so 2^-54 <= u <= 1 - 2^-54 (the Gumbel
+// keys -log(-log u) and the Box-Muller radius of the samplers never see 0 or 1)
 __device__ inline double u01(uint32_t hi, uint32_t lo) {
     uint64_t v = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
     return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
@@ -321,8 +323,9 @@ __device__ inline void logistic_terms(double f, double y, double &ll, double &g)
     g = y - s;
 }
 
-// log(x) for finite x >= 1 (a product of (1 + e) factors): x = 2^k m with m in [1/sqrt2, sqrt2),
-// log m by the same atanh series as log1p_unit_d
+// log(x) for any positive, finite, NORMAL x: x = 2^k m with m in [1/sqrt2, sqrt2) (k of either sign), log m by the same
+// atanh series as log1p_unit_d.  (Written for a product of (1 + e) factors, hence the name; the row team's state machine
+// also takes it on uniforms in (0, 1) and on -log(u) in (0, inf): see log_pos_d.)  x == 0 does NOT give -inf here.
 __device__ inline double log_ge1_d(double x) {
     int k = 0;
     double m = frexp(x, &k);                          // m in [0.5, 1)
@@ -343,6 +346,10 @@ __device__ inline double log_ge1_d(double x) {
     p = fma(p, z, 1.0);
     return fma((double)k, 6.931471805599453094e-01, 2.0 * s * p);
 }
+
+// log(x) of the bookkeeping's arguments -- a uniform of rng_u2 (strictly inside (0, 1): u01() adds one half to a 53-bit
+// integer), minus its logarithm (positive), a sum of weights (0 only when every leaf of a subtree diverged: libm's -inf)
+__device__ inline double log_pos_d(double x) { return x == 0.0 ? -INFINITY : log_ge1_d(x); }
 
 // The same terms with the logarithm left to the caller: log-likelihood term = lin - log(w),
 // w = 1 + exp(-|f|) in [1, 2].  A caller that sums many terms multiplies the w's and takes ONE

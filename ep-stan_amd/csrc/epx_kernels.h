@@ -101,6 +101,9 @@ enum { ST_STEPSIZE_MEAN = 0, ST_STEPSIZE_FINAL, ST_NLEAP, ST_NGRAD, ST_NDIV, ST_
        ST_DEPTH_MEAN, ST_FAIL, ST_COUNT };
 enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
 enum { MAX_DEPTH_CAP = 12 };
+// columns of zeros behind the last site's cavity precision (epx_api.hip allocates them): the streaming sampler's register
+// ring reads up to OM_UNROLL columns past a site's Omega (nuts_stream.hip)
+enum { EPX_OM_PAD_COLS = 64 };
 
 // Default of NutsArgs::yield_cycles: cycles of s_memtime since the state wave's last job went out PLUS the estimate of the
 // bookkeeping still ahead (EPX_SM_YIELD's argument) beyond which the wave lets a pass go by.  A team's pass lasts ~6 500

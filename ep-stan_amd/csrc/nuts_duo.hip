@@ -935,6 +935,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
         lw_m = m_new;
         sum_metro += me;
     };
+#undef SM_EXP
 
     if constexpr (BKW) {
         if (is_bk) {
@@ -1198,7 +1199,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #define EPX_T_END (int)(double)t_end_c
 #define EPX_WAVE_SUM2(a_, b_) do { if constexpr (TEAM) wave_sum2_packed(a_, b_); else wave_sum2(a_, b_); } while (0)
 #define EPX_SM_EXP(x) (TEAM ? exp_d(x) : exp(x))
-#define EPX_SM_LOG(x) (TEAM ? log_ge1_d(x) : log(x))
+#define EPX_SM_LOG(x) (TEAM ? log_pos_d(x) : log(x))
 #define EPX_SM_LSE2(a_, b_) (TEAM ? log_sum_exp2_lean(a_, b_) : log_sum_exp2(a_, b_))
 #define EPX_SM_YIELD(cycles_ahead_) sm_yield(cycles_ahead_)
 #include "nuts_state_machine.inc"

@@ -70,6 +70,7 @@ enum { SMODE_INIT = 0, SMODE_SS = 1, SMODE_TREE = 2 };
 #define EPX_OM_UNROLL 16
 #endif
 constexpr int OM_UNROLL = EPX_OM_UNROLL;   // columns of Omega in flight per thread
+static_assert(OM_UNROLL <= EPX_OM_PAD_COLS, "the cavity-column ring reads OM_UNROLL columns past a site's Omega: epx_api.hip pads EPX_OM_PAD_COLS");
 
 typedef const __attribute__((address_space(4))) NutsArgs StreamArgsK;    // the kernel arguments where they are: kernarg segment
 

@@ -113,9 +113,15 @@ class EpxComm(object):
         cenv = dict(env)
         cenv['CUDA_VISIBLE_DEVICES'] = ''          # the child talks to a TCP store: it needs no device
         cenv['HIP_VISIBLE_DEVICES'] = ''
-        out = subprocess.run([sys.executable, '-c', child, self.addr, env['MASTER_PORT'], str(self.world), key,
-                              uid.hex() if self.rank == 0 else ''], env=cenv, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                             timeout=600)
+        # (the child imports torch: 2-3 s once the image is paged in, up to a minute or two on a fresh box -- hence the limit)
+        try:
+            out = subprocess.run([sys.executable, '-c', child, self.addr, env['MASTER_PORT'], str(self.world), key,
+                                  uid.hex() if self.rank == 0 else ''], env=cenv, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                 timeout=600)
+        except subprocess.TimeoutExpired as ex:
+            raise RuntimeError('epx: the RCCL id did not travel through torchrun\'s store (%s:%s) within 600 s (rank %d of %d): %s'
+                               % (self.addr, env['MASTER_PORT'], self.rank, self.world,
+                                  (ex.stderr or b'').decode('utf-8', 'replace')[-400:]))
         if out.returncode != 0:
             raise RuntimeError('epx: the RCCL id could not travel through torchrun\'s store (%s:%s): %s'
                                % (self.addr, env['MASTER_PORT'], out.stderr.decode('utf-8', 'replace')[-400:]))

@@ -214,6 +214,37 @@ class HipEngine(object):
                                         ctypes.byref(opts), dptr(stats), ctypes.byref(ms)))
         return stats, ms.value
 
+    # ---- test hook: one teacher-forced transition from checkpoint records (epx_sample_piece)
+    CK_SCALARS = ('lps', 'eps', 'da_mu', 's_bar', 'x_bar', 'da_count', 'va_n', 'eps_sum', 'acc_sum', 'depth_sum', 'nleap_tot',
+                  'ngrad', 't', 'va_counter', 'va_wsize', 'va_next', 'ndiv', 'npost', 'kept', 'failed')     # csrc/epx_pieces.h EPX_CK_LIST
+
+    def pack_records(self, scalars, qs, wmean, wm2, inv_e):
+        """Checkpoint records of the pieced launch from their parts: scalars (..., 20) in CK_SCALARS order and four
+        (..., P) vectors -> (..., (4 NV + 1) * 64)."""
+        nv = (self.P + 63) // 64
+        rec = np.zeros(scalars.shape[:-1] + ((4 * nv + 1) * 64,))
+        for j, v in enumerate((qs, wmean, wm2, inv_e)):
+            rec[..., j * nv * 64:j * nv * 64 + self.P] = v
+        if True:
+            rec[..., 3 * nv * 64 + self.P:4 * nv * 64] = 1.0        # (the metric's padding elements are 1, as the kernels keep them)
+        rec[..., 4 * nv * 64:4 * nv * 64 + 20] = scalars
+        return rec
+
+    def unpack_records(self, rec):
+        nv = (self.P + 63) // 64
+        parts = [rec[..., j * nv * 64:j * nv * 64 + self.P] for j in range(4)]
+        return rec[..., 4 * nv * 64:4 * nv * 64 + 20], parts[0], parts[1], parts[2], parts[3]
+
+    def sample_piece(self, seeds, opts, t0, records_in):
+        """Every chain takes transition t0 of a run with `opts` from the state in records_in (K, chains, record); returns
+        the records of boundary t0 + 1."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        rin = np.ascontiguousarray(records_in, dtype=np.float64)
+        out = np.zeros_like(rin)
+        check(self.lib.epx_sample_piece(self.ctx, seeds.ctypes.data_as(_lib.c_int64_p), ctypes.byref(opts), int(t0),
+                                        dptr(rin), dptr(out)))
+        return out
+
     def moments_batch(self, samples, prec_estim, k0=0, count=None):
         """samples: (S, d, count) F-order -- the injected-draws test hook."""
         count = self.K - k0 if count is None else count

@@ -93,6 +93,12 @@ enum epx_site_stat {
 
 const char *epx_last_error(void);
 int epx_device_count(int *count);
+/* HIP runtime version (hipRuntimeGetVersion: major * 10^7 + minor * 10^5 + patch) and the device's gcnArchName.  The
+ * loader (ep-stan_amd/_lib.py) keys ONE optimisation on them: the piece hand-off without the L2 write-back fence
+ * (csrc/epx_pieces.h) is measured behaviour of gfx950 under ROCm 7.2, not an architectural guarantee -- on any other
+ * architecture or runtime the loader takes variants/libepx_fence.so (the build with the fence) when it is there.
+ * No counterpart in the reference. */
+int epx_runtime_info(int device, int *hip_runtime_version, char *arch, int arch_len);
 /* Blocks until every stream of `device` is idle (hipDeviceSynchronize).  Every entry point of a context already returns
  * with its own work finished; this is the bracket a measurement harness puts around a timed region (bench.py) without
  * bringing a second HIP runtime -- PyTorch's bundled one -- into the process. */
@@ -346,6 +352,17 @@ int epx_set_piece_queue(epx_ctx *ctx, int piece_len, const double *rate);
  * sampler state (get_sampler_params(inc_warmup=True), /root/reference/epstan/method.py:99-102 reads stepsize__ from it);
  * tests/test_gpu_round5.py and bench.py's parity record compare it with the same trace of oracle/nuts_oracle.c. */
 int epx_set_trace(epx_ctx *ctx, int sites);
+/* TEST HOOK: teacher-forced transition.  Every chain of every site takes ONE transition, number t0 (0 < t0 < iter) of a
+ * run with the given options, from the state in `records_in` -- per (site, chain) a checkpoint record of the pieced launch
+ * (csrc/epx_pieces.h: (4 NV + 1) x 64 doubles, NV = ceil(P / 64): sample, Welford mean, Welford sum of squares, metric in
+ * element order with stride NV x 64, then the 20 scalars of EPX_CK_LIST: log density, step size, dual-averaging state,
+ * window counters, statistics) -- and leaves the record of boundary t0 + 1 in `records_out`: the adaptation a warm-up
+ * transition performs (stepsize_adaptation::learn_stepsize, var_adaptation::learn_variance and the step-size search behind a
+ * new metric) becomes comparable with oracle/nuts_oracle.c from ANY state of the oracle's run, warm-up included, without
+ * the two runs having to stay together up to there.  Runs the kernels of the piece queue (layouts 5, 7, 3), one workgroup
+ * per site.  With epx_set_trace the transition's trace record is available as well. */
+int epx_sample_piece(epx_ctx *ctx, const int64_t *seeds, const epx_sampler_opts *opts, int t0,
+                     const double *records_in, double *records_out);
 int epx_get_trace(epx_ctx *ctx, double *out, long long n_out);
 /* minus the pieces per site of the last sampling call if it ran from the piece queue, 0: one workgroup per site */
 int epx_last_segments(epx_ctx *ctx);

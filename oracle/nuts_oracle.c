@@ -620,12 +620,22 @@ static int va_learn(var_adapt *v, double *var, const double *q, int P) {
 static double *g_trace = NULL;
 static int g_trace_sites = 0;
 void epo_set_trace(double *buf, int sites) { g_trace = buf; g_trace_sites = sites; }
+/* State dump (test hook, the counterpart of the device library's checkpoint records -- csrc/epx_pieces.h EPX_CK_LIST): at the
+ * transition boundaries ts[0..n) (BEFORE transition ts[i]) every chain of the first g_dump_sites sites writes
+ *   [20 scalars in EPX_CK_LIST order: lps, eps, da_mu, s_bar, x_bar, da_count, va_n, eps_sum, acc_sum, depth_sum, nleap_tot,
+ *    ngrad, t, va_counter, va_wsize, va_next, ndiv, npost, kept, failed] [qs (Pm)] [Welford mean (Pm)] [Welford m2 (Pm)] [metric (Pm)]
+ * to buf[((site * chains + chain) * n + i) * (20 + 4 Pm)]: what a device piece needs to continue the chain from there. */
+static const int *g_dump_ts = NULL;
+static int g_dump_n = 0, g_dump_sites = 0;
+static double *g_dump = NULL;
+void epo_set_dump(const int *ts, int n, double *buf, int sites) { g_dump_ts = ts; g_dump_n = n; g_dump = buf; g_dump_sites = sites; }
 
 /* One chain of one site update: warm-up + sampling. draws: nkeep x P row-major. */
 static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter, int warmup,
                       int thin, int max_depth, const double *init, double *draws,
                       double *last, double *stats, double eps_in, const double *inv_e_in,
-                      int t_offset, double carry_eps, const double *carry_inv_e, double *trace, int trace_stride) {
+                      int t_offset, double carry_eps, const double *carry_inv_e, double *trace, int trace_stride,
+                      double *dump, int dump_stride) {
     const int P = site_in->P, D = site_in->D, d = site_in->d;
     site_t site = *site_in;
     const size_t nvec = 24 + 4 * (size_t)EPO_MAX_DEPTH_CAP;
@@ -698,6 +708,21 @@ static void run_chain(const site_t *site_in, uint64_t seed, int chain, int iter,
     double eps_sum = 0.0, acc_sum = 0.0, depth_sum = 0.0;
     long nleap = 0; int kept = 0, ndiv = 0, npost = 0;
     for (int t = 0; t < iter; ++t) {
+        if (dump) {
+            for (int i = 0; i < g_dump_n; ++i) {
+                if (g_dump_ts[i] != t) continue;
+                double *r = dump + (size_t)i * dump_stride;
+                const int Pm = (dump_stride - 20) / 4;
+                r[0] = c.lps; r[1] = c.eps; r[2] = da_mu; r[3] = s_bar; r[4] = x_bar; r[5] = da_count; r[6] = va.nw;
+                r[7] = eps_sum; r[8] = acc_sum; r[9] = depth_sum; r[10] = (double)nleap; r[11] = (double)c.ngrad; r[12] = t;
+                r[13] = va.counter; r[14] = va.window_size; r[15] = va.next_window; r[16] = ndiv; r[17] = npost; r[18] = kept;
+                r[19] = 0.0;
+                memcpy(r + 20, c.qs, sizeof(double) * P);
+                memcpy(r + 20 + Pm, va.mean, sizeof(double) * P);
+                memcpy(r + 20 + 2 * Pm, va.m2, sizeof(double) * P);
+                memcpy(r + 20 + 3 * Pm, c.inv_e, sizeof(double) * P);
+            }
+        }
         const double eps_used = c.eps;
         trans_info ti = transition(&c, (uint32_t)(t + t_offset + 1));
         eps_sum += c.eps;
@@ -828,7 +853,8 @@ int epo_nuts_sites_carry(int model, int nsites, int D, const int64_t *k_lim, con
         run_chain(&s, (uint64_t)seeds[k], c, iter, warmup, thin, max_depth,
                   init ? in0 : NULL, dr, la, stats + jc * ST_COUNT, -1.0, NULL, 0,
                   carry_eps ? carry_eps[jc] : -1.0, carry_metric ? carry_metric + (size_t)k * Pm : NULL,
-                  (g_trace && k < g_trace_sites) ? g_trace + jc * (size_t)iter * (8 + Pm) : NULL, 8 + Pm);
+                  (g_trace && k < g_trace_sites) ? g_trace + jc * (size_t)iter * (8 + Pm) : NULL, 8 + Pm,
+                  (g_dump && k < g_dump_sites) ? g_dump + jc * (size_t)g_dump_n * (20 + 4 * Pm) : NULL, 20 + 4 * Pm);
         for (int t = 0; t < nkeep; ++t) {
             double *dst = draws + (jc * nkeep + t) * Pm;
             memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);
@@ -894,7 +920,7 @@ int epo_nuts_transitions_groups(int model, int nsites, int D, const int64_t *k_l
         memcpy(in0, q0 + jc * Pm, sizeof(double) * s.P);
         memcpy(ie, inv_e + jc * Pm, sizeof(double) * s.P);
         run_chain(&s, (uint64_t)seeds[k], c, nt, 0, 1, max_depth, in0, dr, la, stats + jc * ST_COUNT, eps[jc],
-                  ie, t_offset, -1.0, NULL, NULL, 0);
+                  ie, t_offset, -1.0, NULL, NULL, 0, NULL, 0);
         for (int t = 0; t < nt; ++t) {
             double *dst = draws + (jc * nt + t) * Pm;
             memcpy(dst, dr + (size_t)t * s.P, sizeof(double) * s.P);

@@ -173,13 +173,16 @@ def carry_history(draws, stats):
 
 def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=None,
                thin=1, max_depth=10, init=None, nthreads=0, g_cnt=None, g_lim=None,
-               carry_eps=None, carry_metric=None, trace_sites=0):
+               carry_eps=None, carry_metric=None, trace_sites=0, dump_at=None):
     """Sample every site; returns (draws (K,chains,nkeep,P), last (K,chains,P),
     stats (K,chains,8)). mu (K,d), Omega (K,d,d) symmetric.  With groups (g_cnt, g_lim) P is the
     largest coordinate count over the sites and shorter sites are zero padded.
     trace_sites > 0: a fourth result, the per-transition trace of the first sites (sites, chains, iter, 8 + P), warm-up
     included: [eps used, leapfrogs, accept, depth, divergent, eps after adaptation, sum of the metric, log density,
-    sample] -- the counterpart of the device library's epx_set_trace / epx_get_trace."""
+    sample] -- the counterpart of the device library's epx_set_trace / epx_get_trace.
+    dump_at (with trace_sites): transition indices; a fifth result, the chains' state BEFORE each of them,
+    (sites, chains, len(dump_at), 20 + 4 P): the 20 scalars of the device's checkpoint record (csrc/epx_pieces.h
+    EPX_CK_LIST order), then sample, Welford mean, Welford sum of squares, metric."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.float64)
     y = _y(model, y)
@@ -206,18 +209,25 @@ def nuts_sites(model, X, y, k_lim, mu, Omega, seeds, chains=4, iter=200, warmup=
         carry_eps = np.ascontiguousarray(carry_eps, dtype=np.float64).reshape(K, chains)
         carry_metric = np.ascontiguousarray(carry_metric, dtype=np.float64).reshape(K, P)
         ce, cm = _p(carry_eps), _p(carry_metric)
-    trace = None
+    trace = dump = None
     if trace_sites > 0:
         trace = np.zeros((min(int(trace_sites), K), chains, iter, 8 + P))
         L.epo_set_trace(_p(trace), trace.shape[0])
+        if dump_at is not None:
+            dts = np.ascontiguousarray(dump_at, dtype=np.int32)
+            dump = np.zeros((trace.shape[0], chains, dts.shape[0], 20 + 4 * P))
+            L.epo_set_dump(_p(dts, ctypes.c_int32), int(dts.shape[0]), _p(dump), trace.shape[0])
     try:
         rc = _nuts_sites_call(L, model, K, D, k_lim, g_cnt, g_lim, X, y, mu, Om, seeds, chains, iter, warmup, thin, max_depth,
                               ip, draws, last, stats, nthreads, ce, cm)
     finally:
         if trace is not None:
             L.epo_set_trace(None, 0)
+            L.epo_set_dump(None, 0, None, 0)
     if rc != 0:
         raise ValueError('epo_nuts_sites rc=%d' % rc)
+    if dump is not None:
+        return draws, last, stats, trace, dump
     if trace is not None:
         return draws, last, stats, trace
     return draws, last, stats
