@@ -369,7 +369,7 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
             elib.device_synchronize(local_rank)
 
     # (EPX_BENCH_SEED_SHIFT: a diagnostic of how far the leapfrog counts of the late iterations depend on the random
-    # streams -- DESIGN.md section 6; the driver's command does not set it and the line says so when it is set)
+    # streams -- HISTORY.md section 6; the driver's command does not set it and the line says so when it is set)
     shift = int(os.environ.get('EPX_BENCH_SEED_SHIFT', '0'))
     if warm > 0:
         info = M.run(warm, verbose=False, seed=1 + shift)[0]

@@ -13,6 +13,7 @@
 
 #include "../../include/epx.h"
 #include "epx_kernels.h"
+#include "epx_pieces.h"
 #include "epx_ctx.h"
 
 using namespace epx;
@@ -702,7 +703,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
             }
         }
         for (int k = 0; k < count; ++k) {
-            const int np = (o.iter + lens_h[k] - 1) / lens_h[k];
+            const int np = piece_boundaries(o.iter, lens_h[k]);     // (nominal pieces, then shorter ones behind 3/4 of the run: epx_pieces.h)
             total_pieces += np;
             nb_site = np + 1 > nb_site ? np + 1 : nb_site;
         }

@@ -107,7 +107,7 @@ enum { EPX_OM_PAD_COLS = 64 };
 
 // Default of NutsArgs::yield_cycles: cycles of s_memtime since the state wave's last job went out PLUS the estimate of the
 // bookkeeping still ahead (EPX_SM_YIELD's argument) beyond which the wave lets a pass go by.  A team's pass lasts ~6 500
-// cycles; a lost pass of one chain costs the team a quarter of a pass (~2 000 cycles): DESIGN.md section 3.1g (round 4)
+// cycles; a lost pass of one chain costs the team a quarter of a pass (~2 000 cycles): HISTORY.md section 3.1g (round 4)
 #ifndef EPX_YIELD_DEFAULT
 #define EPX_YIELD_DEFAULT 8500
 #endif

@@ -44,7 +44,7 @@ namespace epx {
 //            6. the record is read with system-scope atomic loads (ck_load: sc0 sc1, served past the L2).
 // What is NOT used between 2 and 4 is the model's release FENCE: on these parts it is `buffer_wbl2 sc1`, a write-back of
 // EVERY dirty line of the XCD's L2 -- the tree stacks and cold stores of all 32 workgroups of the XCD, which nobody else
-// ever reads (6 of the 18 GB a C3 launch wrote to HBM, section 6 of DESIGN.md).  Steps 1-2 are a release of exactly the
+// ever reads (6 of the 18 GB a C3 launch wrote to HBM, section 6 of HISTORY.md).  Steps 1-2 are a release of exactly the
 // lines that travel; the form is the one /opt/skills/guides/MI355X_MICROARCH.md lists under "Valid forms" (`sc0 sc1`
 // stores drained by every storing wave's vmcnt(0), a workgroup barrier, one lane's flag store; the consumer's acquire kept),
 // measured there on gfx950 / ROCm 7.2 and marked "not an architectural guarantee".  This is an argument from the ISA's behaviour, not from the language's memory model (for which a
@@ -65,17 +65,35 @@ template <typename T> __device__ inline void ck_assign(T &x, double v) { x = (T)
 
 // doubles of one chain's checkpoint record: sample, Welford mean and sum of squares, metric (nv x 64 each), scalars (64)
 __host__ __device__ constexpr size_t piece_record_doubles(int nv) { return (size_t)(4 * nv + 1) * 64; }
-// Every piece BOUNDARY of a site has its own record (boundary b = transitions done / piece length): an address is
-// written once per launch, by one workgroup, and read once, by another -- no XCD can hold an older version of it
-// (the first form had one record per site, and a site that came back to an XCD it had been on could read a mix of
-// that L2's older lines and fresh ones: a rare wrong trajectory, found by the EP parity test)
-// transitions of one piece of `site`: pieces hold equal PREDICTED work, so a site whose transitions are long has short ones
+// Transitions of the piece of `site` that starts at transition t0.  TWO lengths per site (round 5): the nominal one, L,
+// for the first three quarters of the run, a quarter of it (at least 1) behind transition T1 = the last multiple of L at or
+// below 3/4 of the run.  A pieced launch ends with the LAST piece of every workgroup, so on average half a piece of every
+// CU is idle at the end (at C5 a nominal piece is ~1 s of a 31 s launch): the short pieces are handed out when the queue
+// runs dry, and the claim by largest remaining work then evens the workgroups out four times finer.  (Nominal lengths are
+// per site when the host gives them -- NutsArgs::dyn_lens -- else one for all.)
 template <class Args>
 __device__ __forceinline__ int piece_len_of(Args &a, int site) { return a.dyn_lens ? a.dyn_lens[site] : a.dyn_len; }
+__host__ __device__ inline int piece_short_len(int len) { return len >= 4 ? len / 4 : 1; }
+__host__ __device__ inline int piece_switch_at(int iter, int len) { return (iter - iter / 4) / len * len; }       // T1
+__host__ __device__ inline int piece_boundaries(int iter, int len) {        // boundaries behind the start: pieces of a site
+    const int t1 = piece_switch_at(iter, len), ls = piece_short_len(len);
+    return t1 / len + (iter - t1 + ls - 1) / ls;
+}
+template <class Args>
+__device__ __forceinline__ int piece_len_at(Args &a, int site, int t0) {
+    const int len = piece_len_of(a, site);
+    return t0 < piece_switch_at(a.iter, len) ? len : piece_short_len(len);
+}
+// Every piece BOUNDARY of a site has its own record: an address is written once per launch, by one workgroup, and read
+// once, by another -- no XCD can hold an older version of it (the first form had one record per site, and a site that
+// came back to an XCD it had been on could read a mix of that L2's older lines and fresh ones: a rare wrong trajectory,
+// found by the EP parity test).  Boundary t_boundary is number t / L up to T1 and T1 / L + ceil((t - T1) / Ls) behind it
+// (the last boundary is a.iter, whatever the lengths).
 template <class Args>
 __device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundary, int chain, int nv) {
     const int len = piece_len_of(a, site);
-    const int b = (t_boundary + len - 1) / len;          // (the last boundary is a.iter, whatever the length)
+    const int t1 = piece_switch_at(a.iter, len), ls = piece_short_len(len);
+    const int b = t_boundary <= t1 ? t_boundary / len : t1 / len + (t_boundary - t1 + ls - 1) / ls;
     return a.ckpt + (((size_t)site * a.dyn_nb + b) * a.chains + chain) * piece_record_doubles(nv);
 }
 
@@ -174,7 +192,7 @@ template <class Args>
 __device__ __forceinline__ void piece_release(Args &a, unsigned char *smem) {
     volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
     const int r_site = pz[0], r_t0 = pz[1];
-    const int r_len = piece_len_of(a, r_site);
+    const int r_len = piece_len_at(a, r_site, r_t0);
     const int t1 = r_t0 + r_len < a.iter ? r_t0 + r_len : a.iter;
     // progress up, claim off: one store (agent scope: written through to where the other XCDs' claims read it; the
     // checkpoint stores of every wave are complete -- piece_checkpoint_out, then the workgroup barrier in front of this)

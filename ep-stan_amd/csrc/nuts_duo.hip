@@ -212,7 +212,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
     const int sb = queued ? q_site : (a.order ? a.order[blockIdx.x / bps] : (int)(blockIdx.x / bps));
     const int cb = queued ? 0 : blockIdx.x % bps;
     const int t_begin = queued ? q_t0 : 0;
-    const int q_len = queued ? piece_len_of(a, q_site) : 0;
+    const int q_len = queued ? piece_len_at(a, q_site, q_t0) : 0;
     const int t_end = queued ? (q_t0 + q_len < a.iter ? q_t0 + q_len : a.iter) : a.iter;
     const bool resume = t_begin > 0;
     const int k = a.k0 + sb;
@@ -605,7 +605,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                 // One chain per workgroup (layout 6): every look at the job's word asks for the job's DATA as well -- the LDS
                 // serves a wave's reads in order, so data requested behind a word that reads `seq` is that job's -- and the
                 // look that finds the word finds (alpha, beta) with it: one LDS round trip less on the critical chain of a
-                // leapfrog that is nothing but such links.  The compiler barriers keep
+                // leapfrog that is nothing but such links (HISTORY.md section 3.1f, round 4).  The compiler barriers keep
                 // the reads inside the look and in this order.
                 got = DUO_TIMEOUT;
                 for (int spin = 0; spin < DUO_SPIN_LIMIT; ++spin) {
@@ -635,7 +635,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             } else if constexpr (DP <= 16) {
                 // beta to every lane by LDS reads at a uniform address (a broadcast): 8 reads beside the rows' instead of
                 // 32 v_readlane in front of them -- at 16 columns the pass is one round of fixed costs, and the vector
-                // pipe is what it runs on (layout 6 at C2: DESIGN.md section 3.1f).  The writer keeps the entries beyond
+                // pipe is what it runs on (layout 6 at C2: HISTORY.md section 3.1f).  The writer keeps the entries beyond
                 // D at zero.  32 columns stay on scalar registers: 64 more vector registers would spill the row wave.
 #pragma unroll
                 for (int j = 0; j < DP; ++j) bs[j] = job[1 + j];

@@ -84,7 +84,7 @@ __device__ __forceinline__ void stream_piece(StreamArgsK *kargs_p, int q_site, i
     (void)tl_entry; (void)tl_claim;
     const bool queued = PIECED;
     const int t_begin = queued ? q_t0 : 0;
-    const int q_len = queued ? piece_len_of(a, q_site) : 0;
+    const int q_len = queued ? piece_len_at(a, q_site, q_t0) : 0;
     const int t_end = queued ? (q_t0 + q_len < a.iter ? q_t0 + q_len : a.iter) : a.iter;
     const bool resume = t_begin > 0;
     using V = VecS<NV>;

@@ -7,7 +7,7 @@
 // the "view" of their chain between "results in" and "jobs in" while the row team waits, and the row team multiplies
 // while the state waves keep the books at one instruction per matrix instruction.  A subtree end of ONE chain parks four
 // chains, the relay of every finished state from the view's lanes to vector order costs the state wave 60 instructions
-// and eight LDS exchanges, and the stretch between the barriers is 1 500 of a pass's ~9 500 cycles.
+// and eight LDS exchanges, and the stretch between the barriers is 1 500 of a pass's ~9 500 cycles (HISTORY.md 3.1g).
 //
 // Here the row waves own the leapfrog: row wave c carries the view of chain c (location, raw coefficient, log scale of
 // column `lane`; alpha's triple on lane 32) in ten registers.  A pass is

@@ -1,4 +1,4 @@
-// Probe for DESIGN.md section 7 item 1 (a helper workgroup on another CU integrating the other tree end):
+// Probe for HISTORY.md section 7 item 4 (a helper workgroup on another CU integrating the other tree end):
 // what does handing a state (3 vectors x 64 lanes x 8 B) from one workgroup to another through global memory cost?
 // Producer workgroup: payload stores, release store of a sequence number.  Consumer workgroup: acquire-polls the
 // number, reads the payload, checks it.  Ping-pong (the producer waits for an acknowledgement) gives the round trip;

@@ -1068,7 +1068,7 @@ def test_mix_phi_on_gpu_equals_pooled_sample_moments():
 def test_layout_policy_for_the_baseline_shapes():
     """Which thread layout the library picks by itself (epx_sampler_opts.layout = 0) for the shapes
     of BASELINE.json and of the reference's default experiment; tiny iteration counts, the point
-    is the decision."""
+    is the decision (HISTORY.md 3.1-3.1d)."""
     rng = np.random.RandomState(0)
 
     def picked(model, K, D, n, g=None, chains=4):

@@ -371,7 +371,7 @@ def test_one_damped_iteration_at_c5_site_size_through_the_sweep():
     (S = 400 draws against d = 258: the `sample` estimator's S > d + 2 barely holds)."""
     J, D, n = 64, 128, 2000
     mod = models.m4b(J, D, n)
-    data = mod.simulate_data(rng=100)                     # uncorrelated covariates (DESIGN.md section 6, footnote)
+    data = mod.simulate_data(rng=100)                     # uncorrelated covariates (HISTORY.md section 6, footnote)
     _, _, Q0, r0 = mod.get_prior()
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
                prec_estim='olse', df0=0.2)

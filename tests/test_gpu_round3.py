@@ -131,7 +131,7 @@ def test_c5_shard_launch_with_invariants():
     and one site's delta against the oracle's moment stage from the device's own draws."""
     J, D, n = 512, 128, 2000
     mod = models.m4b(J, D, n)
-    data = mod.simulate_data(rng=100)                     # uncorrelated covariates (DESIGN.md section 6, footnote)
+    data = mod.simulate_data(rng=100)                     # uncorrelated covariates (HISTORY.md section 6, footnote)
     _, _, Q0, r0 = mod.get_prior()
     M = Master(mod.site_model, data.X, data.y, site_sizes=data.Nj, prior={'Q': Q0, 'r': r0}, chains=4, iter=200,
                prec_estim='olse', df0=models.default_df0(J))
