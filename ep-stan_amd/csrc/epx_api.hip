@@ -687,6 +687,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // a C5-shard launch shows (profiles/r03_stream_piece_timeline.json) and measured SLOWER (54.6 % against 58.1 % of the
     // HBM peak: more pieces re-prime more often and the light sites' long pieces coarsen the end of the launch); kept off.
     std::vector<int> lens_h;
+    const int tail_div = getenv("EPX_PIECE_TAIL_DIV") ? (atoi(getenv("EPX_PIECE_TAIL_DIV")) > 1 ? atoi(getenv("EPX_PIECE_TAIL_DIV")) : 1) : 4;      // (A/B: 1 = one piece length throughout)
     size_t total_pieces = 0;
     int nb_site = 0;
     if (use_queue) {
@@ -703,7 +704,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
             }
         }
         for (int k = 0; k < count; ++k) {
-            const int np = piece_boundaries(o.iter, lens_h[k]);     // (nominal pieces, then shorter ones behind 3/4 of the run: epx_pieces.h)
+            const int np = piece_boundaries(o.iter, lens_h[k], tail_div);     // (nominal pieces, then shorter ones behind 3/4 of the run: epx_pieces.h)
             total_pieces += np;
             nb_site = np + 1 > nb_site ? np + 1 : nb_site;
         }
@@ -751,7 +752,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         if (!c->dyn_lens_d) HIPCHK(dalloc(&c->dyn_lens_d, (size_t)c->K));
         HIPCHK(hipMemcpyAsync(c->dyn_lens_d, lens_h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));            // (lens_h is a local)
-        a.dyn_lens = c->dyn_lens_d; a.dyn_nb = nb_site;
+        a.dyn_lens = c->dyn_lens_d; a.dyn_nb = nb_site; a.dyn_tail_div = tail_div;
         a.seg_nwg = (int)total_pieces;                      // at most one workgroup per piece ...
         a.persist = getenv("EPX_PIECE_GRID") ? 0 : 1;       // ... looping ones, as many as the device holds (the launcher cuts seg_nwg down); EPX_PIECE_GRID: the first form, for A/B
         if (hook) {

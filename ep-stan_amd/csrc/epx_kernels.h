@@ -191,6 +191,7 @@ struct NutsArgs {
     int dyn_len, dyn_count;
     const int *dyn_lens;          // per site: transitions of one of ITS pieces (pieces of equal predicted work), or NULL: dyn_len for all
     int dyn_nb;                   // checkpoint records (piece boundaries) reserved per site
+    int dyn_tail_div;             // the pieces behind 3/4 of a site's run are 1/dyn_tail_div of the nominal length (epx_pieces.h)
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int

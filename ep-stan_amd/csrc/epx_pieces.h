@@ -73,16 +73,17 @@ __host__ __device__ constexpr size_t piece_record_doubles(int nv) { return (size
 // per site when the host gives them -- NutsArgs::dyn_lens -- else one for all.)
 template <class Args>
 __device__ __forceinline__ int piece_len_of(Args &a, int site) { return a.dyn_lens ? a.dyn_lens[site] : a.dyn_len; }
-__host__ __device__ inline int piece_short_len(int len) { return len >= 4 ? len / 4 : 1; }
+// (div: NutsArgs::dyn_tail_div -- 4 by default; 1 = one length throughout, the form of rounds 2-4: EPX_PIECE_TAIL_DIV for A/B)
+__host__ __device__ inline int piece_short_len(int len, int div) { return len >= div ? len / div : 1; }
 __host__ __device__ inline int piece_switch_at(int iter, int len) { return (iter - iter / 4) / len * len; }       // T1
-__host__ __device__ inline int piece_boundaries(int iter, int len) {        // boundaries behind the start: pieces of a site
-    const int t1 = piece_switch_at(iter, len), ls = piece_short_len(len);
+__host__ __device__ inline int piece_boundaries(int iter, int len, int div) {        // boundaries behind the start: pieces of a site
+    const int t1 = piece_switch_at(iter, len), ls = piece_short_len(len, div);
     return t1 / len + (iter - t1 + ls - 1) / ls;
 }
 template <class Args>
 __device__ __forceinline__ int piece_len_at(Args &a, int site, int t0) {
     const int len = piece_len_of(a, site);
-    return t0 < piece_switch_at(a.iter, len) ? len : piece_short_len(len);
+    return t0 < piece_switch_at(a.iter, len) ? len : piece_short_len(len, a.dyn_tail_div);
 }
 // Every piece BOUNDARY of a site has its own record: an address is written once per launch, by one workgroup, and read
 // once, by another -- no XCD can hold an older version of it (the first form had one record per site, and a site that
@@ -92,7 +93,7 @@ __device__ __forceinline__ int piece_len_at(Args &a, int site, int t0) {
 template <class Args>
 __device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundary, int chain, int nv) {
     const int len = piece_len_of(a, site);
-    const int t1 = piece_switch_at(a.iter, len), ls = piece_short_len(len);
+    const int t1 = piece_switch_at(a.iter, len), ls = piece_short_len(len, a.dyn_tail_div);
     const int b = t_boundary <= t1 ? t_boundary / len : t1 / len + (t_boundary - t1 + ls - 1) / ls;
     return a.ckpt + (((size_t)site * a.dyn_nb + b) * a.chains + chain) * piece_record_doubles(nv);
 }
