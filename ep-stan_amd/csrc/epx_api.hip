@@ -687,7 +687,12 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // a C5-shard launch shows (profiles/r03_stream_piece_timeline.json) and measured SLOWER (54.6 % against 58.1 % of the
     // HBM peak: more pieces re-prime more often and the light sites' long pieces coarsen the end of the launch); kept off.
     std::vector<int> lens_h;
-    const int tail_div = getenv("EPX_PIECE_TAIL_DIV") ? (atoi(getenv("EPX_PIECE_TAIL_DIV")) > 1 ? atoi(getenv("EPX_PIECE_TAIL_DIV")) : 1) : 4;      // (A/B: 1 = one piece length throughout)
+    // Shorter pieces behind 3/4 of a site's run (epx_pieces.h): a quarter of the nominal length for the STREAMING sampler
+    // (layout 3; same-box A/B at the C5 shard: +0.7 %, profiles/r05_piece_tail_ab.txt), one length throughout for the resident
+    // layouts -- there a piece start re-stages the site's 128 KB of rows, the A/B showed no gain (546.6 / 545.9 / 545.6 /
+    // 545.8 site-updates/s) and the extra pieces cost 7 GB of HBM traffic per C3 launch.  EPX_PIECE_TAIL_DIV overrides (A/B).
+    const int tail_div = getenv("EPX_PIECE_TAIL_DIV") ? (atoi(getenv("EPX_PIECE_TAIL_DIV")) > 1 ? atoi(getenv("EPX_PIECE_TAIL_DIV")) : 1)
+                                                      : (layout == 3 ? 4 : 1);
     size_t total_pieces = 0;
     int nb_site = 0;
     if (use_queue) {
