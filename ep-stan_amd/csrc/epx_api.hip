@@ -673,7 +673,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         }
         HIPCHK(hipMemsetAsync(c->trace, 0, need * 8, c->stream));
         a.trace = c->trace; a.trace_sites = ts;
-        c->trace_chains = o.chains; c->trace_iter = o.iter;
+        c->trace_chains = o.chains; c->trace_iter = o.iter; c->trace_last_sites = ts;
     }
     // Piece queue (epx_set_piece_queue): one workgroup per piece, sites claimed by largest remaining predicted work
     const bool hook = c->hook_t0 > 0;          // epx_sample_piece: ONE transition per site from injected checkpoint records
@@ -1065,7 +1065,7 @@ int epx_set_trace(epx_ctx *c, int sites) {
 int epx_get_trace(epx_ctx *c, double *out, long long n_out) {
     CTX(c);
     if (!c->trace || c->trace_chains <= 0) return fail("no trace: epx_set_trace before the sampling call");
-    const int ts = c->trace_sites < c->K ? c->trace_sites : c->K;
+    const int ts = c->trace_last_sites;
     const size_t n = (size_t)ts * c->trace_chains * c->trace_iter * (size_t)(8 + c->P);
     if ((long long)n != n_out) return fail("trace has %zu doubles, the caller expects %lld", n, n_out);
     HIPCHK(hipMemcpy(out, c->trace, n * 8, hipMemcpyDeviceToHost));

@@ -108,7 +108,7 @@ struct epx_ctx {
     const double *hook_in;    // host: K x chains records (csrc/epx_pieces.h layout)
     double *hook_out;         // host: the records the piece leaves at boundary hook_t0 + 1
     // per-transition trace of the sampler (epx_set_trace, test hook): the first trace_sites sites of a sampling call
-    int trace_sites, trace_chains, trace_iter;
+    int trace_sites, trace_chains, trace_iter, trace_last_sites;     // (trace_last_sites: what the last sampling call recorded)
     double *trace;
     size_t trace_n;
 };

@@ -331,10 +331,11 @@ class HipEngine(object):
         self._trace_sites = int(sites)
         check(self.lib.epx_set_trace(self.ctx, int(sites)))
 
-    def get_trace(self, chains, iter):
+    def get_trace(self, chains, iter, count=None):
         """(sites, chains, iter, 8 + P): [eps used, leapfrogs, accept, depth, divergent, eps after adaptation,
-        sum of the metric, log density, sample] of every transition of the last sampling call's traced sites."""
-        out = np.zeros((min(self._trace_sites, self.K), int(chains), int(iter), 8 + self.P))
+        sum of the metric, log density, sample] of every transition of the last sampling call's traced sites
+        (`count`: the sites that call covered, when it was not all of them)."""
+        out = np.zeros((min(self._trace_sites, self.K if count is None else int(count)), int(chains), int(iter), 8 + self.P))
         check(self.lib.epx_get_trace(self.ctx, dptr(out), out.size))
         return out
 
