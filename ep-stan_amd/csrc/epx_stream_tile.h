@@ -39,6 +39,9 @@ namespace epx {
 
 constexpr int TR = 16;          // rows per ring slot
 constexpr int NSL = 6;          // ring slots: 3 resident (backward, logistic, forward) + 3 in flight
+#ifndef EPX_RING_AHEAD
+#define EPX_RING_AHEAD 3      // tiles in flight (diagnostic: 2 shows how far the launch follows the ring's depth; 3 x 17 DMA pieces is what one wave's vmcnt holds)
+#endif
 constexpr int NCH = 4;          // chain slots (waves 0..3) per workgroup
 constexpr int STREAM_WAVES = 6; // + loader (wave 4) + logistic (wave 5)
 constexpr int STREAM_THREADS = 64 * STREAM_WAVES;
@@ -281,7 +284,7 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
 template <int DPB>
 __device__ inline void ring_prime(PassArgs<DPB> &s, int lane) {
     const StreamMap M = stream_map<DPB>(s.ngmax, s.ntmax, s.gauss);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < EPX_RING_AHEAD; ++i) {
         ring_issue<DPB>(s, M, s.t_i, s.slot_i, lane);
         s.t_i = s.t_i + 1 == s.ntile ? 0 : s.t_i + 1;
         s.slot_i = s.slot_i + 1 == NSL ? 0 : s.slot_i + 1;
@@ -396,7 +399,7 @@ __device__ __attribute__((noinline)) PassOut stream_pass_impl(const double *Xg, 
         // ------------------------------------------------ loader
         int slot_i = __builtin_amdgcn_readfirstlane(s.slot_i), t_i = __builtin_amdgcn_readfirstlane(s.t_i);
         for (int p = 0; p < nt + 2; ++p) {
-            if (p < nt) wait_vm<2 * Gm::G>();   // tile p has landed; tiles p+1, p+2 stay in flight
+            if (p < nt) wait_vm<(EPX_RING_AHEAD - 1) * Gm::G>();   // tile p has landed; tiles p+1, p+2 stay in flight
             lds_barrier();
             if (p < nt) {
                 ring_issue<DPB>(s, M, t_i, slot_i, lane);       // tile p+3 -> the slot of tile p-3
