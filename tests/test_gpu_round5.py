@@ -60,11 +60,13 @@ def _parting(tr_d, tr_o):
     return t_star, before, err
 
 
-@pytest.mark.parametrize('layout', [7, 5, 3])
-def test_trace_follows_the_oracle_until_a_decision_parts_them(layout):
-    """Generic cavities (tight = 1: the funnels of the hierarchical scales are felt, trees go deep), the C3 site shape."""
+@pytest.mark.parametrize('layout,D,n', [(7, 32, 500), (5, 32, 500), (3, 32, 500), (6, 16, 200), (1, 16, 200), (2, 16, 200)])
+def test_trace_follows_the_oracle_until_a_decision_parts_them(layout, D, n):
+    """Generic cavities (tight = 1: the funnels of the hierarchical scales are felt, trees go deep); the C3 site shape for
+    the layouts of C3 / C4 / C5, the C2 site shape for C2's layout 6 (a workgroup per chain; it has no pieced form, so this
+    free-running trace is its warm-up check) and for the generic kernels 1 / 2."""
     it = 60
-    tr_d, tr_o, P = _traces('m4b_sg', 32, 500, 3, it, layout, 1.0, 41)
+    tr_d, tr_o, P = _traces('m4b_sg', D, n, 3, it, layout, 1.0, 41)
     t_star, before, err = _parting(tr_d, tr_o)
     K, C, T, _ = tr_d.shape
     n_checked = 0
