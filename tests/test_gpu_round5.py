@@ -104,7 +104,18 @@ def test_teacher_forced_warmup_transitions_at_generic_cavities(layout):
     """iter = 200: warm-up 100, the variance window ends with transition 89 (metric update + step-size search), transition
     99 completes the adaptation.  The oracle runs freely and leaves its state in front of transitions t and t + 1; the
     device starts every chain from the oracle's state at t (epx_sample_piece) and must arrive at the oracle's state at t + 1."""
-    model, D, n, K, it, chains = 'm4b_sg', 32, 500, 2, 200, 4
+    _teacher_forced('m4b_sg', 32, 500, layout, 4)
+
+
+@pytest.mark.parametrize('model,D,n', [('m1b_sg', 32, 300), ('m5b_sg', 21, 333), ('m4b_sg', 16, 200)])
+def test_teacher_forced_warmup_transitions_other_models_and_shapes(model, D, n):
+    """The same check for the model without per-coefficient scales (m1b: the plain path of the state wave), the one with a
+    third hierarchy level (m5b, odd sizes: ragged row tiles) and the C2 site shape, on the layout the headline uses."""
+    _teacher_forced(model, D, n, 7, 0)
+
+
+def _teacher_forced(model, D, n, layout, min_deep):
+    K, it, chains = 2, 200, 4
     X, y, k_lim, Oms, mus, d, P = _site_problem(model, D, n, 23, K=K, tight=1.0)
     eng, Om_dev, mu_dev = _engine_with_cavity(model, X, y, k_lim, Oms, mus)
     seeds = np.array([77, 1234], dtype=np.int64)
@@ -153,4 +164,4 @@ def test_teacher_forced_warmup_transitions_at_generic_cavities(layout):
             # the window's end: the metric changed, the dual averaging restarted around a SEARCHED step size
             assert not np.allclose(inv_e[0, 0], s0[0, 0, 20 + 3 * P:20 + 4 * P])
             assert sc[0, 0, names.index('da_count')] == 0 and sc[0, 0, names.index('va_n')] == 0
-    assert n_deep >= 4, 'the teacher-forced transitions were shallow (%d of depth >= 7)' % n_deep
+    assert n_deep >= min_deep, 'the teacher-forced transitions were shallow (%d of depth >= 7)' % n_deep
