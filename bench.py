@@ -441,6 +441,8 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         # bytes the kernel reads from LDS for the rows: one sweep of the site per gradient in the one-wave-per-chain forms;
         # layout 7 reads the rows TWICE per pass (forward and transposed product) for the FOUR gradients of a site's chains
         passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
+        tp = [x for x in getattr(M, 'team_pass_log', [])[n_launch0:] if x]
+        team_passes = float(np.mean(tp)) if team and tp else None
         lds_bytes = float(passes.mean()) * 2.0 * B_g if team else float(ngrad.mean()) * B_g
         lds_tbs = lds_bytes / t_kernel / 1e12
         roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
@@ -464,6 +466,12 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
                 'ns_per_gradient': t_kernel * 1e9 / float(ngrad.mean()),
                 'pass_cycles': (t_kernel * CLOCK_GHZ * 1e9 * min(n_cu, sites) / max(float(passes.mean()), 1.0)) if team else None,
                 'pass_cycles_note': 'layout 7 only (lock-step passes): launch_ms x %.1f GHz x min(CUs, sites) / row_passes_per_launch' % CLOCK_GHZ,
+                # what the row team really did (a device-side count; epx_get_team_passes): row_passes_per_launch counts the
+                # gradients of every site's longest chain, the team also makes the passes that chain sat out (yields)
+                'team_passes_per_launch': team_passes,
+                'team_pass_cycles': (t_kernel * CLOCK_GHZ * 1e9 * min(n_cu, sites) / team_passes) if team_passes else None,
+                'passes_lost_to_yields_share': (1.0 - float(passes.mean()) / team_passes) if team_passes else None,
+                'chains_per_team_pass': (float(ngrad.mean()) / team_passes) if team_passes else None,
                 'lds_swept_TBps': lds_tbs, 'lds_peak_TBps': LDS_PEAK_TBS, 'lds_frac': lds_tbs / LDS_PEAK_TBS,
                 'hbm_algorithmic_bytes': hbm_alg,
                 'hbm_frac': hbm_alg / t_kernel / 1e9 / HBM_PEAK_GBS}

@@ -92,6 +92,7 @@ SIGNATURES = {
     'epx_set_trace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'epx_sample_piece': (ctypes.c_int, [ctypes.c_void_p, c_int64_p, ctypes.POINTER(SamplerOpts), ctypes.c_int, c_double_p, c_double_p]),
     'epx_get_trace': (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_longlong]),
+    'epx_get_team_passes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p]),
     'epx_last_segments': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
     'epx_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),

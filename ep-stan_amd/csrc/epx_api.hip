@@ -195,7 +195,7 @@ static int ctx_create(int device, int model, int K_local, int D, const int64_t *
         }
     }
     c->dense_ws = nullptr; c->dense_ws_slots = 0;
-    c->draws = c->last = c->chain_stats = c->site_stats = c->stack = nullptr;
+    c->draws = c->last = c->chain_stats = c->site_stats = c->stack = nullptr; c->team_passes = nullptr;
     c->seeds_d = nullptr; c->inj = nullptr; c->inj_elems = 0; c->stack_elems = 0;
     c->s_chains = 0; c->s_nkeep = 0; c->has_last = 0; c->nsamp = 0; c->last_df = 0.0;
     c->stamps = nullptr; c->stamps_n = 0; c->stamps_last = 0;
@@ -291,7 +291,7 @@ int epx_ctx_destroy(epx_ctx *c) {
     void *ptrs[] = {c->dyn_lens_d, c->ckpt, c->dyn_rate, c->dyn_words, c->carry_eps, c->carry_metric, c->min_eig, c->err_flag, c->comm_stage, c->yd, c->site_g0_d, c->g_lim_d, c->sweep_buf, c->order_d, c->k_lim_d, c->X, c->y, c->y32, c->Q0, c->r0, c->Q, c->r, c->S, c->m, c->Qi, c->ri, c->Qi2,
                     c->ri2, c->dQi, c->dri, c->cav_Om, c->cav_mu, c->tilt_mean, c->tilt_scatter,
                     c->flags, c->iflags, c->packed, c->partial, c->dense_ws, c->draws, c->last,
-                    c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj, c->trace};
+                    c->chain_stats, c->site_stats, c->stack, c->seeds_d, c->dbg, c->dbg_seed, c->inj, c->trace, c->team_passes};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -463,11 +463,14 @@ static int ensure_sampler_buffers(epx_ctx *c, int chains, int nkeep) {
         if (c->chain_stats) (void)hipFree(c->chain_stats);
         if (c->site_stats) (void)hipFree(c->site_stats);
         if (c->seeds_d) (void)hipFree(c->seeds_d);
-        c->draws = c->last = c->chain_stats = c->site_stats = nullptr; c->seeds_d = nullptr;
+        if (c->team_passes) (void)hipFree(c->team_passes);
+        c->draws = c->last = c->chain_stats = c->site_stats = nullptr; c->seeds_d = nullptr; c->team_passes = nullptr;
         HIPCHK(dalloc(&c->draws, K * chains * nkeep * P));
         HIPCHK(dalloc(&c->last, K * chains * P));
         HIPCHK(dalloc(&c->chain_stats, K * chains * ST_COUNT));
         HIPCHK(dalloc(&c->site_stats, K * 8));
+        HIPCHK(dalloc(&c->team_passes, K));
+        HIPCHK(hipMemset(c->team_passes, 0, K * 8));
         HIPCHK(dalloc(&c->seeds_d, K));
         if (c->carry_eps) (void)hipFree(c->carry_eps);
         if (c->carry_metric) (void)hipFree(c->carry_metric);
@@ -656,6 +659,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     if (build_nuts_args(c, k0, count, o, a, &wpc, &dp, &nv, &layout)) return -1;
     a.seeds = c->seeds_d; a.draws = c->draws; a.last = c->last; a.chain_stats = c->chain_stats;
     a.eps_in = eps_dev; a.inv_e_in = inv_e_dev; a.t_offset = t_offset;
+    a.team_passes = c->team_passes;
+    HIPCHK(hipMemsetAsync(c->team_passes + k0, 0, (size_t)count * 8, c->stream));
     const bool want_carry = (o.reserved & 2) != 0 && !eps_dev;
     if (want_carry) { a.carry_eps = c->carry_eps; a.carry_metric = c->carry_metric; }
     a.order = (c->order_d && c->order_n == count && k0 == 0) ? c->order_d : nullptr;
@@ -1059,6 +1064,16 @@ int epx_set_trace(epx_ctx *c, int sites) {
     CTX(c);
     if (sites < 0 || sites > c->K) return fail("trace of %d sites outside 0..%d", sites, c->K);
     c->trace_sites = sites;
+    return 0;
+}
+
+int epx_get_team_passes(epx_ctx *c, int k0, int count, double *out) {
+    CTX(c);
+    if (!out) return fail("null argument");
+    if (k0 < 0 || count < 0 || k0 + count > c->K) return fail("sites %d..%d outside 0..%d", k0, k0 + count, c->K);
+    if (!c->team_passes) return fail("no sampling call yet");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->team_passes + k0, (size_t)count * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -63,6 +63,7 @@ struct epx_ctx {
     // sampler buffers (lazily sized)
     int s_chains, s_nkeep;
     double *draws, *last, *chain_stats, *site_stats, *stack;
+    double *team_passes;            // K: row-team passes of the last sampling call per site (layout 7; 0 elsewhere)
     size_t stack_elems;
     int64_t *seeds_d;
     double *dbg;              // [1+P] lp, grad ; [P] theta (test hook)

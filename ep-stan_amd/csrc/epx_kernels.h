@@ -149,6 +149,8 @@ struct NutsArgs {
     double *dbg;                  // test hook: if set, write lp and grad of the initial point (1+P) and stop
     double *trace;                // test hook (epx_set_trace): per (site of the batch < trace_sites, chain, transition) a record of 8 + P doubles
     int trace_sites;
+    double *team_passes;          // K (absolute site): passes the row team of layout 7 made over the site's rows, the ones a chain yielded
+                                  // included (added up over the pieces of a queued launch); NULL = not counted
     double *stack;                // global memory of the chains of the resident layouts, indexed by (site of the batch,
                                   // chain): stack_stride doubles each -- tree stack (max_depth * (4 NV 64 + 2)) first,
                                   // then the state wave's cold store (nuts_duo.hip); one stride for every kernel of a

@@ -367,7 +367,6 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
             TSTAMP_INIT;
             __builtin_amdgcn_s_setprio(EPX_PRIO_R);
             for (int pass = 1;; ++pass) {
-                (void)pass;
 #ifdef EPX_STAMPS
                 const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -405,6 +404,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                         a.stamps[((size_t)2 * a.stamps_nrec + blockIdx.x) * 8 + 4 + wr] += tacc[6];
                     }
 #endif
+                    if (a.team_passes && wr == 0 && lane == 0) atomicAdd(a.team_passes + k, (double)(pass - 1));
                     return;                            // [parity] row wave, behind a B1 with f_live == 0: no wave waits at a barrier again
                 }
                 // ---- operands of this pass
@@ -452,6 +452,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                             a.stamps[((size_t)2 * a.stamps_nrec + blockIdx.x) * 8 + 4 + wr] += tacc[6];
                         }
 #endif
+                        if (a.team_passes && wr == 0 && lane == 0) atomicAdd(a.team_passes + k, (double)(pass - 1));
                         return;                        // [parity] row wave, behind a B1 with f_live == 0 (the look deferred behind the cavity term)
                     }
                 }

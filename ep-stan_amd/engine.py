@@ -356,6 +356,14 @@ class HipEngine(object):
         pad = np.zeros((cs.shape[0], nb * 4)); pad[:, :chains] = cs
         return pad.reshape(cs.shape[0], nb, 4).max(axis=2).sum(axis=1)
 
+    def team_passes(self, k0=0, count=None):
+        """Layout 7 only: the passes the row team actually made per site, yielded passes included (row_passes() counts the
+        gradients of the site's longest chain: a lower bound of this)."""
+        count = self.K - k0 if count is None else count
+        out = np.zeros(count)
+        check(self.lib.epx_get_team_passes(self.ctx, int(k0), int(count), dptr(out)))
+        return out
+
     def get_chain_stats(self, chains, k0=0, count=None):
         count = self.K - k0 if count is None else count
         out = np.zeros((count, chains, N_STAT))

@@ -466,6 +466,7 @@ class Master(object):
         self.sampling_ms = []               # device time of every sampling launch (this rank)
         self.ngrad_log = []                 # gradient evaluations of every sampling launch (this rank)
         self.pass_log = []                  # passes over the site rows of every sampling launch (per site)
+        self.team_pass_log = []             # layout 7: passes the row team made per launch (all sites), else None
         self.sweep_log = []                 # results of `run(..., sweep=...)`, one dict per iteration
         self.df_log = []                    # damping factor accepted in every iteration
         self.othertime_log = []             # host time of every update phase (this rank)
@@ -805,6 +806,8 @@ class Master(object):
                 self.sampling_ms.append(ms)
                 self.ngrad_log.append(float(stats[:, 3].sum()))
                 self.pass_log.append(eng.row_passes(w0.stan_params['chains']))
+                # (layout 7: what the row team really did, yielded passes included -- a measurement aid, bench.py)
+                self.team_pass_log.append(float(eng.team_passes().sum()) if eng.last_layout() == 7 else None)
                 if self.balance_sites and self.K_local > 1:
                     # longest-first dispatch of the next iteration's workgroups (results unaffected)
                     order, n_lead = self._site_schedule(self.pass_log[-1],

@@ -364,6 +364,11 @@ int epx_set_trace(epx_ctx *ctx, int sites);
 int epx_sample_piece(epx_ctx *ctx, const int64_t *seeds, const epx_sampler_opts *opts, int t0,
                      const double *records_in, double *records_out);
 int epx_get_trace(epx_ctx *ctx, double *out, long long n_out);
+/* Passes over the site rows that the last sampling call's ROW TEAM made for sites k0 .. k0 + count - 1 (layout 7: the four
+ * chains of a site share a pass; a pass that one chain sat out while its bookkeeping ran -- a yield -- counts, which the
+ * chains' own gradient counts cannot show).  Zero for sites the other layouts sampled.  A measurement aid (bench.py's
+ * pass_cycles); nothing in the reference corresponds to it. */
+int epx_get_team_passes(epx_ctx *ctx, int k0, int count, double *out);
 /* minus the pieces per site of the last sampling call if it ran from the piece queue, 0: one workgroup per site */
 int epx_last_segments(epx_ctx *ctx);
 /* Compute units of the context's device (the host-side scheduling heuristics size themselves by it). */

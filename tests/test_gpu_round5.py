@@ -165,3 +165,22 @@ def _teacher_forced(model, D, n, layout, min_deep):
             assert not np.allclose(inv_e[0, 0], s0[0, 0, 20 + 3 * P:20 + 4 * P])
             assert sc[0, 0, names.index('da_count')] == 0 and sc[0, 0, names.index('va_n')] == 0
     assert n_deep >= min_deep, 'the teacher-forced transitions were shallow (%d of depth >= 7)' % n_deep
+
+
+def test_team_passes_count_what_the_row_team_did():
+    """epx_get_team_passes (layout 7): a device-side count of the lock-step passes, the ones a chain yielded included --
+    never fewer than the gradients of the site's longest chain, and not many more; zero under the other layouts."""
+    X, y, k_lim, Oms, mus, d, P = _site_problem('m4b_sg', 32, 500, 5, K=3, tight=1.0)
+    eng, Om_dev, mu_dev = _engine_with_cavity('m4b_sg', X, y, k_lim, Oms, mus)
+    seeds = np.arange(3, dtype=np.int64) + 11
+    for layout in (7, 5):
+        opts = HipEngine.sampler_opts(chains=4, iter=40, warmup=None, init='random', layout=layout)
+        eng.sample_batch(seeds, opts)
+        assert eng.last_layout() == layout
+        tp, rp = eng.team_passes(), eng.row_passes(4)
+        if layout == 7:
+            longest = eng.get_chain_stats(4)[:, :, 3].max(axis=1)
+            assert np.all(tp >= longest) and np.all(tp <= 1.3 * longest + 8), (tp, longest)
+            assert np.array_equal(rp, longest)
+        else:
+            assert np.all(tp == 0)
