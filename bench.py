@@ -443,7 +443,7 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         passes = np.array([p.sum() for p in M.pass_log[n_launch0:]])
         tp = [x for x in getattr(M, 'team_pass_log', [])[n_launch0:] if x]
         team_passes = float(np.mean(tp)) if team and tp else None
-        lds_bytes = float(passes.mean()) * 2.0 * B_g if team else float(ngrad.mean()) * B_g
+        lds_bytes = (team_passes or float(passes.mean())) * 2.0 * B_g if team else float(ngrad.mean()) * B_g     # (the team's own count when the library has one: yielded passes sweep the rows too)
         lds_tbs = lds_bytes / t_kernel / 1e12
         roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
                 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
