@@ -399,10 +399,14 @@ __device__ inline void logistic_pair_lean(double fa, double fb, double ya, doubl
                                           double &wa, double &wb, double &ga, double &gb) {
     // -|f| clamped at -800 by ONE instruction (same value as fmin(fmax(-|f|, -800), 800): the compiler's form of it
     // canonicalises -|f| with a v_max of its own first and keeps the idle upper clamp: three instructions)
+    // (fa, fb may come STRAIGHT from v_mfma_f64_4x4x4 -- the row team adds alpha through the accumulator -- and the
+    // compiler's hazard recogniser does not look into inline assembly: a VALU read of a DGEMM 4x4x4 result needs 6 wait
+    // states, which only the instructions that happen to be scheduled in between provided.  Under another machine
+    // scheduler (-amdgpu-sched-strategy=iterative-minreg, round 5) they were not there and every layout-7 test failed; the
+    // s_nop makes the distance part of the statement: 6 cycles per two tiles)
     double ca, cb;
     const double lim = -800.0;
-    asm("v_max_f64 %0, -|%1|, %2" : "=v"(ca) : "v"(fa), "s"(lim));
-    asm("v_max_f64 %0, -|%1|, %2" : "=v"(cb) : "v"(fb), "s"(lim));
+    asm("s_nop 5\n\tv_max_f64 %0, -|%2|, %4\n\tv_max_f64 %1, -|%3|, %4" : "=&v"(ca), "=&v"(cb) : "v"(fa), "v"(fb), "s"(lim));
     const double ka = __builtin_rint(ca * 1.4426950408889634074), kb = __builtin_rint(cb * 1.4426950408889634074);
     double ra = fma(ka, -6.93147180369123816490e-01, ca), rb = fma(kb, -6.93147180369123816490e-01, cb);
     ra = fma(ka, -1.90821492927058770002e-10, ra); rb = fma(kb, -1.90821492927058770002e-10, rb);
