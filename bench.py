@@ -344,6 +344,7 @@ def spawn_ranks(n, argv):
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault('EPX_COMM_PORT', str(port2))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # (the pool's driver only supports dmabuf IPC: RCCL across processes needs it)
     return subprocess.call(cmd, env=env)
 
 
@@ -558,6 +559,7 @@ def main():
     steps = args.steps if args.steps is not None else steps
     warm = args.warmup if args.warmup is not None else warm
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before anything touches the GPU (see spawn_ranks)
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
