@@ -574,3 +574,35 @@ def test_named_draws_restates_the_transformed_parameters():
     np.testing.assert_allclose(og['beta'][:, 1, :], thg[:, 2:2 + D] + thg[:, 2 * D + 2 + ng + D:] * np.exp(thg[:, 2 + D:2 + 2 * D]))
     with pytest.raises(ValueError):
         sp.named_draws(0, D, 1, False, True, th1, ['etb'])
+
+
+def test_inline_assembly_behind_a_matrix_result_keeps_its_wait_states(tmp_path):
+    """gfx950 leaves the MFMA -> VALU read distance to software and LLVM's hazard recogniser does not look into inline
+    assembly: the row team's logistic clamp (`logistic_pair_lean`, epx_device.h) may be handed
+    the result of v_mfma_f64_4x4x4 directly and has to bring its own 6 wait states.  Compile exactly that and count."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = tmp_path / 'haz.hip'
+    src.write_text('#include <hip/hip_runtime.h>\n#include "epx_device.h"\n'
+                   '__global__ void k(double *x, double a, double b) {\n'
+                   '    double f0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, x[threadIdx.x], 0, 0, 0);\n'
+                   '    double f1 = __builtin_amdgcn_mfma_f64_4x4x4f64(b, a, x[threadIdx.x + 64], 0, 0, 0);\n'
+                   '    double l0, l1, w0, w1, g0, g1;\n'
+                   '    epx::logistic_pair_lean(f0, f1, 1.0, 0.0, l0, l1, w0, w1, g0, g1);\n'
+                   '    x[threadIdx.x] = l0 + l1 + w0 + w1 + g0 + g1;\n}\n')
+    out = tmp_path / 'haz.s'
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only', '-S',
+                    '-I', os.path.join(ROOT, 'ep-stan_amd', 'csrc'), str(src), '-o', str(out)],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    ins = [l.strip() for l in out.read_text().splitlines() if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
+    last_mfma = max(i for i, l in enumerate(ins) if l.startswith('v_mfma_f64_4x4x4'))
+    first_max = min(i for i, l in enumerate(ins) if l.startswith('v_max_f64') and i > last_mfma)
+    waits = 0
+    for l in ins[last_mfma + 1:first_max]:
+        m = re.match(r's_nop (\d+)', l)
+        waits += int(m.group(1)) + 1 if m else 1
+    assert waits >= 6, ins[last_mfma:first_max + 1]
