@@ -211,6 +211,8 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
     const int nval = __builtin_amdgcn_readfirstlane(*lds_i(s.lds0 + M.tdesc + tt * 8 + 4)) & 255;
     if (nval == TR) {
         // full tile: one scalar base + the precomputed lane offsets
+        // (the base comes out of v_readfirstlane: a VMEM read of an SGPR that a VALU instruction wrote needs 5 wait states,
+        // and the compiler's hazard recogniser does not look into the statement -- s_mov, s_mov, s_nop 2 are those five)
         const unsigned long long base = (unsigned long long)(s.Xg + (size_t)row0 * s.D);
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
         const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
@@ -218,7 +220,7 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
         unsigned keep;
         if constexpr (Gm::NI == 16) {
             asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" EPX_NT "\n\t"
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %3, %2" EPX_NT "\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2" EPX_NT "\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2" EPX_NT "\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2" EPX_NT "\n\t"
@@ -242,7 +244,7 @@ __device__ inline void ring_issue(const PassArgs<DPB> &s, const StreamMap &M, in
                 : "memory", "scc");
         } else {
             asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2" EPX_NT "\n\t"
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %3, %2" EPX_NT "\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2" EPX_NT "\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2" EPX_NT "\n\t"
                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %2" EPX_NT "\n\t"

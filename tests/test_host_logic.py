@@ -606,3 +606,46 @@ def test_inline_assembly_behind_a_matrix_result_keeps_its_wait_states(tmp_path):
         m = re.match(r's_nop (\d+)', l)
         waits += int(m.group(1)) + 1 if m else 1
     assert waits >= 6, ins[last_mfma:first_max + 1]
+
+
+def test_row_dma_reads_its_scalar_base_five_wait_states_behind_readfirstlane(tmp_path):
+    """The second software-managed distance of the hand-written assembly: a VMEM instruction that
+    reads an SGPR which a VALU instruction (v_readfirstlane) wrote needs 5 wait states.  The LDS-DMA pieces of the
+    streaming sampler's ring take their scalar base that way (`ring_issue`, epx_stream_tile.h): compile it and count."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = tmp_path / 'dma.hip'
+    src.write_text('#include <hip/hip_runtime.h>\n#include "epx_stream_tile.h"\n'
+                   '__global__ void k(const double *X, const int *y, int D, int tt, int slot) {\n'
+                   '    extern __shared__ double smem[];\n'
+                   '    epx::PassArgs<128> s;\n'
+                   '    s.Xg = X; s.yg = y; s.gauss = 0; s.n = 2000; s.D = D; s.ntile = 125; s.ngmax = 1; s.ntmax = 125;\n'
+                   '    s.lds0 = (unsigned)(size_t)smem; s.slot_f = 0; s.slot_i = 0; s.t_i = 0; s.wave = 4; s.lane = threadIdx.x;\n'
+                   '    epx::loader_init<128>(s, threadIdx.x);\n'
+                   '    const epx::StreamMap M = epx::stream_map<128>(1, 125, 0);\n'
+                   '    epx::ring_issue<128>(s, M, tt, slot, threadIdx.x);\n}\n')
+    out = tmp_path / 'dma.s'
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only', '-S',
+                    '-I', os.path.join(ROOT, 'ep-stan_amd', 'csrc'), str(src), '-o', str(out)],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    # the statement has to be self-sufficient: wherever the compiler puts the v_readfirstlane, the wait states INSIDE the
+    # assembly block in front of its first scalar-base DMA are at least 5
+    blocks = out.read_text().split(';;#ASMSTART')[1:]
+    checked = 0
+    for b in blocks:
+        body = [l.strip() for l in b.split(';;#ASMEND')[0].splitlines() if l.strip()]
+        loads = [i for i, l in enumerate(body) if re.match(r'global_load_lds_dwordx4 v\d+, s\[', l)]
+        if not loads:
+            continue
+        waits = 0
+        for l in body[:loads[0]]:
+            n = re.match(r's_nop (\d+)', l)
+            waits += int(n.group(1)) + 1 if n else 1
+        assert waits >= 5, body[:loads[0] + 1]
+        assert len(loads) == 16                        # the 16 pieces of a full tile, every later one behind an M0 update + s_nop
+        checked += 1
+    assert checked >= 1
