@@ -542,8 +542,8 @@ def main():
     ap.add_argument('--adapt', default='fresh', choices=['fresh', 'carry'],
                     help="'fresh' = the reference's behaviour (default, the headline); 'carry' = opt-in carried adaptation")
     ap.add_argument('--cor-input', type=int, default=None, help='0: uncorrelated covariates (fit.py cor_input=False)')
-    ap.add_argument('--cpu-sites', type=int, default=64, help='sites of the all-cores cpu_baseline leg (fast build); 0 disables it')
-    ap.add_argument('--parity-sites', type=int, default=32, help='sites the strict build re-does for the parity record')
+    ap.add_argument('--cpu-sites', type=int, default=None, help='sites of the all-cores cpu_baseline leg (fast build); 0 disables it; default: 64 on a host of 256 threads, a quarter of the threads otherwise (the leg stays ~1 min)')
+    ap.add_argument('--parity-sites', type=int, default=None, help='sites the strict build re-does for the parity record (default: half of --cpu-sites, at most 32)')
     ap.add_argument('--cpu-seq-sites', type=int, default=3, help='sites of the reference-faithful schedule')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-secondary', dest='secondary', action='store_false',
@@ -560,6 +560,12 @@ def main():
     warm = args.warmup if args.warmup is not None else warm
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before anything touches the GPU (see spawn_ranks)
+    # the CPU legs are sized by the host (they are a bounded sample, and the default run has to stay within minutes): 4 work
+    # items per site, one per thread -> 64 sites on the pool's 256-thread hosts, fewer on a smaller one
+    if args.cpu_sites is None:
+        args.cpu_sites = int(min(64, max(4, (os.cpu_count() or 1) // 4)))
+    if args.parity_sites is None:
+        args.parity_sites = int(min(32, max(2, args.cpu_sites // 2))) if args.cpu_sites > 0 else 0
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
