@@ -20,6 +20,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -71,6 +72,73 @@ def cpu_model_name():
     return 'unknown'
 
 
+def host_cpu_limits():
+    """What this process may really use of the host's processors: the affinity mask, the cgroup CPU quota (v2 cpu.max, v1
+    cfs_quota_us / cfs_period_us; the process's own cgroup first, then the root of the mounted hierarchy) and the load
+    other processes already put on the box.  os.cpu_count() sees none of these."""
+    lim = {'host_threads': os.cpu_count(), 'affinity': None, 'cgroup_quota_cpus': None, 'cgroup_source': None,
+           'loadavg_1min': None}
+    try:
+        lim['affinity'] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        lim['loadavg_1min'] = float(open('/proc/loadavg').read().split()[0])
+    except (OSError, ValueError):
+        pass
+    rel = []
+    try:
+        for line in open('/proc/self/cgroup'):
+            parts = line.strip().split(':', 2)
+            if len(parts) == 3 and (parts[1] == '' or 'cpu' in parts[1].split(',')):
+                rel.append(parts[2].lstrip('/'))
+    except OSError:
+        pass
+    cands = []
+    for r in rel + ['']:
+        # walk up from the process's cgroup to the mounted root: the tightest quota on the way binds
+        parts = [x for x in r.split('/') if x]
+        for i in range(len(parts), -1, -1):
+            sub = '/'.join(parts[:i])
+            cands.append(os.path.join('/sys/fs/cgroup', sub, 'cpu.max'))
+            cands.append(os.path.join('/sys/fs/cgroup/cpu', sub, 'cpu.cfs_quota_us'))
+            cands.append(os.path.join('/sys/fs/cgroup/cpu,cpuacct', sub, 'cpu.cfs_quota_us'))
+    best = None
+    for path in cands:
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] == 'max':
+                    continue
+                q = float(txt[0]) / float(txt[1])
+            else:
+                quota = float(txt[0])
+                if quota <= 0:
+                    continue
+                q = quota / float(open(os.path.join(os.path.dirname(path), 'cpu.cfs_period_us')).read().split()[0])
+            if best is None or q < best[0]:
+                best = (q, path)
+        except (OSError, ValueError, IndexError):
+            continue
+    if best is not None:
+        lim['cgroup_quota_cpus'], lim['cgroup_source'] = best
+    return lim
+
+
+def cpu_width(lim, requested=0):
+    """Threads of the CPU legs: what the process can really run at once -- the affinity mask capped by the cgroup quota
+    (16 CPUs of the 256 hardware threads on this pool's GPU boxes, profiles/r06_cpu_probe.txt: beyond the quota more
+    threads only take turns, and gradient throughput FALLS, 1.22e6/s on 64 threads -> 0.75e6/s on 256)."""
+    if requested > 0:
+        return int(requested), 'requested (--cpu-threads)'
+    w = lim['affinity'] or lim['host_threads'] or 1
+    why = 'affinity mask'
+    q = lim['cgroup_quota_cpus']
+    if q is not None and q < w:
+        w, why = max(1, int(q)), 'cgroup CPU quota %.4g (%s)' % (q, lim['cgroup_source'])
+    return int(w), why
+
+
 PARITY_SEED = 3      # seed of the one EP iteration behind the timed region that the CPU leg re-does (Master.run(1, seed=...))
 
 
@@ -109,7 +177,7 @@ def snapshot_for_cpu_leg(M, n_all, chains, siter):
     return {'n_all': n_all, 'mus': mus, 'Oms': Oms, 'last': last, 'Q': Q, 'r': r}
 
 
-def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par):
+def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=None):
     """The CPU port (oracle/, kind 'port') on this box's host cores re-does, for the first sites of the workload, the site
     updates of ONE EP iteration that the device has just run behind the timed region (`Master.run(1, seed=PARITY_SEED)`):
     same cavities, same starting draws, same per-site Stan seeds (method.py:342-346), the C restatement of the sampler +
@@ -122,7 +190,10 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par):
     `n_par` sites -- its time is stated beside the fast one's.  tests/test_nuts_oracle.py holds the two builds together
     (gradients at 1e-9, a site update statistically).
     Two schedules are timed:
-      all-cores           (site, chain) pairs spread over every host thread;
+      all-cores           (site, chain) pairs handed out dynamically to as many threads as the process can really run at
+                          once (cpu_width: affinity mask capped by the cgroup quota) -- `cores` is that number, and the record
+                          carries the CPUs the kernel actually delivered (process CPU time / wall time of the leg) and the
+                          per-thread cost beside the 4-thread leg's, so the count is checked by the timings;
       reference-faithful  sites strictly one after the other, the 4 chains of a site on 4 threads
                           (PyStan n_jobs=-1 inside method.py:1005-1023), plus the reference's own
                           "limiting sampling time" = max over sites (method.py:1043)."""
@@ -141,48 +212,73 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par):
     X, y = M.X[:lim[-1]], M.y[:lim[-1]]
     # the Stan seeds the device used for these sites in the parity iteration
     seeds = stan_seeds(run_seeds(PARITY_SEED, 1, M.K)[0, M.k_lo:M.k_hi])[:n_all].astype(np.int64)
-    nthr = threads if threads > 0 else no.lib().epo_num_threads()
+    limits = limits or host_cpu_limits()
+    nthr, width_why = cpu_width(limits, threads)
 
     trace_c = [None]
 
     def site_update(ks, nt, trace=0):
         sl = slice(ks[0], ks[-1] + 1)
         l = lim[ks[0]:ks[-1] + 2]
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         res = no.nuts_sites(M.model_name, X[l[0]:l[-1]], y[l[0]:l[-1]], l - l[0], mus[sl], Oms[sl],
                             seeds[sl], chains=chains, iter=siter, init=last[sl], nthreads=nt, trace_sites=trace)
+        busy = (time.process_time() - c0) / max(time.perf_counter() - t0, 1e-9)      # CPUs the kernel delivered to the sampler
         draws, stats = res[0], res[2]
         if trace:
             trace_c[0] = res[3]
         mom = [eo.tilted_moments(np.asfortranarray(draws[j].reshape(-1, P)[:, :d]), Q, r, estim) for j in range(len(ks))]
-        return time.perf_counter() - t0, float(stats[:, :, 3].sum()), draws, stats, mom
+        return time.perf_counter() - t0, float(stats[:, :, 3].sum()), draws, stats, mom, busy
 
-    # the timed leg: the fast build, every host thread a (site, chain) pair when there are enough of them
+    # the timed legs: the fast build.  Reference schedule first (a site's chains on 4 threads: the per-thread cost every
+    # other leg is held against), then all sites' (site, chain) pairs over the full width
     with no.timing_build():
-        t_all, g_all, _, _, _ = site_update(list(range(n_all)), nthr)
-        t_seq = [site_update([k], min(chains, nthr))[0] for k in range(n_seq)]
+        seq = [site_update([k], min(chains, nthr)) for k in range(n_seq)]
+        t_seq = [q[0] for q in seq]
+        us_seq = float(np.sum(t_seq)) * 1e6 * min(chains, nthr) / max(float(np.sum([q[1] for q in seq])), 1.0)
+        t_all, g_all, _, _, _, busy_all = site_update(list(range(n_all)), nthr)
     # the compared leg: the strict build (the checker), first n_par sites
     n_par = min(n_par, n_all)
-    t_par, g_par, draws_c, stats_c, mom_c = site_update(list(range(n_par)), nthr, trace=n_par if snap.get('trace') is not None else 0)
+    t_par, g_par, draws_c, stats_c, mom_c, busy_par = site_update(list(range(n_par)), nthr, trace=n_par if snap.get('trace') is not None else 0)
     work_items = n_all * chains
-    base = {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': int(min(nthr, work_items)), 'kind': 'port',
-            'cpu': cpu_model_name(), 'host_threads': os.cpu_count(), 'work_items': int(work_items),
+    used = int(min(nthr, work_items))
+    us_all = t_all * 1e6 * used / max(g_all, 1.0)
+    # the count is held against the timings: `cores` never exceeds what they support.  A leg whose threads cost more than
+    # twice the 4-thread leg's per gradient did not have `used` processors; it is then stated as what was delivered.
+    slowdown = us_all / max(us_seq, 1e-12) if n_seq > 0 else None
+    supported = slowdown is None or slowdown <= 2.0
+    cores = used if supported else int(max(1, round(min(busy_all, used / slowdown))))
+    base = {'value': n_all / t_all, 'unit': 'site-updates/s', 'cores': cores, 'kind': 'port',
+            'cpu': cpu_model_name(), 'host_threads': limits['host_threads'], 'affinity': limits['affinity'],
+            'cgroup_quota_cpus': limits['cgroup_quota_cpus'], 'cgroup_source': limits['cgroup_source'],
+            'loadavg_1min_before': limits['loadavg_1min'],
+            'threads_used': used, 'width_from': width_why, 'work_items': int(work_items),
+            'cpus_delivered': busy_all,
+            'us_per_gradient_and_thread': us_all, 'us_per_gradient_and_thread_of_the_4_thread_leg': us_seq if n_seq > 0 else None,
+            'per_thread_slowdown_vs_the_4_thread_leg': slowdown,
+            'cores_note': ('`cores` = the threads the leg ran on = what the process can run at once (%s); the kernel delivered %.1f '
+                           'CPUs over the leg (process CPU time / wall time) and a thread cost %.2f x the 4-thread leg\'s per '
+                           'gradient' % (width_why, busy_all, slowdown if slowdown is not None else float('nan')))
+                          if supported else
+                          ('the leg ran %d threads (%s) but they cost %.1f x the 4-thread leg\'s per gradient: `cores` is what the '
+                           'timings support (%.1f CPUs delivered), not the thread count' % (used, width_why, slowdown, busy_all)),
             'build': 'fast: gcc -O3 -march=native -ffp-contract=fast, vectorised logistic terms (oracle/Makefile FAST_LIB); '
                      'timing only, never the checker',
             'sample': 'one site update (C-oracle NUTS + NumPy moment stage) of the first %d sites of this workload: the EP '
                       'iteration the device ran behind its timed ones, from the same cavities, last draws and Stan seeds; '
-                      '%d (site, chain) pairs over %d threads: %.1f s wall, %.3g gradients, %.1f us per gradient and thread'
-                      % (n_all, work_items, nthr, t_all, g_all, t_all * 1e6 * min(nthr, work_items) / max(g_all, 1.0)),
+                      '%d (site, chain) pairs handed out dynamically to %d threads: %.1f s wall, %.3g gradients, %.1f us per gradient and thread'
+                      % (n_all, work_items, used, t_all, g_all, us_all),
             'strict_build': {'what': 'the checker (gcc -O2 -ffp-contract=off, libm) on the first %d sites, %d pairs over %d '
-                                     'threads: the run the parity record compares with' % (n_par, n_par * chains, nthr),
-                             'site_updates_per_s': n_par / t_par, 'seconds': t_par, 'gradients': g_par,
+                                     'threads: the run the parity record compares with' % (n_par, n_par * chains, min(nthr, n_par * chains)),
+                             'site_updates_per_s': n_par / t_par, 'seconds': t_par, 'gradients': g_par, 'cpus_delivered': busy_par,
                              'us_per_gradient_and_thread': t_par * 1e6 * min(nthr, n_par * chains) / max(g_par, 1.0)},
             'reference_schedule': {
                 'what': 'sites one after the other, the %d chains of a site on %d threads (method.py:1005-1023); fast build'
                         % (chains, min(chains, nthr)),
-                'sites_timed': n_seq, 'site_updates_per_s': n_seq / float(np.sum(t_seq)),
+                'sites_timed': n_seq, 'site_updates_per_s': (n_seq / float(np.sum(t_seq))) if n_seq > 0 else None,
                 'seconds_per_site': [float(t) for t in t_seq],
-                'max_over_sites_s': float(np.max(t_seq)),
+                'max_over_sites_s': float(np.max(t_seq)) if n_seq > 0 else None,
+                'us_per_gradient_and_thread': us_seq if n_seq > 0 else None,
                 'note': 'the reference reports max over sites as its per-iteration "sampling time" '
                         '(method.py:1043), i.e. the time if every site had its own 4 cores'},
             'extrapolation': 'none: rates are per site update; an EP iteration over J sites costs J / rate'}
@@ -350,7 +446,8 @@ def spawn_ranks(n, argv):
 
 def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom=False):
     """One configuration: workload, Master, `warm` untimed EP iterations, then EXACTLY `steps` timed ones bracketed by
-    barrier + device synchronisation on both sides.  Returns (record, Master) on rank 0, (None, None) elsewhere."""
+    barrier + device synchronisation on both sides.  Returns (record, Master) on rank 0, (None, Master) elsewhere: every rank
+    keeps its Master, because the parity iteration behind the timed region is a collective EP iteration like any other."""
     from epstan_amd import _lib as elib, models
     from epstan_amd.method import Master
     sites, D, n, cor, steps, warm = sizes
@@ -384,7 +481,7 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
     info = res[0]
     tmax = float(comm.allreduce_max(np.array([dt]))[0])
     if rank != 0:
-        return None, None
+        return None, M
     assert info == 0, 'EP failed with info %d' % info
 
     # dominant kernel: the sampler, timed with HIP events on the library's stream
@@ -542,8 +639,8 @@ def main():
     ap.add_argument('--adapt', default='fresh', choices=['fresh', 'carry'],
                     help="'fresh' = the reference's behaviour (default, the headline); 'carry' = opt-in carried adaptation")
     ap.add_argument('--cor-input', type=int, default=None, help='0: uncorrelated covariates (fit.py cor_input=False)')
-    ap.add_argument('--cpu-sites', type=int, default=None, help='sites of the all-cores cpu_baseline leg (fast build); 0 disables it; default: 64 on a host of 256 threads, a quarter of the threads otherwise (the leg stays ~1 min)')
-    ap.add_argument('--parity-sites', type=int, default=None, help='sites the strict build re-does for the parity record (default: half of --cpu-sites, at most 32)')
+    ap.add_argument('--cpu-sites', type=int, default=None, help='sites of the all-cores cpu_baseline leg (fast build); 0 disables it; default: two per thread the process can really run (affinity capped by the cgroup quota), at most 64')
+    ap.add_argument('--parity-sites', type=int, default=None, help='sites the strict build re-does for the parity record (default: --cpu-sites, at most 32)')
     ap.add_argument('--cpu-seq-sites', type=int, default=3, help='sites of the reference-faithful schedule')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--no-secondary', dest='secondary', action='store_false',
@@ -560,12 +657,15 @@ def main():
     warm = args.warmup if args.warmup is not None else warm
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before anything touches the GPU (see spawn_ranks)
-    # the CPU legs are sized by the host (they are a bounded sample, and the default run has to stay within minutes): 4 work
-    # items per site, one per thread -> 64 sites on the pool's 256-thread hosts, fewer on a smaller one
+    # the CPU legs are sized by what the host really gives this process (they are a bounded sample, and the default run has
+    # to stay within minutes): two sites per usable thread's worth of chains, i.e. 8 (site, chain) work items per thread ->
+    # 32 sites on this pool's GPU boxes (256 hardware threads, cgroup quota 16 CPUs), handed out dynamically
+    limits = host_cpu_limits()
+    width = cpu_width(limits, args.cpu_threads)[0]
     if args.cpu_sites is None:
-        args.cpu_sites = int(min(64, max(4, (os.cpu_count() or 1) // 4)))
+        args.cpu_sites = int(min(64, max(4, 2 * width)))
     if args.parity_sites is None:
-        args.parity_sites = int(min(32, max(2, args.cpu_sites // 2))) if args.cpu_sites > 0 else 0
+        args.parity_sites = int(min(32, max(2, args.cpu_sites))) if args.cpu_sites > 0 else 0
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -607,36 +707,83 @@ def main():
     sizes = (sites, D, n, cor, steps, warm)
     out, M = measure(args, args.config, sizes, comm, rank, world, local_rank, on_gpu,
                      custom=(args.sites, args.D, args.n) != (None, None, None))
+    # ---- behind the timed region.  ORDER MATTERS: the parity iteration is an EP iteration, i.e. it
+    # contains the all-reduces of epx_update_trial, so EVERY rank runs it; only behind it do ranks != 0 leave, and from
+    # there on rank 0 calls nothing collective (cpu_leg: engine getters, device-local test hooks, the CPU oracle).
+    # A watchdog guarantees the headline line whatever happens to this part: if the parity iteration or the CPU leg has
+    # not finished by its deadline (a peer died inside a collective: RCCL would spin for ever), rank 0 writes the line
+    # without cpu_baseline / parity and the process exits.
+    emitted = threading.Lock()
+
+    def emit(rec):
+        if emitted.acquire(False):
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(rec) + '\n').encode())
+
+    watchdog = None
+    if args.cpu_sites > 0 and rank == 0:
+        step_s = out['ms_per_step'] * 1e-3
+        deadline = float(os.environ.get('EPX_BENCH_PARITY_DEADLINE_S', max(900.0, 30.0 * step_s)))
+
+        def give_up():
+            rec = dict(out)
+            rec['cpu_baseline'] = {'value': None, 'unit': 'site-updates/s', 'cores': 0, 'kind': 'port',
+                                   'sample': 'failed: the parity iteration / CPU leg did not finish within %.0f s' % deadline}
+            rec['parity'] = None
+            emit(rec)
+            os._exit(0)
+        watchdog = threading.Timer(deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    snap, err_p = None, None
+    if args.cpu_sites > 0:
+        if rank == 0:
+            try:
+                # what the CPU port starts from (cavities, last draws, global approximation): rank-local getters
+                snap = snapshot_for_cpu_leg(M, args.cpu_sites, args.chains, args.siter)
+                if hasattr(M.engine, 'set_trace'):
+                    M.engine.set_trace(min(args.parity_sites, snap['n_all']))     # every transition of the compared sites' chains, warm-up included
+            except Exception as ex:                  # (rank 0 still joins the collective iteration below)
+                import traceback
+                traceback.print_exc()
+                err_p = ex
+        try:
+            # one more EP iteration on the device(s), behind the timed region -- ALL ranks: it holds the all-reduces of the
+            # update phase -- whose first sites the CPU port re-does on rank 0 from the same state and seeds
+            info_p = M.run(1, verbose=False, seed=PARITY_SEED)[0]
+            if info_p != 0:
+                err_p = err_p or RuntimeError('parity EP iteration failed with info %d' % info_p)
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            err_p = err_p or ex
     if rank != 0:
-        # rank 0's cpu_baseline leg needs nothing from the others, and they must not spin in a collective beside it
-        # (an RCCL barrier busy-waits a host thread per rank): they are done -- ncclCommDestroy needs no peer
+        # the last collective of this process is behind it: rank 0's CPU leg needs nothing from the others, and they must
+        # not spin in a barrier beside it (an RCCL barrier busy-waits a host thread per rank) -- ncclCommDestroy needs no peer
         if hasattr(comm, 'close'):
             comm.close()
         return
     if args.cpu_sites > 0:
         try:
-            # one more EP iteration on the device, behind the timed region, whose first sites the CPU port re-does from the
-            # same state and seeds: the CPU's time is the baseline, the two results are the parity record
-            snap = snapshot_for_cpu_leg(M, args.cpu_sites, args.chains, args.siter)
-            n_tr = min(args.parity_sites, snap['n_all'])
-            if hasattr(M.engine, 'set_trace'):
-                M.engine.set_trace(n_tr)             # every transition of the compared sites' chains, warm-up included
-            info_p = M.run(1, verbose=False, seed=PARITY_SEED)[0]
-            assert info_p == 0, 'parity EP iteration failed with info %d' % info_p
+            if err_p is not None:
+                raise err_p
             snap['trace'] = None
             if hasattr(M.engine, 'set_trace'):
                 snap['trace'] = M.engine.get_trace(args.chains, args.siter)
                 M.engine.set_trace(0)
+            # collective-free from here on (the other ranks have gone)
             out['cpu_baseline'], out['parity'] = cpu_leg(M, snap, args.prec_estim, args.chains, args.siter,
                                                          args.cpu_seq_sites, args.cpu_threads,
                                                          M.df_log[-1] if getattr(M, 'df_log', None) else M.df0(M.iter),
-                                                         args.parity_sites)
+                                                         args.parity_sites, limits)
         except Exception as ex:                      # the baseline must not void the GPU measurement
             import traceback
             traceback.print_exc()
             out['cpu_baseline'] = {'value': None, 'unit': 'site-updates/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %r' % (ex,)}
             out['parity'] = None
+    if watchdog is not None:
+        watchdog.cancel()
     # ---- secondary records: the other two single-GPU configurations of BASELINE.json, driver-timed in the same process
     # (configs[1] = C2: 64 sites, D = 16, n = 200, layout 6; one 512-site shard of configs[4] = C5: D = 128, n = 2000, the
     # streaming sampler against the HBM roofline).  Headline keys stay the default workload's.  One GPU only: a rank of a
@@ -680,8 +827,7 @@ def main():
                 out['secondary'].append({'config': {'name': name}, 'value': None, 'error': repr(ex)})
     if hasattr(comm, 'close'):
         comm.close()
-    sys.stdout.flush()
-    os.write(json_fd, (json.dumps(out) + '\n').encode())
+    emit(out)
 
 
 if __name__ == '__main__':

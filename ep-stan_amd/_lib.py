@@ -147,6 +147,8 @@ def runtime_info(lib=None, device=0):
     n = ctypes.c_int(0)
     if lib.epx_device_count(ctypes.byref(n)) != 0 or n.value < 1:
         return None, None
+    if not 0 <= int(device) < n.value:
+        device = 0
     v = ctypes.c_int(0)
     buf = ctypes.create_string_buffer(64)
     if lib.epx_runtime_info(int(device), ctypes.byref(v), buf, 64) != 0:
@@ -155,11 +157,17 @@ def runtime_info(lib=None, device=0):
 
 
 def load():
-    """Load libepx.so; raises (never falls back to a CPU path) when it is missing."""
+    """Load libepx.so; raises (never falls back to a CPU path) when it is missing.
+    NOTE: the platform check below initialises the HIP runtime in the calling process when a device is present (it asks
+    the rank's own device -- LOCAL_RANK -- for its architecture and runtime version)."""
     global _lib
     if _lib is None:
+        import sys
         path = LIB_PATH
-        if 'EPX_LIB' not in os.environ and os.environ.get('EPX_PIECE_FENCE', '') == '1' and os.path.exists(FENCE_LIB_PATH):
+        if 'EPX_LIB' not in os.environ and os.environ.get('EPX_PIECE_FENCE', '') == '1':
+            if not os.path.exists(FENCE_LIB_PATH):
+                raise EpxError('EPX_PIECE_FENCE=1 asks for {} which does not exist: build it with '
+                               'ep-stan_amd/csrc/build.sh'.format(FENCE_LIB_PATH))
             path = FENCE_LIB_PATH
         if not os.path.exists(path):
             raise EpxError(
@@ -167,13 +175,24 @@ def load():
                 '`python -c "import __graft_entry__ as g; g.build()"` '
                 '(there is no CPU fallback)'.format(path))
         lib = _bind(path)
-        if 'EPX_LIB' not in os.environ and path != FENCE_LIB_PATH and os.path.exists(FENCE_LIB_PATH):
-            ver, arch = runtime_info(lib)
+        if 'EPX_LIB' not in os.environ and path != FENCE_LIB_PATH:
+            try:
+                dev = int(os.environ.get('LOCAL_RANK', '0'))
+            except ValueError:
+                dev = 0
+            ver, arch = runtime_info(lib, dev)
             if arch is not None and not (arch.startswith(VALIDATED_ARCH) and ver == VALIDATED_HIP):
-                import sys
-                print('epstan_amd: %s / HIP %s is not the platform the fence-free piece hand-off was validated on (%s / HIP %d.%d): '
-                      'loading %s' % (arch, ver, VALIDATED_ARCH, VALIDATED_HIP[0], VALIDATED_HIP[1], FENCE_LIB_PATH), file=sys.stderr)
-                lib = _bind(FENCE_LIB_PATH)
+                # (both libraries hold gfx950 code only -- build.sh -- so what this branch really covers is another HIP
+                # runtime on gfx950; on another architecture neither loads a kernel)
+                if os.path.exists(FENCE_LIB_PATH):
+                    print('epstan_amd: %s / HIP %s is not the platform the fence-free piece hand-off was validated on (%s / HIP %d.%d): '
+                          'loading %s' % (arch, ver, VALIDATED_ARCH, VALIDATED_HIP[0], VALIDATED_HIP[1], FENCE_LIB_PATH), file=sys.stderr)
+                    lib = _bind(FENCE_LIB_PATH)
+                else:
+                    print('epstan_amd: WARNING: %s / HIP %s is not the platform the fence-free piece hand-off was validated on '
+                          '(%s / HIP %d.%d) and %s is missing: keeping the fence-free build; pieced launches (epx_set_piece_queue) '
+                          'are not validated here' % (arch, ver, VALIDATED_ARCH, VALIDATED_HIP[0], VALIDATED_HIP[1], FENCE_LIB_PATH),
+                          file=sys.stderr)
         _lib = lib
     return _lib
 

@@ -497,6 +497,7 @@ static int build_nuts_args(epx_ctx *c, int k0, int count, const epx_sampler_opts
     if (stack_sites < count) stack_sites = count;       // the HBM tree stack is indexed by site: a split launch sizes it for all
     const int nkeep = (o.iter - o.warmup + o.thin - 1) / o.thin;
     memset(&a, 0, sizeof a);
+    a.dyn_tail_div = 1;                                 // (a divisor: never 0, also for launches that do not come from the piece queue)
     a.model = c->model; a.D = c->D; a.d = c->d; a.P = c->P; a.k0 = k0;
     a.gauss = c->gauss; a.yd = c->yd;
     a.chains = o.chains; a.iter = o.iter; a.warmup = o.warmup; a.thin = o.thin; a.nkeep = nkeep;
@@ -696,8 +697,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
     // (layout 3; same-box A/B at the C5 shard: +0.7 %, profiles/r05_piece_tail_ab.txt), one length throughout for the resident
     // layouts -- there a piece start re-stages the site's 128 KB of rows, the A/B showed no gain (546.6 / 545.9 / 545.6 /
     // 545.8 site-updates/s) and the extra pieces cost 7 GB of HBM traffic per C3 launch.  EPX_PIECE_TAIL_DIV overrides (A/B).
-    const int tail_div = getenv("EPX_PIECE_TAIL_DIV") ? (atoi(getenv("EPX_PIECE_TAIL_DIV")) > 1 ? atoi(getenv("EPX_PIECE_TAIL_DIV")) : 1)
-                                                      : (layout == 3 ? 4 : 1);
+    int tail_div = layout == 3 ? 4 : 1;
+    if (const char *tde = getenv("EPX_PIECE_TAIL_DIV")) { const int v = atoi(tde); tail_div = v > 1 ? v : 1; }
     size_t total_pieces = 0;
     int nb_site = 0;
     if (use_queue) {
@@ -751,14 +752,16 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         // could not be had, unpieced -- must see the buffer that exists now.  The larger buffer also serves the unpieced form.)
         a.stack = c->stack;
     }
+    // (the hook has no unpieced form: if the records could not be had, the call fails instead of running a whole update
+    // and copying out of a checkpoint buffer that is missing or too small)
+    if (hook && !use_queue) return fail("epx_sample_piece: the checkpoint records / tree stacks of the pieced launch could not be allocated");
     if (use_queue) {
         if (!c->dyn_words) HIPCHK(dalloc(&c->dyn_words, 2 * (size_t)c->K));
-        HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemsetAsync(c->dyn_words, 0, 2 * (size_t)count * sizeof(int), c->stream));      // (stream-ordered in front of the launch)
         a.dyn_prog = c->dyn_words; a.dyn_busy = c->dyn_words + count;
         a.dyn_rate = (c->dyn_has_rate && !hook) ? c->dyn_rate : nullptr;
         a.dyn_len = hook ? 1 : c->dyn_len; a.dyn_count = count;
-        if (!c->dyn_words) return fail("piece queue words missing");
+        a.dyn_hook = hook ? 1 : 0;
         if (!c->dyn_lens_d) HIPCHK(dalloc(&c->dyn_lens_d, (size_t)c->K));
         HIPCHK(hipMemcpyAsync(c->dyn_lens_d, lens_h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));            // (lens_h is a local)
@@ -770,6 +773,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
             // one-piece-per-workgroup form claim one site each, run ONE transition, leave the record of boundary t0 + 1
             a.seg_nwg = count; a.persist = 0;
             std::vector<int> prog((size_t)count, 2 * c->hook_t0);
+            HIPCHK(hipStreamSynchronize(c->stream));        // (the memset above is stream-ordered, this copy is not)
             HIPCHK(hipMemcpy(c->dyn_words, prog.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice));
             const size_t rec = (size_t)(4 * nv + 1) * 64;
             for (int k = 0; k < count; ++k)
@@ -805,6 +809,7 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
                 a2.eps_in = nullptr; a2.inv_e_in = nullptr; a2.t_offset = t_offset;
                 a2.carry_eps = a.carry_eps; a2.carry_metric = a.carry_metric;
                 a2.order = a.order;
+                a2.trace = a.trace; a2.trace_sites = a.trace_sites;      // (records are keyed by the REAL site, through `order`, in both launches)
                 a.order = a.order + n_lead;
             }
         }

@@ -194,6 +194,7 @@ struct NutsArgs {
     const int *dyn_lens;          // per site: transitions of one of ITS pieces (pieces of equal predicted work), or NULL: dyn_len for all
     int dyn_nb;                   // checkpoint records (piece boundaries) reserved per site
     int dyn_tail_div;             // the pieces behind 3/4 of a site's run are 1/dyn_tail_div of the nominal length (epx_pieces.h)
+    int dyn_hook;                 // epx_sample_piece: a site is released as FINISHED behind its one transition (never claimable twice)
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int

@@ -194,7 +194,10 @@ __device__ __forceinline__ void piece_release(Args &a, unsigned char *smem) {
     volatile int *pz = reinterpret_cast<volatile int *>(smem + a.off_piece);
     const int r_site = pz[0], r_t0 = pz[1];
     const int r_len = piece_len_at(a, r_site, r_t0);
-    const int t1 = r_t0 + r_len < a.iter ? r_t0 + r_len : a.iter;
+    // (epx_sample_piece, dyn_hook: ONE transition per site -- the site goes back as finished, so a workgroup that starts
+    // late, with more sites than the device holds workgroups, cannot take it for a second transition and leave another
+    // site untouched; the record still lands at boundary t0 + 1, piece_record is keyed by the transition, not by this word)
+    const int t1 = a.dyn_hook ? a.iter : (r_t0 + r_len < a.iter ? r_t0 + r_len : a.iter);
     // progress up, claim off: one store (agent scope: written through to where the other XCDs' claims read it; the
     // checkpoint stores of every wave are complete -- piece_checkpoint_out, then the workgroup barrier in front of this)
 #ifdef EPX_PIECE_FENCE

@@ -64,6 +64,7 @@ class HipEngine(object):
         self.D = X.shape[1]
         self.d, self.P = model_dims(model if model.endswith('_sg') else model + '_sg', self.D)
         self.device = device
+        self._trace_sites = 0                  # (set_trace: sites whose transitions are recorded; 0 = off)
         ctx = ctypes.c_void_p()
         if gauss and g_cnt is None:
             if not model.endswith('_sg'):
@@ -225,8 +226,7 @@ class HipEngine(object):
         rec = np.zeros(scalars.shape[:-1] + ((4 * nv + 1) * 64,))
         for j, v in enumerate((qs, wmean, wm2, inv_e)):
             rec[..., j * nv * 64:j * nv * 64 + self.P] = v
-        if True:
-            rec[..., 3 * nv * 64 + self.P:4 * nv * 64] = 1.0        # (the metric's padding elements are 1, as the kernels keep them)
+        rec[..., 3 * nv * 64 + self.P:4 * nv * 64] = 1.0            # (the metric's padding elements are 1, as the kernels keep them)
         rec[..., 4 * nv * 64:4 * nv * 64 + 20] = scalars
         return rec
 

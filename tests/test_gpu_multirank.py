@@ -340,3 +340,34 @@ def test_two_c5_shards_two_ranks_on_one_device(tmp_path):
     res = _spawn('c5x2', tmp_path, 'host', world=2)
     _own_size_checks(res, 2, 1024, 3)
 
+
+
+def test_bench_main_two_ranks_on_one_device_with_the_parity_and_cpu_legs():
+    """`bench.py --gpus 2` end to end on the device, at its default form (parity iteration + CPU leg ON): two ranks share
+    GPU 0, the library's own multi-rank update with its collectives over gloo (tests/bench_gpu_hostcomm.py).  The parity
+    iteration behind the timed region is a collective EP iteration: both ranks must still be there for it (VERDICT round 5:
+    rank 0 ran it alone), and rank 0's CPU leg behind it must need nobody.  One line, every record filled in."""
+    import json
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'bench_gpu_hostcomm.py'),
+           '--gpus', '2', '--sites', '6', '--D', '8', '--rows', '80', '--siter', '60', '--steps', '2', '--warmup', '1',
+           '--cpu-sites', '4', '--parity-sites', '4', '--cpu-seq-sites', '1', '--no-secondary']
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['rccl_world_size'] == 2 and out['steps'] == 2
+    np.testing.assert_allclose(out['value'], 12 * 2 / (out['ms_per_step'] * 1e-3 * 2), rtol=1e-9)
+    assert out['roofline']['frac'] > 0 and out['roofline']['gradients_per_launch'] > 0
+    assert out['cpu_baseline']['value'] is not None and out['cpu_baseline']['value'] > 0, out['cpu_baseline']
+    assert 1 <= out['cpu_baseline']['cores'] <= out['cpu_baseline']['threads_used']
+    par = out['parity']
+    assert par is not None and par['sites'] == 4, res.stderr[-3000:]
+    assert par['site_delta_vs_numpy_moment_stage_max_rel_err'] < 1e-7
+    assert par['first_draws'] is None or par['first_draws']['max_rel_err'] < 1e-6
+    by_t = par['transition_by_transition']
+    assert by_t is None or by_t['chains_equal_through_the_first_transition'] >= 0.9 * by_t['chains']

@@ -174,23 +174,77 @@ def _run_torchrun(n, script, args, timeout=600):
     return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
 
 
-def test_bench_runs_end_to_end_at_world_size_8_on_cpu():
-    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one process per rank), with the oracle
-    engine and a gloo transport in place of the device: rendezvous, warm-up, timed region between barriers, max over
-    ranks, ONE JSON line from rank 0 with the whole-job value, clean exit of every rank."""
+def _bench_line(res):
     import json
-    res = _run_torchrun(8, os.path.join(ROOT, 'tests', 'bench_cpu_smoke.py'),
-                        ['--gpus', '8', '--sites', '2', '--D', '3', '--rows', '30', '--siter', '20', '--steps', '2',
-                         '--warmup', '1', '--cpu-sites', '0'])
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, res.stdout
-    out = json.loads(lines[0])
-    assert out['n_gpus'] == 8 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak'
-    assert out['config']['rccl_world_size'] == 8
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_runs_end_to_end_on_cpu_with_the_parity_and_cpu_legs(world):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), with the oracle
+    engine and a gloo transport in place of the device, at its DEFAULT form: the parity EP iteration and the CPU leg
+    behind the timed region are ON.  The parity iteration is collective (the all-reduces of the update phase), so every
+    rank has to stay for it; only behind it may ranks != 0 leave.  (Round 5 shipped the opposite order: rank 0 ran the
+    collective alone, 'Connection closed by peer' over gloo, a hang over RCCL -- and this test passed --cpu-sites 0.)
+    ONE JSON line from rank 0 with the whole-job value, cpu_baseline and parity filled in, clean exit of every rank."""
+    res = _run_torchrun(world, os.path.join(ROOT, 'tests', 'bench_cpu_smoke.py'),
+                        ['--gpus', str(world), '--sites', '2', '--D', '3', '--rows', '30', '--siter', '20', '--steps', '2',
+                         '--warmup', '1', '--cpu-sites', '2'])
+    out = _bench_line(res)
+    assert 'Connection closed' not in res.stderr and 'Traceback' not in res.stderr, res.stderr[-3000:]
+    assert out['n_gpus'] == world and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['config']['rccl_world_size'] == world
     assert out['metric'] == 'site-updates/sec' and out['unit'] == 'site-updates/s'
-    np.testing.assert_allclose(out['value'], 16 * 2 / (out['ms_per_step'] * 1e-3 * 2), rtol=1e-9)     # 16 sites, whole job
+    np.testing.assert_allclose(out['value'], 2 * world * 2 / (out['ms_per_step'] * 1e-3 * 2), rtol=1e-9)     # whole job
     assert 'roofline' in out and out['roofline']['frac'] > 0
+    cb = out['cpu_baseline']
+    assert cb['value'] is not None and cb['value'] > 0 and cb['kind'] == 'port'
+    # the stated core count is what the process can run at once, and the timings have to support it
+    assert 1 <= cb['cores'] <= cb['threads_used'] <= (cb['affinity'] or cb['host_threads'])
+    assert cb['cgroup_quota_cpus'] is None or cb['threads_used'] <= max(1, int(cb['cgroup_quota_cpus']))
+    assert cb['cpus_delivered'] > 0 and cb['us_per_gradient_and_thread'] > 0
+    assert out['parity'] is not None and out['parity']['sites'] == 2
+    assert out['parity']['site_delta_vs_numpy_moment_stage_max_rel_err'] < 1e-7
+
+
+def test_bench_without_the_cpu_leg_at_world_size_8_on_cpu():
+    """--cpu-sites 0: no parity iteration, no CPU leg; the ranks leave right behind the timed region."""
+    res = _run_torchrun(8, os.path.join(ROOT, 'tests', 'bench_cpu_smoke.py'),
+                        ['--gpus', '8', '--sites', '2', '--D', '3', '--rows', '30', '--siter', '20', '--steps', '2',
+                         '--warmup', '1', '--cpu-sites', '0'])
+    out = _bench_line(res)
+    assert out['n_gpus'] == 8 and 'cpu_baseline' not in out
+    np.testing.assert_allclose(out['value'], 16 * 2 / (out['ms_per_step'] * 1e-3 * 2), rtol=1e-9)
+
+
+def test_no_rank_leaves_bench_before_the_last_collective():
+    """Source-level guard of the same property: in bench.main() every `comm.close()` lies BEHIND the parity iteration
+    (`M.run(1, ... seed=PARITY_SEED)`), the last collective of the run."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    main = src[src.index('def main():'):]
+    last_collective = main.index('seed=PARITY_SEED')
+    closes = [i for i in range(len(main)) if main.startswith('comm.close()', i)]
+    assert closes and all(i > last_collective for i in closes)
+    assert 'M.run(' not in main[last_collective + 20:]             # nothing collective behind it on rank 0
+
+
+def test_cpu_width_is_the_affinity_capped_by_the_cgroup_quota(tmp_path, monkeypatch):
+    """bench.cpu_width / host_cpu_limits: 256 hardware threads with a cgroup quota of 16 CPUs (this pool's GPU boxes,
+    profiles/r06_cpu_probe.txt) are 16 usable threads; no quota -> the affinity mask; --cpu-threads wins."""
+    sys.path.insert(0, ROOT)
+    import bench
+    lim = {'host_threads': 256, 'affinity': 256, 'cgroup_quota_cpus': 16.0, 'cgroup_source': '/sys/fs/cgroup/cpu.max', 'loadavg_1min': 0.0}
+    assert bench.cpu_width(lim)[0] == 16 and 'quota' in bench.cpu_width(lim)[1]
+    assert bench.cpu_width(dict(lim, cgroup_quota_cpus=None))[0] == 256
+    assert bench.cpu_width(dict(lim, affinity=8))[0] == 8
+    assert bench.cpu_width(dict(lim, cgroup_quota_cpus=0.5))[0] == 1
+    assert bench.cpu_width(lim, requested=4)[0] == 4
+    here = bench.host_cpu_limits()
+    assert here['host_threads'] == os.cpu_count() and 1 <= here['affinity'] <= here['host_threads']
+    assert here['cgroup_quota_cpus'] is None or here['cgroup_quota_cpus'] > 0
 
 
 def test_rccl_id_travels_through_torchruns_store():
