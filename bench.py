@@ -45,7 +45,7 @@ CONFIGS = {
     # name: (sites per GPU, D, n_j, correlated covariates, default steps, default warm-up)
     'c2': (64, 16, 200, 1, 20, 5),
     'c3': (512, 32, 500, 1, 20, 5),      # the driver's command: --steps 20 --warmup 5
-    'c5shard': (512, 128, 2000, 0, 2, 2),
+    'c5shard': (512, 128, 2000, 0, 2, 2),      # (the secondary record of the default run uses these too: README's number = the driver's)
 }
 
 
@@ -161,6 +161,38 @@ def _ess(x):
         tau += 2.0 * pair
         t += 2
     return float(c * n / max(tau, 1.0 / np.log10(max(c * n, 10))))
+
+
+def _chi2_sf(x, k):
+    """P(chi-square with k degrees of freedom > x)."""
+    try:
+        from scipy import stats
+        return float(stats.chi2.sf(x, k))
+    except Exception:                       # Wilson-Hilferty
+        from math import erfc, sqrt
+        z = ((x / k) ** (1.0 / 3.0) - (1.0 - 2.0 / (9.0 * k))) / sqrt(2.0 / (9.0 * k))
+        return 0.5 * erfc(z / sqrt(2.0))
+
+
+def pooled_z(z, what):
+    """The distribution of signed z-scores z (sites, coordinates) of two independent estimates of the same quantities:
+    under agreement they scatter like N(0, 1) -- mean 0, variance ~ 1 -- instead of merely staying within 4.  The
+    coordinates of a site are correlated (one posterior), the sites are independent: the test of the MEAN is made on the
+    per-site means (a t-statistic over the sites), which a bias shared by all coordinates cannot hide in (0.3 standard
+    errors on every coordinate give t ~ 4 with 32 sites; `share_within_4` never sees it).  The chi-square of the pooled
+    sum of squares is given with its nominal degrees of freedom (indicative: it ignores the within-site correlation and the
+    noise of the effective-sample-size estimates in the denominators, both of which fatten the tails)."""
+    z = np.asarray(z, dtype=float)
+    K, n = z.shape
+    site_mean = z.mean(axis=1)
+    t = float(site_mean.mean() / (site_mean.std(ddof=1) / np.sqrt(K))) if K > 1 and site_mean.std(ddof=1) > 0 else 0.0
+    ss = float((z * z).sum())
+    return {'what': what, 'n': int(z.size), 'sites': int(K),
+            'mean': float(z.mean()), 'variance': float(z.var(ddof=1)) if z.size > 1 else 0.0,
+            'mean_of_site_means_t_statistic': t,
+            'chi2': ss, 'chi2_dof': int(z.size), 'chi2_p_value_nominal': _chi2_sf(ss, z.size),
+            'share_beyond_2': float(np.mean(np.abs(z) > 2.0)), 'share_beyond_3': float(np.mean(np.abs(z) > 3.0)),
+            'expected_under_N01': {'mean': 0.0, 'variance': 1.0, 'share_beyond_2': 0.0455, 'share_beyond_3': 0.0027}}
 
 
 def snapshot_for_cpu_leg(M, n_all, chains, siter):
@@ -290,6 +322,7 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
     cs = eng.get_chain_stats(chains)[:n_all]
     first_err, n_first, n_end, n_stats = 0.0, 0, 0, 0
     z_mean, rel_cov, tol_cov, dq_rel = [], [], [], []
+    zs_mean, zs_var = np.zeros((n_all, d)), np.zeros((n_all, d))      # signed z-scores, pooled below
     for k in range(n_all):
         dev = eng.get_draws(k, all_params=True).reshape(chains, nkeep, P)
         ref = draws_c[k]
@@ -314,6 +347,8 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
             z_mean.append(abs(mg[i] - mc[i]) / np.sqrt(vp * (1.0 / eg + 1.0 / ec)))
             rel_cov.append(abs(vg[i] - vc[i]) / vp)
             tol_cov.append(4.0 * np.sqrt(2.0 / eg + 2.0 / ec))
+            zs_mean[k, i] = (mg[i] - mc[i]) / np.sqrt(vp * (1.0 / eg + 1.0 / ec))
+            zs_var[k, i] = np.log(vg[i] / vc[i]) / np.sqrt(2.0 / eg + 2.0 / ec)
         # the site delta the device formed from ITS draws against the NumPy moment stage on the same draws (deterministic)
         dQ_dev, dr_dev = eng.get_site(DQI, k)
         dQ_o = eo.tilted_moments(np.asfortranarray(dev.reshape(-1, P)[:, :d]), Q, r, estim)[0]
@@ -393,6 +428,11 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
                         'the rounding differences of the two summation orders grow by the factor above per transition until they '
                         'reach 1e-6 or flip a decision: chaos, not a difference of the algorithm -- the first transition, step-size '
                         'search included, agrees to rounding'}
+    pz_m = pooled_z(zs_mean, 'signed (device mean - CPU mean) / sqrt(pooled variance (1/ESS_dev + 1/ESS_cpu)), every coordinate of every compared site')
+    pz_v = pooled_z(zs_var, 'log(device variance / CPU variance) / sqrt(2/ESS_dev + 2/ESS_cpu), every coordinate of every compared site')
+    # agreement of the two samplers in distribution: no shared bias (|t| of the per-site means), and a scatter that is
+    # neither much wider than the Monte-Carlo error (a real difference) nor much narrower (a leg that is not independent)
+    pooled_ok = all(abs(q['mean_of_site_means_t_statistic']) <= 4.5 and q['variance'] <= 2.5 for q in (pz_m, pz_v)) if n_all >= 8 else True
     parity = {
         'what': 'the EP iteration behind the timed ones, sites 0..%d: device (the timed kernel, piece queue and all) against the '
                 'CPU port from the same cavities, starting draws and Stan seeds' % (n_all - 1),
@@ -410,15 +450,19 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
                                     'share_within_4': float(np.mean(z_mean <= 4.0))},
         'tilted_cov_rel_err': {'max': float(rel_cov.max()), 'median': float(np.median(rel_cov)),
                                'share_within_tolerance': float(np.mean(rel_cov <= tol_cov))},
+        # the whole distribution of the z-scores, not only their tails
+        'tilted_mean_z_pooled': pz_m, 'tilted_log_variance_ratio_z_pooled': pz_v,
         'site_delta_vs_numpy_moment_stage_max_rel_err': float(np.max(dq_rel)),
         'global_moments_with_cpu_deltas_for_these_sites': glob,
         'transition_by_transition': by_t,
         'tolerance': 'first draws (one transition from the same state): 1e-6 relative; tilted mean within 4 MCSE per coordinate, '
                      'tilted variances within 4 sqrt(2/ESS_dev + 2/ESS_cpu) relative (SURVEY.md section 8c; ESS by Geyer\'s '
-                     'initial positive sequence over the %d chains); site delta from the device\'s own draws against the NumPy '
+                     'initial positive sequence over the %d chains); pooled over all coordinates of all compared sites the signed '
+                     'z-scores of means and log variance ratios must have |t| <= 4.5 for the mean of the per-site means and a '
+                     'variance <= 2.5 (N(0, 1) expected; from 8 sites on); site delta from the device\'s own draws against the NumPy '
                      'moment stage: 1e-7; transition by transition: >= 90 %% of the chains equal through the first transition (step-size '
                      'search included), its draws and adapted step sizes within 1e-6' % chains,
-        'ok': bool((tf is None or tf['max_rel_err'] < 1e-6) and np.mean(z_mean <= 4.0) >= 0.99
+        'ok': bool((tf is None or tf['max_rel_err'] < 1e-6) and np.mean(z_mean <= 4.0) >= 0.99 and pooled_ok
                    and np.mean(rel_cov <= tol_cov) >= 0.99 and np.max(dq_rel) < 1e-7
                    # the same problem, and no drift: nearly every chain gets through its first transition (step-size search
                    # included) with the oracle's, and what lies in front of a parting agrees to rounding
@@ -472,10 +516,19 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
     if warm > 0:
         info = M.run(warm, verbose=False, seed=1 + shift)[0]
         assert info == 0, 'warm-up EP iterations failed with info %d' % info
+    # BASELINE configs[4] is "damped EP (find_damp path)": every EP iteration scores the reference's 31 damping factors
+    # (find_damp.py:105-173) before its own damped update -- epx_damp_sweep, inside the timed region.  find_damp scores
+    # against a full-posterior fit, which needs Stan; here the target is the prior's moments shrunk (any positive
+    # definite target runs the same 31 x (global Cholesky + cavities of all sites + criteria)).
+    sweep = None
+    if cfg_name == 'c5shard':
+        from epstan_amd import find_damp
+        sweep = dict(damps=find_damp.default_damps(), m_target=np.zeros(M.dphi), S_target=np.linalg.inv(Q0) * 0.25,
+                     samp_target=None)
     n_launch0 = len(M.sampling_ms)
     sync()
     t0 = time.perf_counter()
-    res = M.run(steps, verbose=False, return_analytics=True, seed=2 + shift)
+    res = M.run(steps, verbose=False, return_analytics=True, seed=2 + shift, **({'sweep': sweep} if sweep else {}))
     sync()
     dt = time.perf_counter() - t0
     info = res[0]
@@ -503,16 +556,23 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         + sites * args.chains * ((args.siter - args.siter // 2) * P * 8 + P * 8)
     key = [sites, D, n, args.model, args.chains, args.siter]
 
-    def measured_traffic(names):
-        """HBM bytes per launch from a committed rocprofv3 --pmc run of THIS command (FETCH_SIZE x 2 +
-        WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be collected inside the timed run."""
+    def measured_traffic(names, alg_bytes_this_run):
+        """HBM bytes of THIS run's launches as the counters see such launches: the ratio counter bytes / algorithmic bytes
+        of a committed rocprofv3 --pmc run of this command (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md: counters
+        cannot be collected inside the timed run) times the algorithmic bytes of this run's launches -- never the
+        absolute bytes of another run's launches, whose trajectories made a different number of passes.
+        Returns (bytes per launch, ratio, source)."""
         for name in names:
             path = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(path):
                 pj = json.load(open(path))
                 if pj.get('workload_key', pj.get('workload')) == key:
-                    return pj['hbm_bytes_per_launch_corrected'], 'profiles/' + name
-        return None, None
+                    ratio = pj.get('traffic_over_algorithmic')
+                    if ratio is None and pj.get('algorithmic_bytes_per_launch'):
+                        ratio = pj['hbm_bytes_per_launch_corrected'] / pj['algorithmic_bytes_per_launch']
+                    if ratio is not None:
+                        return float(ratio) * alg_bytes_this_run, float(ratio), 'profiles/' + name
+        return None, None, None
 
     if layout == 3:
         # streaming sampler: the site rows (and the cavity precision) come from HBM once per
@@ -521,9 +581,11 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         B_pass = n_rows * D * 8 + n_rows * 4 + M.dphi**2 * 8     # X, y (int32), Omega
         hbm_alg = float(passes.mean()) * B_pass
         gbs = hbm_alg / t_kernel / 1e9
-        tr, src = measured_traffic(('r05_stream_pmc_hbm.json', 'r04_stream_pmc_hbm.json', 'r02_stream_pmc_hbm.json', 'r01_stream_pmc_hbm.json'))
+        tr, tr_ratio, src = measured_traffic(tuple('r%02d_stream_pmc_hbm.json' % r for r in (6, 5, 4, 2, 1)), hbm_alg)
         roof = {'kernel': 'k_nuts_stream (sampler)', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'traffic_source': src,
+                'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'traffic_over_algorithmic': tr_ratio,
+                'traffic_source': src, 'algorithmic_bytes_per_launch': hbm_alg,
+                'traffic_note': 'counter bytes per algorithmic byte of the committed --pmc run of this command x the algorithmic bytes of THIS run\'s launches',
                 'note': 'algorithmic bytes = row passes x (n D 8 + n 4 + d^2 8) over the HIP-event duration '
                         'of the sampler launch; includes the tail where few sites are still sampling',
                 'launch_ms': float(ms.mean()), 'row_passes_per_launch': float(passes.mean()),
@@ -534,7 +596,7 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
                 'bytes_per_row_pass': B_pass,
                 'ns_per_row_pass_per_cu': t_kernel * 1e9 * n_cu / float(passes.mean())}
     else:
-        tr, src = measured_traffic(tuple('r%02d_%s_pmc_hbm.json' % (r, cfg_name) for r in (5, 4, 3, 2)))
+        tr, tr_ratio, src = measured_traffic(tuple('r%02d_%s_pmc_hbm.json' % (r, cfg_name) for r in (6, 5, 4, 3, 2)), hbm_alg)
         team = layout == 7
         # bytes the kernel reads from LDS for the rows: one sweep of the site per gradient in the one-wave-per-chain forms;
         # layout 7 reads the rows TWICE per pass (forward and transposed product) for the FOUR gradients of a site's chains
@@ -545,7 +607,9 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         lds_tbs = lds_bytes / t_kernel / 1e12
         roof = {'kernel': 'NUTS sampler (site rows resident in LDS)', 'bound': 'mfma' if team else 'fp64-valu',
                 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_source': src,
+                'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': tr, 'traffic_over_algorithmic': tr_ratio, 'traffic_source': src,
+                'traffic_note': 'counter bytes per algorithmic byte (hbm_algorithmic_bytes) of the committed --pmc run of this command x this run\'s algorithmic bytes',
+
                 'note': ('FP64 flops of the gradient sweeps (G x (4 n D + 12 n)) over the HIP-event duration of the '
                          'sampler launch.  Layout 7: the two products of a gradient run on v_mfma_f64_4x4x4 for the four '
                          'chains of a site in lock step (dense FP64 matrix peak = FP64 vector peak = 78.6 TFLOP/s); X is '
@@ -580,10 +644,11 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'ep_iters_per_sec': steps / tmax,
         'config': {'workload': 'hierarchical logistic regression %s, J=%d sites (=%d/GPU), D=%d, n_j=%d, '
-                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s%s'
+                               'chains=%d, iter=%d (S=%d draws/site), prec_estim=%s, df0=default_df0(K)%s%s%s'
                                % (args.model, J, sites, D, n, args.chains, args.siter,
                                   args.chains * (args.siter - args.siter // 2), args.prec_estim,
                                   '' if cor else ', uncorrelated covariates',
+                                  ', the 31-factor damping sweep of find_damp.py in every timed iteration' if sweep else '',
                                   '' if args.adapt == 'fresh' else ', adapt=carry (NOT the reference\'s per-update re-adaptation)'),
                    'adapt': args.adapt, **({'seed_shift_DIAGNOSTIC': shift} if shift else {}),
                    'name': 'custom' if custom else cfg_name,
@@ -592,6 +657,8 @@ def measure(args, cfg_name, sizes, comm, rank, world, local_rank, on_gpu, custom
         'roofline': roof,
         'sampler_share_of_step': float(ms.sum() * 1e-3 / dt),
         'update_phase_ms_per_step': float(np.mean(M.othertime_log[-steps:]) * 1e3),
+        **({'damping_sweep': {'factors': int(len(sweep['damps'])), 'admissible_last_iteration': int(np.sum(np.isfinite(M.sweep_log[-1]['kls']))),
+                              'df_taken_last_iteration': float(M.df_log[-1]) if getattr(M, 'df_log', None) else None}} if sweep else {}),
         'mean_leapfrogs_per_transition': float(M.last_site_stats[:, 2].sum()
                                                / (sites * args.chains * args.siter)),
     }
@@ -797,7 +864,7 @@ def main():
             pass
         del M
         gc.collect()
-        for name, (st_, wm_) in (('c2', (20, 5)), ('c5shard', (1, 1))):
+        for name, (st_, wm_) in (('c2', (20, 5)), ('c5shard', (2, 2))):
             try:
                 t_s = time.perf_counter()
                 sz = CONFIGS[name][:4] + (st_, wm_)
@@ -806,12 +873,14 @@ def main():
                 rf = rec['roofline']
                 keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launch_ms', 'row_passes_per_launch',
                         'gradients_per_launch', 'ns_per_gradient', 'pass_cycles', 'bytes_per_row_pass',
-                        'ns_per_row_pass_per_cu', 'traffic', 'traffic_source')
+                        'ns_per_row_pass_per_cu', 'traffic', 'traffic_over_algorithmic', 'traffic_source', 'algorithmic_bytes_per_launch')
                 out['secondary'].append({
                     'config': rec['config'], 'value': rec['value'], 'unit': rec['unit'], 'steps': st_, 'warmup': wm_,
                     'ms_per_step': rec['ms_per_step'], 'ep_iters_per_sec': rec['ep_iters_per_sec'],
                     'roofline': {k: rf[k] for k in keep if k in rf},
                     'launch_tail': rec['launch_tail'], 'mean_leapfrogs_per_transition': rec['mean_leapfrogs_per_transition'],
+                    **({'damping_sweep': rec['damping_sweep']} if 'damping_sweep' in rec else {}),
+                    'update_phase_ms_per_step': rec['update_phase_ms_per_step'],
                     'wall_s_with_setup': time.perf_counter() - t_s})
                 try:
                     if hasattr(comm2, 'close'):

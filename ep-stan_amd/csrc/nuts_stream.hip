@@ -740,12 +740,14 @@ static int launch_stream_one(const NutsArgs &a, int nblocks, size_t lds, hipStre
 template <int DPB, bool RES>
 static int launch_stream_nv(const NutsArgs &a, int nblocks, int nv, size_t lds, hipStream_t stream) {
     switch (nv) {
+#ifndef EPX_STREAM_MIN      // (scripts/build_stream_variant.sh: A/B builds of the C5 shape only -- NV = 7, DPB = 128 -- in seconds)
     case 1: return launch_stream_one<1, DPB, RES>(a, nblocks, lds, stream);
     case 2: return launch_stream_one<2, DPB, RES>(a, nblocks, lds, stream);
     case 3: return launch_stream_one<3, DPB, RES>(a, nblocks, lds, stream);
     case 4: return launch_stream_one<4, DPB, RES>(a, nblocks, lds, stream);
     case 5: return launch_stream_one<5, DPB, RES>(a, nblocks, lds, stream);
     case 6: return launch_stream_one<6, DPB, RES>(a, nblocks, lds, stream);
+#endif
     case 7: return launch_stream_one<7, DPB, RES>(a, nblocks, lds, stream);
     }
     return -1;
@@ -757,9 +759,11 @@ int launch_nuts_stream(const NutsArgs &a, int count, int dpb, int nv, hipStream_
     const int bps = (a.chains + NCH - 1) / NCH;
     const int nblocks = count * bps;
     const size_t lds = (size_t)a.lds_bytes;          // (the host laid it out: nuts_stream_lds_bytes + the piece words)
+#ifndef EPX_STREAM_MIN
     if (dpb == 16) return launch_stream_nv<16, true>(a, nblocks, nv, lds, stream);
     if (dpb == 32) return launch_stream_nv<32, true>(a, nblocks, nv, lds, stream);
     if (dpb == 64) return launch_stream_nv<64, false>(a, nblocks, nv, lds, stream);
+#endif
     if (dpb == 128) return launch_stream_nv<128, false>(a, nblocks, nv, lds, stream);
     return -1;
 }

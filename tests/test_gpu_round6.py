@@ -50,7 +50,7 @@ def test_teacher_forced_transition_with_more_sites_than_resident_workgroups(layo
 def test_trace_of_a_split_launch_covers_the_lead_sites():
     """epx_set_site_split + epx_set_trace: the lead sites (second launch, layout 2) leave their trace records too, keyed by
     the real site -- the kept tail of every site's trace is its draws, and every transition has a leapfrog count."""
-    K, it, chains = 48, 24, 4
+    K, it, chains = 330, 24, 4               # (enough sites for the library to pick one workgroup per site by itself, as the split needs)
     X, y, k_lim, Oms, mus, d, P = _site_problem('m1b_sg', 4, 30, 5, K=K, tight=30.0)
     eng, _, _ = _engine_with_cavity('m1b_sg', X, y, k_lim, Oms, mus)
     seeds = np.arange(K, dtype=np.int64) + 11
