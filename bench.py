@@ -268,7 +268,7 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
         seq = [site_update([k], min(chains, nthr)) for k in range(n_seq)]
         t_seq = [q[0] for q in seq]
         us_seq = float(np.sum(t_seq)) * 1e6 * min(chains, nthr) / max(float(np.sum([q[1] for q in seq])), 1.0)
-        t_all, g_all, _, _, _, busy_all = site_update(list(range(n_all)), nthr)
+        t_all, g_all, draws_f, _, _, busy_all = site_update(list(range(n_all)), nthr)
     # the compared leg: the strict build (the checker), first n_par sites
     n_par = min(n_par, n_all)
     t_par, g_par, draws_c, stats_c, mom_c, busy_par = site_update(list(range(n_par)), nthr, trace=n_par if snap.get('trace') is not None else 0)
@@ -428,11 +428,43 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
                         'the rounding differences of the two summation orders grow by the factor above per transition until they '
                         'reach 1e-6 or flip a decision: chaos, not a difference of the algorithm -- the first transition, step-size '
                         'search included, agrees to rounding'}
+    # The null reference of those scatters: the FAST CPU build's draws of the same site updates (the timed leg above) against
+    # the strict build's -- two CPU runs of one algorithm that differ in rounding only (contraction, polynomial exp), part
+    # like the device's chains do, and share the random stream with them (common random numbers keep parted chains
+    # coupled: that, not the ESS estimate, is why all these z-scores scatter by LESS than 1).  The device agrees with the
+    # CPU port in distribution if device-vs-strict scatters like fast-vs-strict.
+    def pair_z(A, B):
+        zm, zv = np.zeros((n_all, d)), np.zeros((n_all, d))
+        for k in range(n_all):
+            a_, b_ = A[k][:, :, :d], B[k][:, :, :d]
+            ma, mb = a_.reshape(-1, d).mean(axis=0), b_.reshape(-1, d).mean(axis=0)
+            va, vb = a_.reshape(-1, d).var(axis=0, ddof=1), b_.reshape(-1, d).var(axis=0, ddof=1)
+            for i in range(d):
+                ea, eb = _ess(a_[:, :, i]), _ess(b_[:, :, i])
+                zm[k, i] = (ma[i] - mb[i]) / np.sqrt(0.5 * (va[i] + vb[i]) * (1.0 / ea + 1.0 / eb))
+                zv[k, i] = np.log(va[i] / vb[i]) / np.sqrt(2.0 / ea + 2.0 / eb)
+        return zm, zv
+    null_ref = None
+    if draws_f is not None and len(draws_f) >= n_all and n_all >= 8:
+        zm0, zv0 = pair_z([np.asarray(draws_f[k]) for k in range(n_all)], [np.asarray(draws_c[k]) for k in range(n_all)])
+        null_ref = {'what': 'CPU fast build against CPU strict build, same sites, cavities, starting draws and seeds: what two runs of '
+                            'ONE algorithm that differ in rounding only look like in these statistics',
+                    'tilted_mean_z_pooled': pooled_z(zm0, 'fast-build mean - strict-build mean, in the same units'),
+                    'tilted_log_variance_ratio_z_pooled': pooled_z(zv0, 'log(fast-build variance / strict-build variance), in the same units')}
     pz_m = pooled_z(zs_mean, 'signed (device mean - CPU mean) / sqrt(pooled variance (1/ESS_dev + 1/ESS_cpu)), every coordinate of every compared site')
     pz_v = pooled_z(zs_var, 'log(device variance / CPU variance) / sqrt(2/ESS_dev + 2/ESS_cpu), every coordinate of every compared site')
     # agreement of the two samplers in distribution: no shared bias (|t| of the per-site means), and a scatter that is
     # neither much wider than the Monte-Carlo error (a real difference) nor much narrower (a leg that is not independent)
     pooled_ok = all(abs(q['mean_of_site_means_t_statistic']) <= 4.5 and q['variance'] <= 2.5 for q in (pz_m, pz_v)) if n_all >= 8 else True
+    scatter_ratio = None
+    if null_ref is not None:
+        # device-vs-CPU scatter over the CPU-vs-CPU scatter (variances of the pooled z-scores): ~1 when the device is "one
+        # more run of the same algorithm" (0 when it equals the strict build draw for draw); F-like with ~sites x (effective
+        # coordinates) degrees of freedom each -- a factor of 2 is far outside its noise
+        scatter_ratio = {'means': pz_m['variance'] / max(null_ref['tilted_mean_z_pooled']['variance'], 1e-300),
+                         'log_variance_ratios': pz_v['variance'] / max(null_ref['tilted_log_variance_ratio_z_pooled']['variance'], 1e-300)}
+        pooled_ok = pooled_ok and all(v <= 2.0 for v in scatter_ratio.values()) \
+            and all(abs(null_ref[q]['mean_of_site_means_t_statistic']) <= 4.5 for q in ('tilted_mean_z_pooled', 'tilted_log_variance_ratio_z_pooled'))
     parity = {
         'what': 'the EP iteration behind the timed ones, sites 0..%d: device (the timed kernel, piece queue and all) against the '
                 'CPU port from the same cavities, starting draws and Stan seeds' % (n_all - 1),
@@ -452,6 +484,7 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
                                'share_within_tolerance': float(np.mean(rel_cov <= tol_cov))},
         # the whole distribution of the z-scores, not only their tails
         'tilted_mean_z_pooled': pz_m, 'tilted_log_variance_ratio_z_pooled': pz_v,
+        'null_reference_cpu_fast_vs_cpu_strict': null_ref, 'scatter_device_vs_cpu_over_cpu_vs_cpu': scatter_ratio,
         'site_delta_vs_numpy_moment_stage_max_rel_err': float(np.max(dq_rel)),
         'global_moments_with_cpu_deltas_for_these_sites': glob,
         'transition_by_transition': by_t,
@@ -459,7 +492,8 @@ def cpu_leg(M, snap, estim, chains, siter, n_seq, threads, df, n_par, limits=Non
                      'tilted variances within 4 sqrt(2/ESS_dev + 2/ESS_cpu) relative (SURVEY.md section 8c; ESS by Geyer\'s '
                      'initial positive sequence over the %d chains); pooled over all coordinates of all compared sites the signed '
                      'z-scores of means and log variance ratios must have |t| <= 4.5 for the mean of the per-site means and a '
-                     'variance <= 2.5 (N(0, 1) expected; from 8 sites on); site delta from the device\'s own draws against the NumPy '
+                     'variance <= 2.5 (N(0, 1) expected; from 8 sites on), and their variances must not exceed twice the '
+                     'same statistics between the two CPU builds (the null reference: rounding-only differences); site delta from the device\'s own draws against the NumPy '
                      'moment stage: 1e-7; transition by transition: >= 90 %% of the chains equal through the first transition (step-size '
                      'search included), its draws and adapted step sizes within 1e-6' % chains,
         'ok': bool((tf is None or tf['max_rel_err'] < 1e-6) and np.mean(z_mean <= 4.0) >= 0.99 and pooled_ok

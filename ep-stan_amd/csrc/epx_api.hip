@@ -762,6 +762,8 @@ static int run_sampler(epx_ctx *c, int k0, int count, const int64_t *seeds, cons
         a.dyn_rate = (c->dyn_has_rate && !hook) ? c->dyn_rate : nullptr;
         a.dyn_len = hook ? 1 : c->dyn_len; a.dyn_count = count;
         a.dyn_hook = hook ? 1 : 0;
+        a.dyn_wait_s = EPX_PIECE_WAIT_S;
+        if (const char *we = getenv("EPX_PIECE_WAIT_S")) { const int v = atoi(we); if (v > 0) a.dyn_wait_s = v; }
         if (!c->dyn_lens_d) HIPCHK(dalloc(&c->dyn_lens_d, (size_t)c->K));
         HIPCHK(hipMemcpyAsync(c->dyn_lens_d, lens_h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));            // (lens_h is a local)

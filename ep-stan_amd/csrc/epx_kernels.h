@@ -101,6 +101,12 @@ enum { ST_STEPSIZE_MEAN = 0, ST_STEPSIZE_FINAL, ST_NLEAP, ST_NGRAD, ST_NDIV, ST_
        ST_DEPTH_MEAN, ST_FAIL, ST_COUNT };
 enum { K_INIT = 0, K_MOM = 1, K_DIR = 2, K_TOP = 3, K_MERGE = 4, K_SSMOM = 5 };
 enum { MAX_DEPTH_CAP = 12 };
+// seconds a workgroup of a pieced launch looks for a site before it reports a lost piece (epx_pieces.h); the environment
+// variable of the same name overrides it at run time (NutsArgs::dyn_wait_s)
+#ifndef EPX_PIECE_WAIT_S
+#define EPX_PIECE_WAIT_S 60
+#endif
+
 // columns of zeros behind the last site's cavity precision (epx_api.hip allocates them): the streaming sampler's register
 // ring reads up to OM_UNROLL columns past a site's Omega (nuts_stream.hip)
 enum { EPX_OM_PAD_COLS = 64 };
@@ -195,6 +201,7 @@ struct NutsArgs {
     int dyn_nb;                   // checkpoint records (piece boundaries) reserved per site
     int dyn_tail_div;             // the pieces behind 3/4 of a site's run are 1/dyn_tail_div of the nominal length (epx_pieces.h)
     int dyn_hook;                 // epx_sample_piece: a site is released as FINISHED behind its one transition (never claimable twice)
+    int dyn_wait_s;               // seconds a workgroup looks for a site before it reports a lost piece (EPX_PIECE_WAIT_S; epx_pieces.h)
 };
 
 // launch wrapper implemented in nuts.hip; returns hipError_t as int

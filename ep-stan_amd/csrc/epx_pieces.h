@@ -101,7 +101,10 @@ __device__ __forceinline__ double *piece_record(Args &a, int site, int t_boundar
 // Claim a site (all threads of the workgroup; the LDS must not hold anything yet: smem[0..1100) is scratch, and
 // (site, first transition) stay at smem + off_piece for piece_release).  Returns 1 with a site, 0 when every site of the
 // launch has run all its transitions (a persistent workgroup's way out), -1 after EPX_PIECE_WAIT_S seconds without a site
-// (never seen; the caller reports it and the host call fails with an error).
+// (never seen on a device of its own; the caller reports it and the host call fails with an error.  The limit is wall time:
+// when several PROCESSES share one device -- the multi-rank tests on a one-GPU box -- the driver may park a workgroup that
+// holds a site for as long as the other process's launch lasts, tens of seconds; such runs raise it, EPX_PIECE_WAIT_S in
+// the environment -> NutsArgs::dyn_wait_s).
 template <class Args>
 __device__ __forceinline__ int piece_claim(Args &a, unsigned char *smem, int tid, int &q_site, int &q_t0) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +152,7 @@ __device__ __forceinline__ int piece_claim(Args &a, unsigned char *smem, int tid
                 t0_got = expect >> 1;                      // (the progress that was claimed: same word, same instant)
             }
             // (thread 0 decides for the workgroup when to give up: every thread must leave the loop in the same round)
-            if (got < 0 && __builtin_amdgcn_s_memrealtime() - t_claim0 > (unsigned long long)EPX_PIECE_WAIT_S * 100000000ull) got = -3;
+            if (got < 0 && __builtin_amdgcn_s_memrealtime() - t_claim0 > (unsigned long long)(a.dyn_wait_s > 0 ? a.dyn_wait_s : EPX_PIECE_WAIT_S) * 100000000ull) got = -3;
             si[32] = got;
             if (got >= 0) {
                 si[33] = t0_got;

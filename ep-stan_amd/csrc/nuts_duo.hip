@@ -82,6 +82,16 @@ __device__ inline void wave_lds_exchange() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Between the steps of the state wave's relay (one wave writes a scratch line in one lane order and reads it back in
+// another): -DEPX_RELAY_NOWAIT (A/B) keeps only the compiler from reordering -- the LDS executes one wave's accesses in
+// issue order -- instead of draining the wave's LDS operations at every step.
+__device__ inline void relay_step() {
+#ifdef EPX_RELAY_NOWAIT
+    asm volatile("" ::: "memory");
+#else
+    wave_lds_exchange();
+#endif
+}
 // The TEAM form's hand-off: every wave of the workgroup is in lock step with the passes anyway, so "the jobs are in"
 // and "the results are in" are the two s_barriers of a pass (LDS traffic drained first; vector-memory operations stay
 // in flight).  A waiting wave is parked by the hardware: no polls on the SIMD its partner computes on, no wake-up latency.
@@ -1415,25 +1425,25 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     const double lp2 = laplace ? -fabs(q2o) : -0.5 * q2o * q2o;
                     duo_lds_f64 *scr = duo_lds_at(smem + a.off_scr) + team * a.scr_doubles;
                     if (v_lane) { scr[ve1] = q1o; scr[ve2] = q2o; scr[ve3] = q3o; }
-                    wave_lds_exchange();
+                    relay_step();
                     // (the line holds the P live elements; what lies beyond is 0 by definition)
                     const int scr_n = a.scr_doubles;
 #define EPX_SCR(i_) (lane + 64 * (i_) < scr_n ? scr[lane + 64 * (i_) < scr_n ? lane + 64 * (i_) : 0] : 0.0)
                     FORV zq.v[i] = EPX_SCR(i);
-                    wave_lds_exchange();
+                    relay_step();
                     if (v_lane) { scr[ve1] = fp1; scr[ve2] = fp2; scr[ve3] = fp3; }
-                    wave_lds_exchange();
+                    relay_step();
                     FORV zp.v[i] = EPX_SCR(i);
-                    wave_lds_exchange();
+                    relay_step();
                     if (v_lane) { scr[ve1] = g1; scr[ve2] = g2; scr[ve3] = g3; }
-                    wave_lds_exchange();
+                    relay_step();
                     FORV zg.v[i] = EPX_SCR(i);
-                    wave_lds_exchange();
+                    relay_step();
                     if (v_lane) { scr[ve1] = lp1; scr[ve2] = lp2; scr[ve3] = lp3; }
-                    wave_lds_exchange();
+                    relay_step();
                     double lpt = 0.0, ks = 0.0;
                     FORV { lpt += EPX_SCR(i); ks += inv_e.v[i] * zp.v[i] * zp.v[i]; }
-                    wave_lds_exchange();
+                    relay_step();
 #undef EPX_SCR
                     f_lpt = lpt; f_ks = ks; f_ll = uniform_d(ll);
                     pending = true;
