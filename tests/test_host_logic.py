@@ -649,3 +649,20 @@ def test_row_dma_reads_its_scalar_base_five_wait_states_behind_readfirstlane(tmp
         assert len(loads) == 16                        # the 16 pieces of a full tile, every later one behind an M0 update + s_nop
         checked += 1
     assert checked >= 1
+
+
+def test_pooled_z_statistics_see_a_shared_bias_that_per_coordinate_bounds_miss():
+    """bench.pooled_z (the statistical leg of the parity record): z-scores that all stay within 4
+    but share a bias of 0.3 standard errors give a large t-statistic of the per-site means; unbiased ones do not."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rng = np.random.RandomState(3)
+    z0 = rng.randn(32, 66)
+    z1 = z0 + 0.3
+    a, b = bench.pooled_z(z0, 'unbiased'), bench.pooled_z(z1, 'biased')
+    assert np.abs(z1).max() < 4.5                                   # "share_within_4" would pass both
+    assert abs(a['mean_of_site_means_t_statistic']) < 3.5 and abs(b['mean_of_site_means_t_statistic']) > 8.0
+    assert 0.85 < a['variance'] < 1.15 and 0.01 < a['chi2_p_value_nominal'] < 0.99
+    assert a['n'] == 32 * 66 and a['sites'] == 32
+    # a scatter twice as wide as expected is far outside the chi-square's noise
+    assert bench.pooled_z(2.0 * z0, 'wide')['chi2_p_value_nominal'] < 1e-6
