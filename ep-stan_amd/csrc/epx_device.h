@@ -258,35 +258,55 @@ __device__ inline void merge_weights(double a, double b, double &lse, double &p_
 // The kernel is bound by instruction issue, and the library exp/log1p cost ~250
 // instructions per logistic term (extended-precision internals); these are
 // ~1e-16 relative (checked against the oracle's libm in the gradient tests) in ~60.
+// v_rcp_f64 is good to 2^-24.4 (scripts/probe/rcp_accuracy.hip, profiles/r06_rcp_f64_accuracy.txt).  One THIRD-order
+// step behind it -- t = 1 - x r, r (1 + t + t^2): truncation t^3 ~ 1e-22 -- takes three FMAs where two Newton steps took
+// four, and rounds as well (round 6; the logistic pair is the row phase's instruction count).
 __device__ inline double rcp_d(double x) {            // 1/x, x finite and normal
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double t = fma(-x, r, 1.0);
+    return fma(r, fma(t, t, t), r);
 }
+
+// exp(r) on |r| <= ln2 / 2 (+ the slack of the two-constant range reduction): Chebyshev interpolant of degree 11 on
+// [-0.3466, 0.3466] in the monomial basis, computed in 60-digit arithmetic (scripts/exp_minimax.py: approximation error
+// 4.2e-18 relative; the double-precision Horner form errs by 2.2e-16, exactly as the degree-13 Taylor form did).
+// c1 = c0 = 1 to the last bit.  ONE list: exp_d, exp_d_vc and the logistic pairs below evaluate the same polynomial in
+// the same order, so they agree bit for bit with one another.
+#define EPX_EXP_MAGIC 6755399441055744.0       /* 1.5 * 2^52 */
+#define EPX_EXP_C11 2.5110046444457486e-08
+#define EPX_EXP_C10 2.7632651132874099e-07
+#define EPX_EXP_C9 2.7557240894691074e-06
+#define EPX_EXP_C8 2.4801485451264055e-05
+#define EPX_EXP_C7 0.00019841269890069431
+#define EPX_EXP_C6 0.0013888888952343797
+#define EPX_EXP_C5 0.0083333333333195925
+#define EPX_EXP_C4 0.041666666666487988
+#define EPX_EXP_C3 0.1666666666666668
+#define EPX_EXP_C2 0.50000000000000189
 
 __device__ inline double exp_d(double x) {
     const double xc = fmin(fmax(x, -800.0), 800.0);   // keeps k*ln2 finite; ldexp saturates to 0 / inf
-    const double kf = __builtin_rint(xc * 1.4426950408889634074);
+    // k = round(x / ln2) by the magic-number form: x log2(e) + 1.5 * 2^52 (one FMA, rounded once) has k in its low mantissa
+    // bits -- as an integer for ldexp WITHOUT a conversion instruction -- and kf = that minus the constant (round 6)
+    const double kt = fma(xc, 1.4426950408889634074, EPX_EXP_MAGIC);
+    const double kf = kt - EPX_EXP_MAGIC;
     double r = fma(kf, -6.93147180369123816490e-01, xc);
     r = fma(kf, -1.90821492927058770002e-10, r);
-    // |r| <= 0.3466: Taylor to r^13 (remainder 4e-18)
-    double p = 1.6059043836821613e-10;                // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);              // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);             // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);             // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);            // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);              // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);             // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);             // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);             // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);            // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);            // 1/3!
-    p = fma(p, r, 0.5);
+    // |r| <= 0.3466: the degree-11 near-minimax polynomial (EPX_EXP_C*, above: 4.2e-18, the accuracy of the Taylor form
+    // to r^13 it replaced in round 6, two steps shorter)
+    double p = EPX_EXP_C11;
+    p = fma(p, r, EPX_EXP_C10);
+    p = fma(p, r, EPX_EXP_C9);
+    p = fma(p, r, EPX_EXP_C8);
+    p = fma(p, r, EPX_EXP_C7);
+    p = fma(p, r, EPX_EXP_C6);
+    p = fma(p, r, EPX_EXP_C5);
+    p = fma(p, r, EPX_EXP_C4);
+    p = fma(p, r, EPX_EXP_C3);
+    p = fma(p, r, EPX_EXP_C2);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double res = ldexp(p, (int)kf);
+    const double res = ldexp(p, __double2loint(kt));
     return (x != x) ? x : res;                        // NaN in, NaN out
 }
 
@@ -370,24 +390,21 @@ __device__ inline void logistic_split2(double fa, double fb, double ya, double y
                                        double &wa, double &wb, double &ga, double &gb) {
     const double xa = -fabs(fa), xb = -fabs(fb);
     const double ca = fmin(fmax(xa, -800.0), 800.0), cb = fmin(fmax(xb, -800.0), 800.0);
-    const double ka = __builtin_rint(ca * 1.4426950408889634074), kb = __builtin_rint(cb * 1.4426950408889634074);
+    const double kta = fma(ca, 1.4426950408889634074, EPX_EXP_MAGIC), ktb = fma(cb, 1.4426950408889634074, EPX_EXP_MAGIC);
+    const double ka = kta - EPX_EXP_MAGIC, kb = ktb - EPX_EXP_MAGIC;          // (exp_d's magic-number rounding)
     double ra = fma(ka, -6.93147180369123816490e-01, ca), rb = fma(kb, -6.93147180369123816490e-01, cb);
     ra = fma(ka, -1.90821492927058770002e-10, ra); rb = fma(kb, -1.90821492927058770002e-10, rb);
-    double pa = 1.6059043836821613e-10, pb = 1.6059043836821613e-10;
+    double pa = EPX_EXP_C11, pb = EPX_EXP_C11;
 #define EPX_STEP2(c) pa = fma(pa, ra, c); pb = fma(pb, rb, c); __builtin_amdgcn_sched_barrier(0)
-    EPX_STEP2(2.08767569878681e-09); EPX_STEP2(2.505210838544172e-08); EPX_STEP2(2.755731922398589e-07);
-    EPX_STEP2(2.7557319223985893e-06); EPX_STEP2(2.48015873015873e-05); EPX_STEP2(1.984126984126984e-04);
-    EPX_STEP2(1.388888888888889e-03); EPX_STEP2(8.333333333333333e-03); EPX_STEP2(4.1666666666666664e-02);
-    EPX_STEP2(1.6666666666666666e-01); EPX_STEP2(0.5); EPX_STEP2(1.0); EPX_STEP2(1.0);
+    EPX_STEP2(EPX_EXP_C10); EPX_STEP2(EPX_EXP_C9); EPX_STEP2(EPX_EXP_C8); EPX_STEP2(EPX_EXP_C7); EPX_STEP2(EPX_EXP_C6);
+    EPX_STEP2(EPX_EXP_C5); EPX_STEP2(EPX_EXP_C4); EPX_STEP2(EPX_EXP_C3); EPX_STEP2(EPX_EXP_C2); EPX_STEP2(1.0); EPX_STEP2(1.0);
 #undef EPX_STEP2
-    double ea = ldexp(pa, (int)ka), eb = ldexp(pb, (int)kb);
+    double ea = ldexp(pa, __double2loint(kta)), eb = ldexp(pb, __double2loint(ktb));
     ea = (xa != xa) ? xa : ea; eb = (xb != xb) ? xb : eb;
     wa = 1.0 + ea; wb = 1.0 + eb;
     double qa = __builtin_amdgcn_rcp(wa), qb = __builtin_amdgcn_rcp(wb);
-    double ta = fma(-wa, qa, 1.0), tb = fma(-wb, qb, 1.0);
-    qa = fma(qa, ta, qa); qb = fma(qb, tb, qb);
-    ta = fma(-wa, qa, 1.0); tb = fma(-wb, qb, 1.0);
-    qa = fma(qa, ta, qa); qb = fma(qb, tb, qb);
+    const double ta = fma(-wa, qa, 1.0), tb = fma(-wb, qb, 1.0);          // (rcp_d's third-order step, two at a time)
+    qa = fma(qa, fma(ta, ta, ta), qa); qb = fma(qb, fma(tb, tb, tb), qb);
     const double sa = (fa >= 0) ? qa : ea * qa, sb = (fb >= 0) ? qb : eb * qb;
     lina = ya * fa - fmax(fa, 0.0); linb = yb * fb - fmax(fb, 0.0);
     ga = ya - sa; gb = yb - sb;
@@ -395,7 +412,7 @@ __device__ inline void logistic_split2(double fa, double fb, double ya, double y
 
 // The same two logistic terms without the not-a-number select behind the exponential: a non-finite argument still
 // shows in `lin` (y f - max(f, 0)), which is how the row team's caller learns of it -- through the log density.
-__device__ inline void logistic_pair_lean(double fa, double fb, double ya, double yb, double &lina, double &linb,
+__device__ inline void logistic_pair_lean(double fa, double fb, double nha, double nhb, double &lina, double &linb,
                                           double &wa, double &wb, double &ga, double &gb) {
     // -|f| clamped at -800 by ONE instruction (same value as fmin(fmax(-|f|, -800), 800): the compiler's form of it
     // canonicalises -|f| with a v_max of its own first and keeps the idle upper clamp: three instructions)
@@ -407,26 +424,31 @@ __device__ inline void logistic_pair_lean(double fa, double fb, double ya, doubl
     double ca, cb;
     const double lim = -800.0;
     asm("s_nop 5\n\tv_max_f64 %0, -|%2|, %4\n\tv_max_f64 %1, -|%3|, %4" : "=&v"(ca), "=&v"(cb) : "v"(fa), "v"(fb), "s"(lim));
-    const double ka = __builtin_rint(ca * 1.4426950408889634074), kb = __builtin_rint(cb * 1.4426950408889634074);
+    const double kta = fma(ca, 1.4426950408889634074, EPX_EXP_MAGIC), ktb = fma(cb, 1.4426950408889634074, EPX_EXP_MAGIC);
+    const double ka = kta - EPX_EXP_MAGIC, kb = ktb - EPX_EXP_MAGIC;          // (exp_d's magic-number rounding)
     double ra = fma(ka, -6.93147180369123816490e-01, ca), rb = fma(kb, -6.93147180369123816490e-01, cb);
     ra = fma(ka, -1.90821492927058770002e-10, ra); rb = fma(kb, -1.90821492927058770002e-10, rb);
-    double pa = 1.6059043836821613e-10, pb = 1.6059043836821613e-10;
+    double pa = EPX_EXP_C11, pb = EPX_EXP_C11;
 #define EPX_STEP2(c) pa = fma(pa, ra, c); pb = fma(pb, rb, c); __builtin_amdgcn_sched_barrier(0)
-    EPX_STEP2(2.08767569878681e-09); EPX_STEP2(2.505210838544172e-08); EPX_STEP2(2.755731922398589e-07);
-    EPX_STEP2(2.7557319223985893e-06); EPX_STEP2(2.48015873015873e-05); EPX_STEP2(1.984126984126984e-04);
-    EPX_STEP2(1.388888888888889e-03); EPX_STEP2(8.333333333333333e-03); EPX_STEP2(4.1666666666666664e-02);
-    EPX_STEP2(1.6666666666666666e-01); EPX_STEP2(0.5); EPX_STEP2(1.0); EPX_STEP2(1.0);
+    EPX_STEP2(EPX_EXP_C10); EPX_STEP2(EPX_EXP_C9); EPX_STEP2(EPX_EXP_C8); EPX_STEP2(EPX_EXP_C7); EPX_STEP2(EPX_EXP_C6);
+    EPX_STEP2(EPX_EXP_C5); EPX_STEP2(EPX_EXP_C4); EPX_STEP2(EPX_EXP_C3); EPX_STEP2(EPX_EXP_C2); EPX_STEP2(1.0); EPX_STEP2(1.0);
 #undef EPX_STEP2
-    const double ea = ldexp(pa, (int)ka), eb = ldexp(pb, (int)kb);
+    const double ea = ldexp(pa, __double2loint(kta)), eb = ldexp(pb, __double2loint(ktb));
     wa = 1.0 + ea; wb = 1.0 + eb;
     double qa = __builtin_amdgcn_rcp(wa), qb = __builtin_amdgcn_rcp(wb);
-    double ta = fma(-wa, qa, 1.0), tb = fma(-wb, qb, 1.0);
-    qa = fma(qa, ta, qa); qb = fma(qb, tb, qb);
-    ta = fma(-wa, qa, 1.0); tb = fma(-wb, qb, 1.0);
-    qa = fma(qa, ta, qa); qb = fma(qb, tb, qb);
-    const double sa = (fa >= 0) ? qa : ea * qa, sb = (fb >= 0) ? qb : eb * qb;
-    lina = ya * fa - fmax(fa, 0.0); linb = yb * fb - fmax(fb, 0.0);
-    ga = ya - sa; gb = yb - sb;
+    const double ta = fma(-wa, qa, 1.0), tb = fma(-wb, qb, 1.0);          // (rcp_d's third-order step, two at a time)
+    qa = fma(qa, fma(ta, ta, ta), qa); qb = fma(qb, fma(tb, tb, tb), qb);
+    // The responses arrive as nh = 1/2 - y (+1/2 for y = 0, -1/2 for y = 1: two bit operations from the row's bit, as
+    // many as the conversion to 0.0 / 1.0 took).  sigmoid(f) - 1/2 is odd in f and q = sigmoid(|f|), so
+    //     y - sigmoid(f) = -nh - copysign(q - 1/2, f)          (q - 1/2 is exact: q in [1/2, 1])
+    // is a subtraction, a sign transfer and an addition where the selected form (f >= 0 ? q : e q, then y - s) took a
+    // product, a comparison, two conditional moves and a subtraction; and  y f - max(f, 0) = -nh f - |f| / 2  exactly
+    // (round 6).  The residual of a row with f << 0 now carries q's ABSOLUTE rounding error (1e-16) instead of a relative
+    // one -- the size of the rounding of the sums it enters.
+    const double ha = qa - 0.5, hb = qb - 0.5;
+    lina = fma(-nha, fa, -0.5 * fabs(fa)); linb = fma(-nhb, fb, -0.5 * fabs(fb));
+    ga = -nha - __builtin_copysign(ha, fa); gb = -nhb - __builtin_copysign(hb, fb);
+    (void)ea; (void)eb;
 }
 
 // p * x + c as the three-address instruction, whatever register class the compiler found for the constant: where the
@@ -441,16 +463,16 @@ __device__ inline double fma_vc(double p, double x, double c) {
 // exp_d, bit for bit, with those steps (the state wave's view update: the exponential sits on the critical stretch)
 __device__ inline double exp_d_vc(double x) {
     const double xc = fmin(fmax(x, -800.0), 800.0);
-    const double kf = __builtin_rint(xc * 1.4426950408889634074);
+    const double kt = fma(xc, 1.4426950408889634074, EPX_EXP_MAGIC);
+    const double kf = kt - EPX_EXP_MAGIC;
     double r = fma(kf, -6.93147180369123816490e-01, xc);
     r = fma(kf, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;
-    p = fma_vc(p, r, 2.08767569878681e-09); p = fma_vc(p, r, 2.505210838544172e-08); p = fma_vc(p, r, 2.755731922398589e-07);
-    p = fma_vc(p, r, 2.7557319223985893e-06); p = fma_vc(p, r, 2.48015873015873e-05); p = fma_vc(p, r, 1.984126984126984e-04);
-    p = fma_vc(p, r, 1.388888888888889e-03); p = fma_vc(p, r, 8.333333333333333e-03); p = fma_vc(p, r, 4.1666666666666664e-02);
-    p = fma_vc(p, r, 1.6666666666666666e-01);
-    p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
-    const double res = ldexp(p, (int)kf);
+    double p = EPX_EXP_C11;
+    p = fma_vc(p, r, EPX_EXP_C10); p = fma_vc(p, r, EPX_EXP_C9); p = fma_vc(p, r, EPX_EXP_C8); p = fma_vc(p, r, EPX_EXP_C7);
+    p = fma_vc(p, r, EPX_EXP_C6); p = fma_vc(p, r, EPX_EXP_C5); p = fma_vc(p, r, EPX_EXP_C4); p = fma_vc(p, r, EPX_EXP_C3);
+    p = fma_vc(p, r, EPX_EXP_C2);
+    p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    const double res = ldexp(p, __double2loint(kt));
     return (x != x) ? x : res;
 }
 // log_ge1_d, bit for bit, with those steps (the row team's one logarithm per pass)

@@ -486,7 +486,7 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
 #pragma unroll
                 for (int r = 0; r < NRD; ++r) { pf[r] = reinterpret_cast<lds_v2f64_p>((uintptr_t)af[r]); pb[r] = reinterpret_cast<lds_v2f64_p>((uintptr_t)ab[r]); }
                 constexpr int TILEV = TILEB / 16;              // a tile in 16-byte units
-                auto do_round = [&](const int t, const double y0, const double y1) {
+                auto do_round = [&](const int t, const double y0, const double y1) {       // (y0, y1: 1/2 - y of the lane's row in either tile)
                     double f0 = alpha_c, f1 = alpha_c;
 #pragma unroll
                     for (int r = 0; r < NRD; ++r) {
@@ -536,7 +536,9 @@ __device__ __forceinline__ void duo_piece(DuoArgsK *kargs_p, int tid, bool queue
                     // spilled registers -- the cavity operands, reloaded from scratch at the top of every pass)
                     unsigned yb = ybits;
                     for (int t = t0; t < t1; t += 2, yb >>= 2) {
-                        do_round(t, (double)(yb & 1u), (double)((yb >> 1) & 1u));
+                        // 1/2 - y as a double, from the row's bit: sign = the bit, the rest 0x3FE00000'00000000
+                        do_round(t, __hiloint2double((int)((yb << 31) | 0x3FE00000u), 0),
+                                 __hiloint2double((int)(((yb << 30) & 0x80000000u) | 0x3FE00000u), 0));
 #pragma unroll
                         for (int r = 0; r < NRD; ++r) { pf[r] += 2 * TILEV; pb[r] += 2 * TILEV; }
                     }
